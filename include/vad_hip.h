@@ -1,0 +1,163 @@
+/* vad_hip.h — C ABI of libvad_hip.so: the MI355X (gfx950) per-frame anomaly-scoring hot path.
+ *
+ * The reference (KuldeepChoksi/video-anomaly-detection) has no FFI: its boundary is the Python
+ * nn.Module API of models/.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference root).  Everything is plain pointers and sizes; `stream` is a
+ * hipStream_t passed as void*.  All device pointers are fp32 unless stated.  Calls are
+ * asynchronous on `stream`, never allocate and never synchronise (except vad_prof_read).
+ *
+ * Return value: VAD_OK or a negative VAD_ERR_*; vad_last_error() gives the text.
+ */
+#ifndef VAD_HIP_H
+#define VAD_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAD_ABI_VERSION 1
+#define VAD_OK 0
+#define VAD_ERR_ARG (-1)   /* bad argument / unsupported shape */
+#define VAD_ERR_HIP (-2)   /* HIP runtime error */
+#define VAD_ERR_WS (-3)    /* workspace too small */
+
+#define VAD_ACT_NONE 0
+#define VAD_ACT_LEAKY 1    /* LeakyReLU(0.2): models/autoencoder.py:41, models/video_autoencoder.py:195 */
+#define VAD_ACT_RELU 2     /* ReLU: models/autoencoder.py:106 */
+
+int vad_abi_version(void);
+const char* vad_last_error(void);
+
+/* ------------------------------------------------------------------ weight packing (host, CPU)
+ * Folds eval-mode BatchNorm2d (eps 1e-5; y = (x-mean)/sqrt(var+eps)*gamma+beta) into the preceding
+ * conv in fp64, rounds once to fp32 and re-orders for the kernels' MFMA B-operand loads.
+ * bn == NULL means "no BatchNorm after this conv"; bn = {gamma, beta, running_mean, running_var}. */
+
+/* Conv2d k3 p1 weight OIHW (Cout,Cin,3,3) -> [9][ceil(Cin/8)][Cout][8]; bias_out[Cout].
+ * Replaces nn.Conv2d+nn.BatchNorm2d pairs of models/autoencoder.py:38-79,103-139 and
+ * models/video_autoencoder.py:46-52,191-215. */
+size_t vad_pack_conv3x3_floats(int cout, int cin);
+int vad_pack_conv3x3(const float* w_oihw, const float* bias, const float* const* bn,
+                     int cout, int cin, float* w_packed, float* bias_out);
+
+/* First-layer form (Cin == 3, K = 27 padded to 28): -> [14][2][Cout]. */
+size_t vad_pack_conv3x3_c3_floats(int cout);
+int vad_pack_conv3x3_c3(const float* w_oihw, const float* bias, const float* const* bn,
+                        int cout, float* w_packed, float* bias_out);
+
+/* ConvTranspose2d k2 s2 weight IOHW (Cin,Cout,2,2) -> [4][Cin/8][Cout][8] (quadrant q = 2*a+b).
+ * Replaces models/autoencoder.py:104,113,122,131 and models/video_autoencoder.py:244-260. */
+size_t vad_pack_convt2x2_floats(int cin, int cout);
+int vad_pack_convt2x2(const float* w_iohw, const float* bias, const float* const* bn,
+                      int cin, int cout, float* w_packed, float* bias_out);
+
+/* Conv2d k1 (VideoAutoencoder.proj, models/video_autoencoder.py:311) -> [Cin/8][Cout][8]. */
+size_t vad_pack_conv1x1_floats(int cout, int cin);
+int vad_pack_conv1x1(const float* w_oihw, const float* bias, int cout, int cin,
+                     float* w_packed, float* bias_out);
+
+/* ------------------------------------------------------------------ layer kernels (device)
+ * Activations are NHWC fp32.  H, W are the INPUT spatial size.  *_fs = frame stride in floats
+ * (0 means dense: H*W*C of that tensor). */
+
+/* x NCHW [N,3,H,W] -> conv3x3(3->Cout)+bias+act(+maxpool2) -> NHWC.  Cout multiple of 32. */
+int vad_conv3x3_c3(const float* x_nchw, const float* w_packed, const float* bias, float* out_nhwc,
+                   int n, int h, int w, int cout, int act, int pool, void* stream);
+
+/* NHWC conv3x3 p1 + bias + act (+ MaxPool2d(2,2) when pool != 0).  Cin multiple of 8 (32 for
+ * speed), Cout multiple of 32.  pool needs even H, W. */
+int vad_conv3x3(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
+                float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,
+                int act, int pool, void* stream);
+
+/* NHWC ConvTranspose2d k2 s2 + bias + act: [N,H,W,Cin] -> [N,2H,2W,Cout]. */
+int vad_convt2x2(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
+                 float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,
+                 int act, void* stream);
+
+/* NHWC 1x1 conv + bias (no activation). */
+int vad_conv1x1(const float* in_nhwc, const float* w_packed, const float* bias, float* out_nhwc,
+                long long npix, int cin, int cout, void* stream);
+
+/* One ConvLSTMCell step (models/video_autoencoder.py:54-85), gates fused in the conv epilogue.
+ * w_packed = vad_pack_conv3x3 of the (4*hid, cin_x+hid, 3, 3) weight.  x [N,H,W,cin_x] (frame
+ * stride x_fs), h_prev [N,H,W,hid] (frame stride h_prev_fs), c_prev dense (both NULL mean zeros,
+ * models/video_autoencoder.py:87-91).  Writes h_out (frame stride h_out_fs) and c_out (dense;
+ * may alias c_prev). */
+int vad_convlstm_step(const float* x, long long x_fs, const float* h_prev, long long h_prev_fs,
+                      const float* c_prev, const float* w_packed, const float* bias, float* h_out, long long h_out_fs,
+                      float* c_out, int n, int h, int w, int cin_x, int hid, void* stream);
+
+/* Scoring tails.  x is the ORIGINAL input, NCHW [N,3,H2,W2] with H2 = output size.
+ * partials: [N][vad_score_partials(H2,W2)] per-tile sums of sum_c (x-recon)^2.
+ * recon_nchw (NCHW [N,3,H2,W2]) and errmap ([N,H2,W2], channel mean) may be NULL.
+ * Replaces models/autoencoder.py:211-221 and models/video_autoencoder.py:368-384. */
+int vad_score_partials(int kind /*0: conv3x3 tail, 1: convT tail*/, int h2, int w2);
+/* Conv2d(cin->3) weight OIHW (3,cin,3,3) -> [9][cin][4] (4th lane zero) for wave-uniform loads. */
+size_t vad_pack_conv3x3_to3_floats(int cin);
+int vad_pack_conv3x3_to3(const float* w_oihw, int cin, float* w_packed);
+/* Conv2d(32->3) k3 p1 + Tanh (models/autoencoder.py:134-135) on NHWC [N,H2,W2,32]. */
+int vad_conv3x3_to3_score(const float* in_nhwc, const float* w_packed /*vad_pack_conv3x3_to3*/,
+                          const float* bias3, const float* x_nchw, float* partials,
+                          float* recon_nchw, float* errmap, int n, int h2, int w2, int cin,
+                          void* stream);
+/* ConvTranspose2d(32->3) k2 s2 + Tanh (models/video_autoencoder.py:259-260) on NHWC [N,H,W,32]. */
+int vad_convt2x2_to3_score(const float* in_nhwc, const float* w_iohw /*[cin][3][2][2]*/,
+                           const float* bias3, const float* x_nchw, float* partials,
+                           float* recon_nchw, float* errmap, int n, int h, int w, int cin,
+                           void* stream);
+/* frame_scores[N] = sum(partials[n][:]) / (3*H2*W2) in a fixed order (bit-exact under any
+ * batching); if seq_scores != NULL also seq_scores[N/t] = mean over t consecutive frames. */
+int vad_score_finalize(const float* partials, int nparts, int n, int h2, int w2,
+                       float* frame_scores, float* seq_scores, int t, void* stream);
+
+int vad_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, void* stream);
+int vad_nchw_to_nhwc(const float* in, float* out, int n, int h, int w, int c, void* stream);
+
+/* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1]. */
+int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_frame, long long n,
+                     int c, int h, int w, int anomalies, void* stream);
+
+/* ------------------------------------------------------------------ whole-model scoring
+ * Image autoencoder.  Replaces ConvAutoencoder.forward / get_latent / get_reconstruction_error
+ * (models/autoencoder.py:181-221) as driven by evaluate.compute_auroc (evaluate.py:56-64).
+ * params: VAD_IMG_NPARAMS host pointers in state_dict order with num_batches_tracked removed. */
+#define VAD_IMG_NPARAMS 92
+size_t vad_img_packed_floats(int in_ch, int latent);
+int vad_img_pack(const float* const* params, int nparams, int in_ch, int latent, float* packed_host);
+size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent);
+/* x NCHW [B,3,H,W] on device.  Frames are processed in chunks of `chunk` through `workspace`.
+ * Outputs (device, any may be NULL): scores [B]; errmap [B,H,W]; recon NCHW [B,3,H,W];
+ * latent NCHW [B,latent,H/16,W/16]. */
+int vad_img_score(const float* x_nchw, long long b, int h, int w, int latent,
+                  const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk,
+                  float* scores, float* errmap, float* recon_nchw, float* latent_nchw, void* stream);
+
+/* Video ConvLSTM autoencoder.  Replaces VideoAutoencoder.forward / get_reconstruction_error
+ * (models/video_autoencoder.py:329-384) as driven by evaluate_video.py:138-154,346-352.
+ * params: host pointers in state_dict order with num_batches_tracked removed:
+ *   4 x (conv w,b, bn g,b,m,v) ; layers x (cell w,b) ; [proj w,b] ; 3 x (convT w,b, bn g,b,m,v) ; convT w,b */
+int vad_vid_nparams(int layers, int has_proj);
+size_t vad_vid_packed_floats(int latent, int hid, int layers);
+int vad_vid_pack(const float* const* params, int nparams, int latent, int hid, int layers, float* packed_host);
+size_t vad_vid_workspace_bytes(int chunk_clips, int t, int h, int w, int latent, int hid, int layers);
+/* x [B,T,3,H,W].  Outputs (any may be NULL): seq_scores [B]; frame_scores [B,T];
+ * errmap [B,T,H,W]; recon [B,T,3,H,W]. */
+int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
+                  const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips,
+                  float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
+
+/* ------------------------------------------------------------------ per-layer timing
+ * When enabled, the model-level calls bracket every layer launch with hipEvents on `stream`.
+ * vad_prof_read synchronises the events and returns the accumulated ms and launch count per
+ * layer slot since the last vad_prof_reset. */
+#define VAD_PROF_SLOTS 32
+int vad_prof_enable(int on);
+int vad_prof_reset(void);
+int vad_prof_read(float* ms /*[VAD_PROF_SLOTS]*/, int* launches /*[VAD_PROF_SLOTS]*/);
+const char* vad_prof_slot_name(int model /*0 img, 1 vid*/, int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

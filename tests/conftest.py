@@ -1,0 +1,52 @@
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+GOLDEN = REPO / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def vad():
+    """The product package (its directory name is not a Python identifier)."""
+    return importlib.import_module("video-anomaly-detection_amd")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(GOLDEN / name, allow_pickle=False)
+    return load
+
+
+def synthetic_state_for(vad_pkg, module, seed):
+    """Deterministic state dict (numpy) for one of our modules; same generator make_golden.py used."""
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    return vad_pkg.synth.synthetic_state(shapes, seed)
+
+
+def load_synthetic(vad_pkg, module, seed):
+    import torch
+    st = synthetic_state_for(vad_pkg, module, seed)
+    module.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, strict=True)
+    return st
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
+
+
+def max_abs(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))

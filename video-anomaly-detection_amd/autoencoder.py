@@ -1,0 +1,211 @@
+"""Drop-in `ConvAutoencoder` (reference models/autoencoder.py:149-221) on the MI355X HIP path.
+
+Same constructor, `forward` / `get_latent` / `get_reconstruction_error` signatures, module tree and
+state_dict keys as the reference, so a reference checkpoint strict-loads.  Parameters stay ordinary
+`nn.Parameter`s in PyTorch layouts; the kernels read a derived blob (BatchNorm folded, MFMA operand
+order) that is rebuilt whenever a parameter changes.
+
+Inference (`eval()` under `torch.no_grad()`) runs ONLY through libvad_hip.so and raises if the
+library or a GPU tensor is missing.  `train()` mode / autograd keep the stock torch.nn composition,
+which is what the reference's train.py differentiates through (reference train.py:41-46); that is
+outside the scoring hot path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+
+LEAK = 0.2  # reference models/autoencoder.py:41
+
+
+def _conv_bn_act(cin: int, cout: int, act: nn.Module) -> list:
+    return [nn.Conv2d(cin, cout, kernel_size=3, padding=1), nn.BatchNorm2d(cout), act]
+
+
+class Encoder(nn.Module):
+    """4 x [conv3x3-BN-LeakyReLU, conv3x3-BN-LeakyReLU, MaxPool2] (reference models/autoencoder.py:24-86).
+    Sub-module names enc1..enc4 with Sequential indices 0,1,3,4 carrying state, as in the reference."""
+
+    def __init__(self, in_channels: int = 3, latent_dim: int = 256):
+        super().__init__()
+        widths = [in_channels, 32, 64, 128, latent_dim]
+        for i in range(4):
+            layers = (_conv_bn_act(widths[i], widths[i + 1], nn.LeakyReLU(LEAK, inplace=True))
+                      + _conv_bn_act(widths[i + 1], widths[i + 1], nn.LeakyReLU(LEAK, inplace=True))
+                      + [nn.MaxPool2d(2, 2)])
+            setattr(self, f"enc{i + 1}", nn.Sequential(*layers))
+
+    def forward(self, x):
+        for i in range(1, 5):
+            x = getattr(self, f"enc{i}")(x)
+        return x
+
+
+class Decoder(nn.Module):
+    """3 x [convT2x2s2-BN-ReLU, conv3x3-BN-ReLU] + [convT-BN-ReLU, conv3x3, Tanh]
+    (reference models/autoencoder.py:89-146)."""
+
+    def __init__(self, out_channels: int = 3, latent_dim: int = 256):
+        super().__init__()
+        widths = [latent_dim, 128, 64, 32, 32]
+        for i in range(4):
+            layers = [nn.ConvTranspose2d(widths[i], widths[i + 1], kernel_size=2, stride=2),
+                      nn.BatchNorm2d(widths[i + 1]), nn.ReLU(inplace=True)]
+            if i < 3:
+                layers += _conv_bn_act(widths[i + 1], widths[i + 1], nn.ReLU(inplace=True))
+            else:
+                layers += [nn.Conv2d(widths[i + 1], out_channels, kernel_size=3, padding=1), nn.Tanh()]
+            setattr(self, f"dec{i + 1}", nn.Sequential(*layers))
+
+    def forward(self, x):
+        for i in range(1, 5):
+            x = getattr(self, f"dec{i}")(x)
+        return x
+
+
+def _init_like_reference(module: nn.Module) -> None:
+    """Xavier-normal conv/convT weights, zero biases, identity BN (reference models/autoencoder.py:170-179)."""
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.xavier_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+class _HipScorer:
+    """Packed-weight cache + workspace for one model instance."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = None
+        self.ws = None
+
+    @staticmethod
+    def state_key(module: nn.Module):
+        return tuple((t.data_ptr(), t._version, str(t.device)) for t in module.state_dict(keep_vars=True).values())
+
+    @staticmethod
+    def float_params(module: nn.Module):
+        """State-dict tensors in order, num_batches_tracked dropped, as contiguous fp32 numpy."""
+        out = []
+        for k, v in module.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            out.append(np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy()))
+        return out
+
+    def workspace(self, nbytes: int, device) -> torch.Tensor:
+        if self.ws is None or self.ws.numel() < nbytes or self.ws.device != device:
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.ws
+
+
+class ConvAutoencoder(nn.Module):
+    """Reference `ConvAutoencoder(in_channels=3, latent_dim=256)` (models/autoencoder.py:149-221)."""
+
+    #: frames per launch group; intermediates of one chunk (chunk * 8.4 MB at 256x256) stay cache resident
+    chunk = 32
+
+    def __init__(self, in_channels: int = 3, latent_dim: int = 256):
+        super().__init__()
+        self.in_channels = in_channels
+        self.latent_dim = latent_dim
+        self.encoder = Encoder(in_channels, latent_dim)
+        self.decoder = Decoder(in_channels, latent_dim)
+        _init_like_reference(self)
+        self._hip = _HipScorer()
+
+    # ------------------------------------------------------------------ HIP path
+    def _use_hip(self) -> bool:
+        return not self.training and not torch.is_grad_enabled()
+
+    def _packed(self, device) -> torch.Tensor:
+        key = _HipScorer.state_key(self)
+        if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
+            l = hip.lib()
+            n = l.vad_img_packed_floats(self.in_channels, self.latent_dim)
+            if n == 0:
+                raise hip.VadError(
+                    f"ConvAutoencoder(in_channels={self.in_channels}, latent_dim={self.latent_dim}) is not "
+                    "supported by the HIP path (needs in_channels == 3 and latent_dim % 32 == 0)")
+            params = _HipScorer.float_params(self)
+            blob = np.empty(n, dtype=np.float32)
+            hip.check(l.vad_img_pack(hip.pointer_array(params), len(params), self.in_channels,
+                                     self.latent_dim, blob.ctypes.data), "vad_img_pack")
+            self._hip.packed = torch.from_numpy(blob).to(device)
+            self._hip.key = key
+        return self._hip.packed
+
+    def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise hip.VadError(f"expected input [B,3,H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise hip.VadError(
+                "ConvAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
+                "'cuda' (there is no CPU fallback)")
+        b, _, h, w = x.shape
+        x = x.contiguous().float()
+        l = hip.lib()
+        dev = x.device
+        packed = self._packed(dev)
+        chunk = max(1, min(int(self.chunk), b))
+        nbytes = l.vad_img_workspace_bytes(chunk, h, w, self.latent_dim)
+        if nbytes == 0:
+            raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
+        ws = self._hip.workspace(nbytes, dev)
+        out = {}
+        if scores:
+            out["scores"] = torch.empty(b, dtype=torch.float32, device=dev)
+        if errmap:
+            out["errmap"] = torch.empty(b, 1, h, w, dtype=torch.float32, device=dev)
+        if recon:
+            out["recon"] = torch.empty(b, 3, h, w, dtype=torch.float32, device=dev)
+        if latent:
+            out["latent"] = torch.empty(b, self.latent_dim, h // 16, w // 16, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            hip.check(l.vad_img_score(x.data_ptr(), b, h, w, self.latent_dim, packed.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), chunk, hip.ptr(out.get("scores")), hip.ptr(out.get("errmap")),
+                                      hip.ptr(out.get("recon")), hip.ptr(out.get("latent")), hip.current_stream()),
+                      "vad_img_score")
+        hip.calls["img_score"] += 1
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x):
+        """[B,C,H,W] -> reconstruction [B,C,H,W] (reference models/autoencoder.py:181-193)."""
+        if self._use_hip():
+            return self._run_hip(x, recon=True)["recon"]
+        return self.decoder(self.encoder(x))
+
+    def get_latent(self, x):
+        """Latent code [B,latent,H/16,W/16] (reference models/autoencoder.py:195-197)."""
+        if self._use_hip():
+            return self._run_hip(x, latent=True)["latent"]
+        return self.encoder(x)
+
+    def get_reconstruction_error(self, x, per_pixel: bool = False):
+        """Anomaly score: channel-mean squared error map [B,1,H,W] or its spatial mean [B]
+        (reference models/autoencoder.py:199-221)."""
+        if self._use_hip():
+            if per_pixel:
+                return self._run_hip(x, errmap=True)["errmap"]
+            return self._run_hip(x, scores=True)["scores"]
+        recon = self.decoder(self.encoder(x))
+        error = ((x - recon) ** 2).mean(dim=1, keepdim=True)
+        return error if per_pixel else error.mean(dim=[1, 2, 3])
+
+    def score_all(self, x):
+        """One pass returning recon, error map and scores together (the reference's callers run
+        2-3 forwards for these: evaluate.py:146-147, main.py:274-276)."""
+        if not self._use_hip():
+            raise hip.VadError("score_all is an inference entry point: call under eval() and torch.no_grad()")
+        return self._run_hip(x, scores=True, errmap=True, recon=True)
+
+
+Autoencoder = ConvAutoencoder  # name used by BASELINE.json's north_star

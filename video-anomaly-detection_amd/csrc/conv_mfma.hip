@@ -1,0 +1,521 @@
+// Implicit-GEMM convolutions on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Orientation used by every kernel here: GEMM M = pixels, N = output channels, K = (tap, cin).
+//   A (pixels x k)   : NHWC input tile staged in LDS with a 1-pixel halo, padded pixel stride
+//                      (CK+4 floats, so consecutive pixels land on different 16-B bank slots);
+//                      lane (i = lane&31, h = lane>>5) reads 4 consecutive channels with one
+//                      ds_read_b128 and feeds them to 4 consecutive MFMAs (k-pair j = {4h+j}).
+//   B (k x cout)     : weights pre-packed on the host as [tap][cin/8][cout][8] so that the same
+//                      lane reads its 4 k-values for its cout with ONE coalesced 16-B global load
+//                      (a wave reads 1 KiB contiguous); weights stay L2 resident, no LDS copy.
+//   C/D              : column = lane&31 = cout, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = pixel.
+// The 32 pixels of an M-tile are 2 rows x 16 columns ordered as 8 pooling windows x 4 positions
+// (i -> window i>>2, dy (i>>1)&1, dx i&1), so the 4 registers reg&3 of one lane are exactly one
+// MaxPool2d(2,2) window: pooling is 3 v_max in registers, and every store instruction writes two
+// full 128-B channel rows.
+//
+// Reference ops restated: nn.Conv2d(k3,p1)+BatchNorm2d(eval, folded)+LeakyReLU/ReLU(+MaxPool2d)
+// (models/autoencoder.py:38-79,103-139; models/video_autoencoder.py:191-215), ConvLSTMCell
+// (models/video_autoencoder.py:54-85), nn.ConvTranspose2d(k2,s2)+BN+ReLU
+// (models/autoencoder.py:104-131; models/video_autoencoder.py:244-256).
+#include "vad_common.h"
+
+enum { MODE_PLAIN = 0, MODE_POOL = 1, MODE_LSTM = 2 };
+
+struct Conv3P {
+    const float* in;  long long in_fs;  int cin_a;   // channels [0, cin_a)
+    const float* in2; long long in2_fs;              // channels [cin_a, cin); NULL = zeros
+    const float* w;   const float* bias;
+    float* out;       long long out_fs;
+    const float* c_prev; float* c_out;               // MODE_LSTM
+    int h, w_, cin, cout, hid;
+    int tiles_x, tiles_y, cblocks;
+    unsigned nblocks;
+};
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
+    static_assert(WM * WN == 4, "4 waves per work-group");
+    static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
+    constexpr int TH = 2 * MT * WM, LH = TH + 2, LW = 18, PS = CK + 4;
+    __shared__ __attribute__((aligned(16))) float tile[LH * LW * PS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    unsigned L = vad_xcd_remap(blockIdx.x, p.nblocks);
+    const int cb = L % p.cblocks; L /= p.cblocks;
+    const int tx = L % p.tiles_x; L /= p.tiles_x;
+    const int ty = L % p.tiles_y;
+    const int n = L / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16;
+
+    // per-lane pixel inside an M-tile
+    const int prow = (li >> 1) & 1, pcol = 2 * (li >> 2) + (li & 1);
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        abase[mt] = ((2 * (wm * MT + mt) + prow) * LW + pcol) * PS + 4 * lh;
+
+    // per-lane weight row pointers and bias
+    const float* wp[NT];
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int co;
+        if (MODE == MODE_LSTM) co = nt * p.hid + (cb * WN + wn) * 32 + li;
+        else co = ((cb * WN + wn) * NT + nt) * 32 + li;
+        wp[nt] = p.w + (size_t)co * 8 + 4 * lh;
+        bv[nt] = p.bias[co];
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
+
+    const int nch_a = p.cin_a / CK;
+    const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
+    const size_t wstep = (size_t)p.cout * 8;           // floats per (tap, k8) slab
+    const size_t wtap = (size_t)(p.cin / 8) * wstep;   // floats per tap
+
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* src;
+        int pstride, coff;
+        if (ch < nch_a) { src = p.in + (size_t)n * p.in_fs; pstride = p.cin_a; coff = ch * CK; }
+        else { src = p.in2 + (size_t)n * p.in2_fs; pstride = p.cin - p.cin_a; coff = ch * CK - p.cin_a; }
+
+        __syncthreads();
+        for (int idx = tid; idx < LH * LW * (CK / 4); idx += 256) {
+            const int c4 = idx % (CK / 4), pix = idx / (CK / 4);
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
+                v = *(const f32x4*)(src + ((size_t)gy * p.w_ + gx) * pstride + coff + c4 * 4);
+            *(f32x4*)&tile[pix * PS + c4 * 4] = v;
+        }
+        __syncthreads();
+
+        const size_t kbase = (size_t)(ch * (CK / 8)) * wstep;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = ((tap / 3) * LW + (tap % 3)) * PS;
+#pragma unroll
+            for (int k8 = 0; k8 < CK / 8; ++k8) {
+                f32x4 a[MT], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)&tile[abase[mt] + toff + k8 * 8];
+                const size_t woff = (size_t)tap * wtap + kbase + (size_t)k8 * wstep;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wp[nt] + woff);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = MFMA32(a[mt][j], b[nt][j], acc[mt][nt]);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    if (MODE == MODE_LSTM) {
+        const int hc = (cb * WN + wn) * 32 + li;
+        const size_t cfs = (size_t)p.h * p.w_ * p.hid;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int wq = 2 * (r >> 2) + lh, pos = r & 3;
+                const int y = y0 + 2 * (wm * MT + mt) + (pos >> 1), x = x0 + 2 * wq + (pos & 1);
+                if (y < p.h && x < p.w_) {
+                    const size_t pix = (size_t)y * p.w_ + x;
+                    const float cp = p.c_prev ? p.c_prev[(size_t)n * cfs + pix * p.hid + hc] : 0.f;
+                    const float gi = vad_sigmoid(acc[mt][0][r]);
+                    const float gf = vad_sigmoid(acc[mt][1][r]);
+                    const float gg = tanhf(acc[mt][2][r]);
+                    const float go = vad_sigmoid(acc[mt][3][r]);
+                    const float cn = gf * cp + gi * gg;
+                    p.c_out[(size_t)n * cfs + pix * p.hid + hc] = cn;
+                    p.out[(size_t)n * p.out_fs + pix * p.hid + hc] = go * tanhf(cn);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = ((cb * WN + wn) * NT + nt) * 32 + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int wq = 2 * q + lh;
+                    float v[4];
+#pragma unroll
+                    for (int pos = 0; pos < 4; ++pos) v[pos] = vad_act(acc[mt][nt][4 * q + pos], ACT);
+                    if (MODE == MODE_POOL) {
+                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        const int oy = (y0 >> 1) + (wm * MT + mt), ox = (x0 >> 1) + wq;
+                        if (oy < (p.h >> 1) && ox < (p.w_ >> 1))
+                            p.out[(size_t)n * p.out_fs + ((size_t)oy * (p.w_ >> 1) + ox) * p.cout + co] = m;
+                    } else {
+#pragma unroll
+                        for (int pos = 0; pos < 4; ++pos) {
+                            const int y = y0 + 2 * (wm * MT + mt) + (pos >> 1), x = x0 + 2 * wq + (pos & 1);
+                            if (y < p.h && x < p.w_)
+                                p.out[(size_t)n * p.out_fs + ((size_t)y * p.w_ + x) * p.cout + co] = v[pos];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CK, int MT, int NT, int WM, int WN, int MODE>
+static int launch_conv3(Conv3P& p, int n, int act, hipStream_t s) {
+    constexpr int TH = 2 * MT * WM;
+    p.tiles_x = (p.w_ + 15) / 16;
+    p.tiles_y = (p.h + TH - 1) / TH;
+    p.cblocks = (MODE == MODE_LSTM) ? p.hid / (32 * WN) : p.cout / (32 * NT * WN);
+    const long long nb = (long long)n * p.tiles_x * p.tiles_y * p.cblocks;
+    VAD_REQUIRE(nb > 0 && nb < (1ll << 31), "conv3x3: grid of %lld blocks out of range", nb);
+    p.nblocks = (unsigned)nb;
+    dim3 g((unsigned)nb), b(256);
+    if (MODE == MODE_LSTM || act == VAD_ACT_NONE)
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, VAD_ACT_NONE>), g, b, 0, s, p);
+    else if (act == VAD_ACT_LEAKY)
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, VAD_ACT_LEAKY>), g, b, 0, s, p);
+    else
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, VAD_ACT_RELU>), g, b, 0, s, p);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, const float* bias,
+                           float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
+                           int act, int pool, void* stream) {
+    VAD_REQUIRE(in && w && bias && out, "conv3x3: null pointer");
+    VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "conv3x3: bad shape n=%d h=%d w=%d", n, h, wd);
+    VAD_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
+                "conv3x3: cin=%d cout=%d must be positive multiples of 32", cin, cout);
+    VAD_REQUIRE(!pool || (h % 2 == 0 && wd % 2 == 0), "conv3x3: pooling needs even H,W (got %dx%d)", h, wd);
+    VAD_REQUIRE(act >= 0 && act <= 2, "conv3x3: bad act %d", act);
+    Conv3P p{};
+    p.in = in; p.in_fs = in_fs ? in_fs : (long long)h * wd * cin; p.cin_a = cin;
+    p.in2 = nullptr; p.in2_fs = 0;
+    p.w = w; p.bias = bias; p.out = out;
+    const int ho = pool ? h / 2 : h, wo = pool ? wd / 2 : wd;
+    p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
+    p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.hid = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (cout % 128 == 0) {
+        return pool ? launch_conv3<32, 2, 2, 2, 2, MODE_POOL>(p, n, act, s)
+                    : launch_conv3<32, 2, 2, 2, 2, MODE_PLAIN>(p, n, act, s);
+    } else if (cout % 64 == 0) {
+        return pool ? launch_conv3<32, 2, 2, 4, 1, MODE_POOL>(p, n, act, s)
+                    : launch_conv3<32, 2, 2, 4, 1, MODE_PLAIN>(p, n, act, s);
+    } else {
+        return pool ? launch_conv3<32, 2, 1, 4, 1, MODE_POOL>(p, n, act, s)
+                    : launch_conv3<32, 2, 1, 4, 1, MODE_PLAIN>(p, n, act, s);
+    }
+}
+
+extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_prev, long long h_prev_fs, const float* c_prev,
+                                 const float* w, const float* bias, float* h_out, long long h_out_fs,
+                                 float* c_out, int n, int h, int wd, int cin_x, int hid, void* stream) {
+    VAD_REQUIRE(x && w && bias && h_out && c_out, "convlstm_step: null pointer");
+    VAD_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), "convlstm_step: h_prev and c_prev must both be given or both NULL");
+    VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "convlstm_step: bad shape");
+    VAD_REQUIRE(cin_x % 32 == 0 && hid % 64 == 0 && cin_x > 0 && hid > 0,
+                "convlstm_step: cin_x=%d must be a multiple of 32 and hid=%d a multiple of 64", cin_x, hid);
+    Conv3P p{};
+    p.in = x; p.in_fs = x_fs ? x_fs : (long long)h * wd * cin_x; p.cin_a = cin_x;
+    p.in2 = h_prev; p.in2_fs = h_prev_fs ? h_prev_fs : (long long)h * wd * hid;
+    p.w = w; p.bias = bias; p.out = h_out;
+    p.out_fs = h_out_fs ? h_out_fs : (long long)h * wd * hid;
+    p.c_prev = c_prev; p.c_out = c_out;
+    p.h = h; p.w_ = wd; p.cin = cin_x + hid; p.cout = 4 * hid; p.hid = hid;
+    return launch_conv3<32, 1, 4, 2, 2, MODE_LSTM>(p, n, VAD_ACT_NONE, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// First layer: Conv2d(3 -> Cout) straight from the NCHW input planes.  K = 27 padded to 28 (14
+// k-pairs); the B operand (14 floats per lane) lives in registers for the whole work-group.
+struct ConvC3P {
+    const float* x; const float* w; const float* bias; float* out;
+    int h, w_, cout, tiles_x, tiles_y;
+    unsigned nblocks;
+};
+
+template <int MT, int POOL, int ACT>
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
+    constexpr int TH = 2 * MT * 4, LH = TH + 2, RS = 20;
+    __shared__ float tile[3 * LH * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    unsigned L = vad_xcd_remap(blockIdx.x, p.nblocks);
+    const int tx = L % p.tiles_x; L /= p.tiles_x;
+    const int ty = L % p.tiles_y;
+    const int n = L / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * 16;
+
+    const float* xin = p.x + (size_t)n * 3 * p.h * p.w_;
+    for (int idx = tid; idx < 3 * LH * 18; idx += 256) {
+        const int lx = idx % 18, t = idx / 18, ly = t % LH, c = t / LH;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        float v = 0.f;
+        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) v = xin[((size_t)c * p.h + gy) * p.w_ + gx];
+        tile[(c * LH + ly) * RS + lx] = v;
+    }
+    __syncthreads();
+
+    const int prow = (li >> 1) & 1, pcol = 2 * (li >> 2) + (li & 1);
+    // per-lane tap offsets: k = 2s + h -> (c, dy, dx) = (k/9, (k%9)/3, k%3); k = 27 is padding
+    int koff[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int o0 = ((k0 / 9) * LH + (k0 % 9) / 3) * RS + (k0 % 3);
+        const int o1 = (k1 < 27) ? ((k1 / 9) * LH + (k1 % 9) / 3) * RS + (k1 % 3) : 0;
+        koff[s] = lh ? o1 : o0;
+    }
+
+    for (int nt = 0; nt < p.cout / 32; ++nt) {
+        const int co = nt * 32 + li;
+        float b[14];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
+        const float bv = p.bias[co];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int base = ((2 * (wave * MT + mt) + prow) * RS + pcol);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bv;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) acc = MFMA32(tile[base + koff[s]], b[s], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int wq = 2 * q + lh;
+                float v[4];
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) v[pos] = vad_act(acc[4 * q + pos], ACT);
+                if (POOL) {
+                    const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    const int oy = (y0 >> 1) + (wave * MT + mt), ox = (x0 >> 1) + wq;
+                    if (oy < (p.h >> 1) && ox < (p.w_ >> 1))
+                        p.out[(((size_t)n * (p.h >> 1) + oy) * (p.w_ >> 1) + ox) * p.cout + co] = m;
+                } else {
+#pragma unroll
+                    for (int pos = 0; pos < 4; ++pos) {
+                        const int y = y0 + 2 * (wave * MT + mt) + (pos >> 1), x = x0 + 2 * wq + (pos & 1);
+                        if (y < p.h && x < p.w_)
+                            p.out[(((size_t)n * p.h + y) * p.w_ + x) * p.cout + co] = v[pos];
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" int vad_conv3x3_c3(const float* x, const float* w, const float* bias, float* out,
+                              int n, int h, int wd, int cout, int act, int pool, void* stream) {
+    VAD_REQUIRE(x && w && bias && out, "conv3x3_c3: null pointer");
+    VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && cout > 0 && cout % 32 == 0, "conv3x3_c3: bad shape");
+    VAD_REQUIRE(!pool || (h % 2 == 0 && wd % 2 == 0), "conv3x3_c3: pooling needs even H,W");
+    VAD_REQUIRE(act == VAD_ACT_LEAKY || act == VAD_ACT_RELU || act == VAD_ACT_NONE, "conv3x3_c3: bad act");
+    ConvC3P p{x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 15) / 16, 0};
+    const long long nb = (long long)n * p.tiles_x * p.tiles_y;
+    VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");
+    p.nblocks = (unsigned)nb;
+    dim3 g((unsigned)nb), b(256);
+    hipStream_t s = (hipStream_t)stream;
+#define C3_LAUNCH(POOL, ACT) hipLaunchKernelGGL((conv3x3_c3_kernel<2, POOL, ACT>), g, b, 0, s, p)
+    if (pool) {
+        if (act == VAD_ACT_LEAKY) C3_LAUNCH(1, VAD_ACT_LEAKY);
+        else if (act == VAD_ACT_RELU) C3_LAUNCH(1, VAD_ACT_RELU);
+        else C3_LAUNCH(1, VAD_ACT_NONE);
+    } else {
+        if (act == VAD_ACT_LEAKY) C3_LAUNCH(0, VAD_ACT_LEAKY);
+        else if (act == VAD_ACT_RELU) C3_LAUNCH(0, VAD_ACT_RELU);
+        else C3_LAUNCH(0, VAD_ACT_NONE);
+    }
+#undef C3_LAUNCH
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvTranspose2d k2 s2 (and 1x1 conv when UPS == 0) as a GEMM over flattened input pixels:
+// out[n, 2y+a, 2x+b, co] = bias[co] + sum_ci in[n,y,x,ci] * W[ci,co,a,b]; N index = (quadrant, co).
+struct ConvTP {
+    const float* in; long long in_fs;
+    const float* w; const float* bias;
+    float* out; long long out_fs;
+    int h, w_, cin, cout;
+    long long npix;          // n*h*w
+    int nblocks_n;           // column blocks
+    unsigned nblocks;
+};
+
+template <int CK, int MT, int NT, int WM, int WN, int UPS, int ACT>
+__global__ __launch_bounds__(256) void convt2x2_mfma_kernel(ConvTP p) {
+    constexpr int TM = 32 * MT * WM, PS = CK + 4;
+    __shared__ __attribute__((aligned(16))) float tile[TM * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    unsigned L = vad_xcd_remap(blockIdx.x, p.nblocks);
+    const int nb_n = L % p.nblocks_n;
+    const long long m0 = (long long)(L / p.nblocks_n) * TM;
+    const int hw = p.h * p.w_;
+    const int ctiles = p.cout / 32;
+
+    const float* wp[NT];
+    float bv[NT];
+    int qd[NT], cob[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int g = (nb_n * WN + wn) * NT + nt;
+        qd[nt] = g / ctiles;
+        cob[nt] = (g % ctiles) * 32 + li;
+        wp[nt] = p.w + ((size_t)qd[nt] * (p.cin / 8) * p.cout + cob[nt]) * 8 + 4 * lh;
+        bv[nt] = p.bias[cob[nt]];
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
+
+    const size_t wstep = (size_t)p.cout * 8;
+    for (int ch = 0; ch < p.cin / CK; ++ch) {
+        __syncthreads();
+        for (int idx = tid; idx < TM * (CK / 4); idx += 256) {
+            const int c4 = idx % (CK / 4), pm = idx / (CK / 4);
+            const long long m = m0 + pm;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.npix) {
+                const long long nn = m / hw;
+                const int rem = (int)(m - nn * hw);
+                v = *(const f32x4*)(p.in + (size_t)nn * p.in_fs + (size_t)rem * p.cin + ch * CK + c4 * 4);
+            }
+            *(f32x4*)&tile[pm * PS + c4 * 4] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k8 = 0; k8 < CK / 8; ++k8) {
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *(const f32x4*)&tile[((wm * MT + mt) * 32 + li) * PS + k8 * 8 + 4 * lh];
+            const size_t woff = (size_t)(ch * (CK / 8) + k8) * wstep;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wp[nt] + woff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = MFMA32(a[mt][j], b[nt][j], acc[mt][nt]);
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long long m = m0 + (wm * MT + mt) * 32 + row;
+            if (m < p.npix) {
+                const long long nn = m / hw;
+                const int rem = (int)(m - nn * hw);
+                const int y = rem / p.w_, x = rem - y * p.w_;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float v = vad_act(acc[mt][nt][r], ACT);
+                    size_t o;
+                    if (UPS) {
+                        const int oy = 2 * y + (qd[nt] >> 1), ox = 2 * x + (qd[nt] & 1);
+                        o = (size_t)nn * p.out_fs + ((size_t)oy * (2 * p.w_) + ox) * p.cout + cob[nt];
+                    } else {
+                        o = (size_t)nn * p.out_fs + (size_t)rem * p.cout + cob[nt];
+                    }
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int UPS>
+static int launch_convt(ConvTP& p, int act, hipStream_t s) {
+    // 128 pixels x 128 columns per work-group; the column count is (UPS ? 4 : 1) * cout
+    const int ncols = (UPS ? 4 : 1) * p.cout;
+    constexpr int TM = 128;
+    const long long mblocks = (p.npix + TM - 1) / TM;
+    dim3 b(256);
+    if (ncols % 128 == 0) {
+        p.nblocks_n = ncols / 128;
+        const long long nb = mblocks * p.nblocks_n;
+        VAD_REQUIRE(nb < (1ll << 31), "convt: grid too large");
+        p.nblocks = (unsigned)nb;
+        dim3 g((unsigned)nb);
+        if (act == VAD_ACT_RELU) hipLaunchKernelGGL((convt2x2_mfma_kernel<32, 2, 2, 2, 2, UPS, VAD_ACT_RELU>), g, b, 0, s, p);
+        else if (act == VAD_ACT_LEAKY) hipLaunchKernelGGL((convt2x2_mfma_kernel<32, 2, 2, 2, 2, UPS, VAD_ACT_LEAKY>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((convt2x2_mfma_kernel<32, 2, 2, 2, 2, UPS, VAD_ACT_NONE>), g, b, 0, s, p);
+    } else {
+        // narrow outputs (1x1 conv with cout 32/64/96): 128 pixels x 32 columns
+        p.nblocks_n = ncols / 32;
+        const long long nb = mblocks * p.nblocks_n;
+        VAD_REQUIRE(nb < (1ll << 31), "convt: grid too large");
+        p.nblocks = (unsigned)nb;
+        dim3 g((unsigned)nb);
+        if (act == VAD_ACT_RELU) hipLaunchKernelGGL((convt2x2_mfma_kernel<32, 1, 1, 4, 1, UPS, VAD_ACT_RELU>), g, b, 0, s, p);
+        else if (act == VAD_ACT_LEAKY) hipLaunchKernelGGL((convt2x2_mfma_kernel<32, 1, 1, 4, 1, UPS, VAD_ACT_LEAKY>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((convt2x2_mfma_kernel<32, 1, 1, 4, 1, UPS, VAD_ACT_NONE>), g, b, 0, s, p);
+    }
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, const float* bias,
+                            float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
+                            int act, void* stream) {
+    VAD_REQUIRE(in && w && bias && out, "convt2x2: null pointer");
+    VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "convt2x2: bad shape");
+    VAD_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
+                "convt2x2: cin=%d cout=%d must be positive multiples of 32", cin, cout);
+    VAD_REQUIRE(act >= 0 && act <= 2, "convt2x2: bad act");
+    ConvTP p{};
+    p.in = in; p.in_fs = in_fs ? in_fs : (long long)h * wd * cin;
+    p.w = w; p.bias = bias; p.out = out;
+    p.out_fs = out_fs ? out_fs : (long long)4 * h * wd * cout;
+    p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.npix = (long long)n * h * wd;
+    return launch_convt<1>(p, act, (hipStream_t)stream);
+}
+
+extern "C" int vad_conv1x1(const float* in, const float* w, const float* bias, float* out,
+                           long long npix, int cin, int cout, void* stream) {
+    VAD_REQUIRE(in && w && bias && out, "conv1x1: null pointer");
+    VAD_REQUIRE(npix > 0 && cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0, "conv1x1: bad shape");
+    ConvTP p{};
+    // one "frame" of npix x 1 pixels
+    p.in = in; p.in_fs = 0; p.w = w; p.bias = bias; p.out = out; p.out_fs = 0;
+    p.h = 1; p.w_ = (int)((npix < (1ll << 30)) ? npix : 0); p.cin = cin; p.cout = cout; p.npix = npix;
+    VAD_REQUIRE(p.w_ > 0, "conv1x1: npix too large");
+    return launch_convt<0>(p, VAD_ACT_NONE, (hipStream_t)stream);
+}

@@ -1,0 +1,253 @@
+// Host-side weight packing: eval-mode BatchNorm folding (fp64, one rounding to fp32) and the
+// re-ordering the kernels' B-operand loads expect.  Pure CPU code, no HIP calls.
+//
+// BatchNorm2d eval semantics restated (torch defaults, eps = 1e-5; used after every conv/convT of
+// reference models/autoencoder.py:38-131 and models/video_autoencoder.py:191-256):
+//   y = (conv(x) - running_mean) / sqrt(running_var + eps) * gamma + beta
+//     = conv_{w * s}(x) + ((b - running_mean) * s + beta),   s = gamma / sqrt(running_var + eps)
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "vad_layout.h"
+
+static thread_local char g_err[512] = "";
+
+int vad_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* vad_last_error(void) { return g_err; }
+extern "C" int vad_abi_version(void) { return VAD_ABI_VERSION; }
+
+#define REQ(cond, ...) do { if (!(cond)) return vad_fail(VAD_ERR_ARG, __VA_ARGS__); } while (0)
+
+static void bn_scale_shift(const float* bias, const float* const* bn, int cout,
+                           std::vector<double>& s, float* bias_out) {
+    s.assign(cout, 1.0);
+    for (int co = 0; co < cout; ++co) {
+        double b = bias ? (double)bias[co] : 0.0;
+        if (bn) {
+            const double sc = (double)bn[0][co] / std::sqrt((double)bn[3][co] + 1e-5);
+            s[co] = sc;
+            b = (b - (double)bn[2][co]) * sc + (double)bn[1][co];
+        }
+        bias_out[co] = (float)b;
+    }
+}
+
+extern "C" size_t vad_pack_conv3x3_floats(int cout, int cin) { return (size_t)9 * ((cin + 7) / 8) * cout * 8; }
+
+extern "C" int vad_pack_conv3x3(const float* w, const float* bias, const float* const* bn,
+                                int cout, int cin, float* out, float* bias_out) {
+    REQ(w && out && bias_out && cout > 0 && cin > 0, "pack_conv3x3: bad arguments");
+    std::vector<double> s;
+    bn_scale_shift(bias, bn, cout, s, bias_out);
+    const int c8n = (cin + 7) / 8;
+    memset(out, 0, vad_pack_conv3x3_floats(cout, cin) * sizeof(float));
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int tap = 0; tap < 9; ++tap)
+                out[(((size_t)tap * c8n + ci / 8) * cout + co) * 8 + (ci & 7)] =
+                    (float)((double)w[((size_t)co * cin + ci) * 9 + tap] * s[co]);
+    return VAD_OK;
+}
+
+extern "C" size_t vad_pack_conv3x3_c3_floats(int cout) { return (size_t)28 * cout; }
+
+extern "C" int vad_pack_conv3x3_c3(const float* w, const float* bias, const float* const* bn,
+                                   int cout, float* out, float* bias_out) {
+    REQ(w && out && bias_out && cout > 0, "pack_conv3x3_c3: bad arguments");
+    std::vector<double> s;
+    bn_scale_shift(bias, bn, cout, s, bias_out);
+    for (int k = 0; k < 28; ++k)
+        for (int co = 0; co < cout; ++co)
+            out[(size_t)k * cout + co] = k < 27 ? (float)((double)w[(size_t)co * 27 + k] * s[co]) : 0.f;
+    return VAD_OK;
+}
+
+extern "C" size_t vad_pack_convt2x2_floats(int cin, int cout) { return (size_t)4 * (cin / 8) * cout * 8; }
+
+extern "C" int vad_pack_convt2x2(const float* w, const float* bias, const float* const* bn,
+                                 int cin, int cout, float* out, float* bias_out) {
+    REQ(w && out && bias_out && cout > 0 && cin > 0 && cin % 8 == 0, "pack_convt2x2: bad arguments");
+    std::vector<double> s;
+    bn_scale_shift(bias, bn, cout, s, bias_out);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int q = 0; q < 4; ++q)
+                out[(((size_t)q * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] =
+                    (float)((double)w[((size_t)ci * cout + co) * 4 + q] * s[co]);
+    return VAD_OK;
+}
+
+extern "C" size_t vad_pack_conv1x1_floats(int cout, int cin) { return (size_t)(cin / 8) * cout * 8; }
+
+extern "C" int vad_pack_conv1x1(const float* w, const float* bias, int cout, int cin, float* out, float* bias_out) {
+    REQ(w && out && bias_out && cout > 0 && cin > 0 && cin % 8 == 0, "pack_conv1x1: bad arguments");
+    for (int co = 0; co < cout; ++co) {
+        bias_out[co] = bias ? bias[co] : 0.f;
+        for (int ci = 0; ci < cin; ++ci)
+            out[((size_t)(ci / 8) * cout + co) * 8 + (ci & 7)] = w[(size_t)co * cin + ci];
+    }
+    return VAD_OK;
+}
+
+extern "C" size_t vad_pack_conv3x3_to3_floats(int cin) { return (size_t)9 * cin * 4; }
+
+extern "C" int vad_pack_conv3x3_to3(const float* w, int cin, float* out) {
+    REQ(w && out && cin > 0, "pack_conv3x3_to3: bad arguments");
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < cin; ++ci) {
+            float* o = out + ((size_t)tap * cin + ci) * 4;
+            for (int co = 0; co < 3; ++co) o[co] = w[((size_t)co * cin + ci) * 9 + tap];
+            o[3] = 0.f;
+        }
+    return VAD_OK;
+}
+
+// --------------------------------------------------------------------------- image autoencoder
+static size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+ImgLayout img_layout(int latent) {
+    ImgLayout L{};
+    const int ch[5] = {3, 32, 64, 128, latent};
+    size_t off = 0;
+    int li = 0;
+    auto add = [&](int kind, int cin, int cout, size_t wfloats) {
+        LayerSlot& s = L.layer[li++];
+        s.kind = kind; s.cin = cin; s.cout = cout;
+        s.w = off; off = align4(off + wfloats);
+        s.b = off; off = align4(off + (size_t)cout);
+    };
+    for (int b = 0; b < 4; ++b) {   // encoder blocks (models/autoencoder.py:38-79)
+        if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
+        else add(LK_CONV, ch[b], ch[b + 1], vad_pack_conv3x3_floats(ch[b + 1], ch[b]));
+        add(LK_CONV, ch[b + 1], ch[b + 1], vad_pack_conv3x3_floats(ch[b + 1], ch[b + 1]));
+    }
+    const int dch[5] = {latent, 128, 64, 32, 32};
+    for (int b = 0; b < 4; ++b) {   // decoder blocks (models/autoencoder.py:103-139)
+        add(LK_CONVT, dch[b], dch[b + 1], vad_pack_convt2x2_floats(dch[b], dch[b + 1]));
+        if (b < 3) add(LK_CONV, dch[b + 1], dch[b + 1], vad_pack_conv3x3_floats(dch[b + 1], dch[b + 1]));
+        else add(LK_TAIL_CONV, 32, 3, vad_pack_conv3x3_to3_floats(32));
+    }
+    L.nlayers = li;
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t vad_img_packed_floats(int in_ch, int latent) {
+    if (in_ch != 3 || latent <= 0 || latent % 32) return 0;
+    return img_layout(latent).total;
+}
+
+extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int latent, float* out) {
+    REQ(P && out, "img_pack: null pointer");
+    REQ(in_ch == 3, "img_pack: in_channels=%d unsupported (every reference call site uses 3)", in_ch);
+    REQ(latent > 0 && latent % 32 == 0, "img_pack: latent_dim=%d must be a positive multiple of 32", latent);
+    REQ(nparams == VAD_IMG_NPARAMS, "img_pack: expected %d parameter tensors, got %d", VAD_IMG_NPARAMS, nparams);
+    for (int i = 0; i < nparams; ++i) REQ(P[i], "img_pack: parameter %d is NULL", i);
+    const ImgLayout L = img_layout(latent);
+    memset(out, 0, L.total * sizeof(float));
+    int pi = 0, rc = VAD_OK;
+    for (int li = 0; li < L.nlayers && rc == VAD_OK; ++li) {
+        const LayerSlot& s = L.layer[li];
+        const float* w = P[pi], *b = P[pi + 1];
+        if (s.kind == LK_TAIL_CONV) {
+            rc = vad_pack_conv3x3_to3(w, s.cin, out + s.w);
+            for (int c = 0; c < 3; ++c) out[s.b + c] = b[c];
+            pi += 2;
+            continue;
+        }
+        const float* bn[4] = {P[pi + 2], P[pi + 3], P[pi + 4], P[pi + 5]};
+        if (s.kind == LK_CONV_C3) rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b);
+        else if (s.kind == LK_CONV) rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, out + s.w, out + s.b);
+        else rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, out + s.w, out + s.b);
+        pi += 6;
+    }
+    if (rc == VAD_OK && pi != nparams) return vad_fail(VAD_ERR_ARG, "img_pack: consumed %d of %d parameters", pi, nparams);
+    return rc;
+}
+
+// --------------------------------------------------------------------------- video autoencoder
+VidLayout vid_layout(int latent, int hid, int layers) {
+    VidLayout L{};
+    size_t off = 0;
+    int li = 0;
+    auto add = [&](int kind, int cin, int cout, size_t wfloats) {
+        LayerSlot& s = L.layer[li++];
+        s.kind = kind; s.cin = cin; s.cout = cout;
+        s.w = off; off = align4(off + wfloats);
+        s.b = off; off = align4(off + (size_t)cout);
+    };
+    const int ch[5] = {3, 32, 64, 128, latent};
+    for (int b = 0; b < 4; ++b) {   // VideoEncoder (models/video_autoencoder.py:191-215)
+        if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
+        else add(LK_CONV, ch[b], ch[b + 1], vad_pack_conv3x3_floats(ch[b + 1], ch[b]));
+    }
+    for (int l = 0; l < layers; ++l) {   // ConvLSTM cells (models/video_autoencoder.py:118-125)
+        const int cin = (l == 0 ? latent : hid) + hid;
+        add(LK_LSTM, cin, 4 * hid, vad_pack_conv3x3_floats(4 * hid, cin));
+    }
+    L.has_proj = hid != latent;          // models/video_autoencoder.py:311-312
+    if (L.has_proj) add(LK_PROJ, hid, latent, vad_pack_conv1x1_floats(latent, hid));
+    const int dch[4] = {latent, 128, 64, 32};
+    for (int b = 0; b < 3; ++b) add(LK_CONVT, dch[b], dch[b + 1], vad_pack_convt2x2_floats(dch[b], dch[b + 1]));
+    add(LK_TAIL_CONVT, 32, 3, (size_t)32 * 12);   // VideoDecoder (models/video_autoencoder.py:242-261)
+    L.nlayers = li;
+    L.total = off;
+    return L;
+}
+
+extern "C" int vad_vid_nparams(int layers, int has_proj) { return 24 + 2 * layers + (has_proj ? 2 : 0) + 18 + 2; }
+
+static int vid_dims_ok(int latent, int hid, int layers) {
+    REQ(latent > 0 && latent % 32 == 0, "vid: latent_dim=%d must be a positive multiple of 32", latent);
+    REQ(hid > 0 && hid % 64 == 0, "vid: lstm_hidden_dim=%d must be a positive multiple of 64", hid);
+    REQ(layers >= 1 && layers <= 8, "vid: lstm_num_layers=%d out of range [1,8]", layers);
+    return VAD_OK;
+}
+
+extern "C" size_t vad_vid_packed_floats(int latent, int hid, int layers) {
+    if (vid_dims_ok(latent, hid, layers) != VAD_OK) return 0;
+    return vid_layout(latent, hid, layers).total;
+}
+
+extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int hid, int layers, float* out) {
+    REQ(P && out, "vid_pack: null pointer");
+    int rc = vid_dims_ok(latent, hid, layers);
+    if (rc != VAD_OK) return rc;
+    const VidLayout L = vid_layout(latent, hid, layers);
+    REQ(nparams == vad_vid_nparams(layers, L.has_proj), "vid_pack: expected %d parameter tensors, got %d",
+        vad_vid_nparams(layers, L.has_proj), nparams);
+    for (int i = 0; i < nparams; ++i) REQ(P[i], "vid_pack: parameter %d is NULL", i);
+    memset(out, 0, L.total * sizeof(float));
+    int pi = 0;
+    for (int li = 0; li < L.nlayers && rc == VAD_OK; ++li) {
+        const LayerSlot& s = L.layer[li];
+        const float* w = P[pi], *b = P[pi + 1];
+        const float* bn[4] = {nullptr, nullptr, nullptr, nullptr};
+        switch (s.kind) {
+        case LK_CONV_C3: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
+            rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b); pi += 6; break;
+        case LK_CONV: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
+            rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, out + s.w, out + s.b); pi += 6; break;
+        case LK_CONVT: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
+            rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, out + s.w, out + s.b); pi += 6; break;
+        case LK_LSTM: rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break;
+        case LK_PROJ: rc = vad_pack_conv1x1(w, b, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break;
+        case LK_TAIL_CONVT:
+            memcpy(out + s.w, w, (size_t)32 * 12 * sizeof(float));
+            for (int c = 0; c < 3; ++c) out[s.b + c] = b[c];
+            pi += 2; break;
+        default: return vad_fail(VAD_ERR_ARG, "vid_pack: internal layout error");
+        }
+    }
+    if (rc == VAD_OK && pi != nparams) return vad_fail(VAD_ERR_ARG, "vid_pack: consumed %d of %d parameters", pi, nparams);
+    return rc;
+}

@@ -1,0 +1,299 @@
+// Memory-bound tails of the scoring path (VALU kernels): the Cout = 3 output layers fused with
+// Tanh, the squared reconstruction error and a deterministic per-frame reduction; layout
+// transposes; the on-device synthetic frame generator.
+//
+// Reference ops restated: Conv2d(32->3)+Tanh (models/autoencoder.py:134-135),
+// ConvTranspose2d(32->3)+Tanh (models/video_autoencoder.py:259-260), error = (x-recon)**2,
+// channel mean, spatial / temporal means (models/autoencoder.py:214-221,
+// models/video_autoencoder.py:371-384).
+#include "vad_common.h"
+
+struct TailP {
+    const float* in;      // NHWC activations feeding the last layer
+    const float* w;       // packed weights
+    const float* bias;    // [3]
+    const float* x;       // original input, NCHW [N,3,H2,W2]
+    float* partials;      // [N][nparts]
+    float* recon;         // NCHW or NULL
+    float* errmap;        // [N,H2,W2] or NULL
+    int h, w_;            // spatial size of `in`
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Fixed-shape block reduction: wave butterfly, then waves 0..3 added in order by thread 0.
+__device__ __forceinline__ void block_partial(float e, float* red, float* dst) {
+    const float s = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_to3_score_kernel(TailP p) {
+    constexpr int TH = 8, TW = 32, LH = TH + 2, LW = TW + 2, PS = CIN + 4;
+    __shared__ __attribute__((aligned(16))) float tile[LH * LW * PS];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    unsigned L = blockIdx.x;
+    const int tx = L % p.tiles_x; L /= p.tiles_x;
+    const int ty = L % p.tiles_y;
+    const int n = L / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* src = p.in + (size_t)n * p.h * p.w_ * CIN;
+    for (int idx = tid; idx < LH * LW * (CIN / 4); idx += 256) {
+        const int c4 = idx % (CIN / 4), pix = idx / (CIN / 4);
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
+            v = *(const f32x4*)(src + ((size_t)gy * p.w_ + gx) * CIN + c4 * 4);
+        *(f32x4*)&tile[pix * PS + c4 * 4] = v;
+    }
+    __syncthreads();
+
+    const int ly = tid / TW, lx = tid % TW;
+    float a0 = p.bias[0], a1 = p.bias[1], a2 = p.bias[2];
+    const f32x4* wv = (const f32x4*)p.w;   // [9][CIN] of (w0, w1, w2, 0): wave-uniform -> scalar loads
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* row = &tile[((ly + tap / 3) * LW + lx + tap % 3) * PS];
+#pragma unroll
+        for (int c4 = 0; c4 < CIN / 4; ++c4) {
+            const f32x4 a = *(const f32x4*)(row + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 wq = wv[tap * CIN + c4 * 4 + j];
+                a0 = fmaf(a[j], wq[0], a0);
+                a1 = fmaf(a[j], wq[1], a1);
+                a2 = fmaf(a[j], wq[2], a2);
+            }
+        }
+    }
+    const float r[3] = {tanhf(a0), tanhf(a1), tanhf(a2)};
+    const int y = y0 + ly, x = x0 + lx;
+    float e = 0.f;
+    if (y < p.h && x < p.w_) {
+        const size_t plane = (size_t)p.h * p.w_;
+        const size_t o = (size_t)n * 3 * plane + (size_t)y * p.w_ + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = p.x[o + c * plane] - r[c];
+            e += d * d;
+            if (p.recon) p.recon[o + c * plane] = r[c];
+        }
+        if (p.errmap) p.errmap[(size_t)n * plane + (size_t)y * p.w_ + x] = e / 3.0f;
+    }
+    block_partial(e, red, &p.partials[(size_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx]);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
+    constexpr int TH = 8, TW = 32, PS = CIN + 4;
+    __shared__ __attribute__((aligned(16))) float tile[TH * TW * PS];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    unsigned L = blockIdx.x;
+    const int tx = L % p.tiles_x; L /= p.tiles_x;
+    const int ty = L % p.tiles_y;
+    const int n = L / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* src = p.in + (size_t)n * p.h * p.w_ * CIN;
+    for (int idx = tid; idx < TH * TW * (CIN / 4); idx += 256) {
+        const int c4 = idx % (CIN / 4), pix = idx / (CIN / 4);
+        const int gy = y0 + pix / TW, gx = x0 + pix % TW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy < p.h && gx < p.w_) v = *(const f32x4*)(src + ((size_t)gy * p.w_ + gx) * CIN + c4 * 4);
+        *(f32x4*)&tile[pix * PS + c4 * 4] = v;
+    }
+    __syncthreads();
+
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = p.bias[k >> 2];
+    const float* row = &tile[tid * PS];
+#pragma unroll
+    for (int c4 = 0; c4 < CIN / 4; ++c4) {
+        const f32x4 a = *(const f32x4*)(row + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* wr = p.w + (c4 * 4 + j) * 12;   // IOHW row: (co, a, b), wave-uniform
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] = fmaf(a[j], wr[k], acc[k]);
+        }
+    }
+    const int y = y0 + tid / TW, x = x0 + tid % TW;
+    float e = 0.f;
+    if (y < p.h && x < p.w_) {
+        const int h2 = 2 * p.h, w2 = 2 * p.w_;
+        const size_t plane = (size_t)h2 * w2;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float ea[2] = {0.f, 0.f};
+            const size_t o = (size_t)n * 3 * plane + (size_t)(2 * y + a) * w2 + 2 * x;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                const float2 xv = *(const float2*)(p.x + o + co * plane);
+                const float r0 = tanhf(acc[co * 4 + a * 2 + 0]), r1 = tanhf(acc[co * 4 + a * 2 + 1]);
+                const float d0 = xv.x - r0, d1 = xv.y - r1;
+                ea[0] += d0 * d0;
+                ea[1] += d1 * d1;
+                if (p.recon) *(float2*)(p.recon + o + co * plane) = make_float2(r0, r1);
+            }
+            if (p.errmap)
+                *(float2*)(p.errmap + (size_t)n * plane + (size_t)(2 * y + a) * w2 + 2 * x) =
+                    make_float2(ea[0] / 3.0f, ea[1] / 3.0f);
+            e += ea[0] + ea[1];
+        }
+    }
+    block_partial(e, red, &p.partials[(size_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx]);
+}
+
+// One 64-lane block per clip (t frames): lane l adds partials l, l+64, ... in order, then the
+// wave butterfly; the result depends only on (frame data, tile grid), never on batch or rank.
+__global__ __launch_bounds__(64) void score_finalize_kernel(const float* partials, int nparts, float denom,
+                                                            float* frame_scores, float* seq_scores, int t) {
+    const int clip = blockIdx.x, lane = threadIdx.x;
+    float seq = 0.f;
+    for (int f = 0; f < t; ++f) {
+        const float* pp = partials + ((size_t)clip * t + f) * nparts;
+        float s = 0.f;
+        for (int i = lane; i < nparts; i += 64) s += pp[i];
+        s = wave_sum(s) / denom;
+        if (lane == 0 && frame_scores) frame_scores[(size_t)clip * t + f] = s;
+        seq += s;
+    }
+    if (lane == 0 && seq_scores) seq_scores[clip] = seq / (float)t;
+}
+
+extern "C" int vad_score_partials(int kind, int h2, int w2) {
+    if (kind == 0) return ((h2 + 7) / 8) * ((w2 + 31) / 32);
+    if (kind == 1) return ((h2 / 2 + 7) / 8) * ((w2 / 2 + 31) / 32);
+    return vad_fail(VAD_ERR_ARG, "score_partials: kind must be 0 (conv3x3 tail) or 1 (convT tail)");
+}
+
+extern "C" int vad_conv3x3_to3_score(const float* in, const float* w_packed, const float* bias3,
+                                     const float* x, float* partials, float* recon, float* errmap,
+                                     int n, int h2, int w2, int cin, void* stream) {
+    VAD_REQUIRE(in && w_packed && bias3 && x && partials, "conv3x3_to3_score: null pointer");
+    VAD_REQUIRE(cin == 32, "conv3x3_to3_score: cin=%d unsupported (the reference's dec4.3 has 32)", cin);
+    VAD_REQUIRE(n > 0 && h2 > 0 && w2 > 0, "conv3x3_to3_score: bad shape");
+    TailP p{in, w_packed, bias3, x, partials, recon, errmap, h2, w2, (w2 + 31) / 32, (h2 + 7) / 8};
+    const long long nb = (long long)n * p.tiles_x * p.tiles_y;
+    VAD_REQUIRE(nb < (1ll << 31), "conv3x3_to3_score: grid too large");
+    hipLaunchKernelGGL((conv3x3_to3_score_kernel<32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_convt2x2_to3_score(const float* in, const float* w_iohw, const float* bias3,
+                                      const float* x, float* partials, float* recon, float* errmap,
+                                      int n, int h, int w, int cin, void* stream) {
+    VAD_REQUIRE(in && w_iohw && bias3 && x && partials, "convt2x2_to3_score: null pointer");
+    VAD_REQUIRE(cin == 32, "convt2x2_to3_score: cin=%d unsupported (the reference's decoder.9 has 32)", cin);
+    VAD_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_to3_score: bad shape");
+    TailP p{in, w_iohw, bias3, x, partials, recon, errmap, h, w, (w + 31) / 32, (h + 7) / 8};
+    const long long nb = (long long)n * p.tiles_x * p.tiles_y;
+    VAD_REQUIRE(nb < (1ll << 31), "convt2x2_to3_score: grid too large");
+    hipLaunchKernelGGL((convt2x2_to3_score_kernel<32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_score_finalize(const float* partials, int nparts, int n, int h2, int w2,
+                                  float* frame_scores, float* seq_scores, int t, void* stream) {
+    VAD_REQUIRE(partials && nparts > 0 && n > 0 && t > 0 && n % t == 0, "score_finalize: bad arguments");
+    VAD_REQUIRE(frame_scores || seq_scores, "score_finalize: no output requested");
+    const float denom = 3.0f * (float)h2 * (float)w2;
+    hipLaunchKernelGGL(score_finalize_kernel, dim3(n / t), dim3(64), 0, (hipStream_t)stream,
+                       partials, nparts, denom, frame_scores, seq_scores, t);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// --------------------------------------------------------------------------------- transposes
+// Per frame [P][C] <-> [C][P] through a 32x33 LDS tile (both sides coalesced).
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int rows, int cols) {
+    __shared__ float t[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int j = ly; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + lx;
+        if (r < rows && c < cols) t[j][lx] = in[base + (size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = ly; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + lx;
+        if (r < rows && c < cols) out[base + (size_t)c * rows + r] = t[lx][j];
+    }
+}
+
+static int launch_transpose(const float* in, float* out, int n, int rows, int cols, void* stream) {
+    VAD_REQUIRE(in && out && n > 0 && rows > 0 && cols > 0 && n < 65536, "transpose: bad arguments");
+    dim3 g((cols + 31) / 32, (rows + 31) / 32, n);
+    VAD_REQUIRE(g.y < 65536, "transpose: too many row tiles");
+    hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, void* stream) {
+    return launch_transpose(in, out, n, h * w, c, stream);
+}
+extern "C" int vad_nchw_to_nhwc(const float* in, float* out, int n, int h, int w, int c, void* stream) {
+    return launch_transpose(in, out, n, c, h * w, stream);
+}
+
+// ----------------------------------------------------------------------- synthetic frames
+// Must stay bit-identical to synth.py: splitmix64 finaliser of (element index + seed*golden),
+// top byte -> u8 -> (u8/255 - 0.5)/0.5 in fp32 (mirrors ToTensor+Normalize, reference
+// utils/dataset.py:67-69).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_frames_kernel(float* out, unsigned long long seed, long long first_frame,
+                                                           long long total, int c, int h, int w, int anomalies) {
+    const unsigned long long golden = 0x9E3779B97F4A7C15ull;
+    const long long per = (long long)c * h * w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const unsigned long long gidx = (unsigned long long)(first_frame * per + i);
+        unsigned u8 = (unsigned)(mix64(gidx + seed * golden) >> 56);
+        if (anomalies) {
+            const long long f = first_frame + i / per;
+            const unsigned long long lab = mix64((unsigned long long)f + (seed ^ 0x5DEECE66Dull) * golden) >> 63;
+            if (lab) {
+                const unsigned long long z = mix64((unsigned long long)f + (seed ^ 0xB5297A4Dull) * golden);
+                const int ph = h - 32 + 1 > 1 ? h - 32 + 1 : 1, pw = w - 32 + 1 > 1 ? w - 32 + 1 : 1;
+                const int py = (int)((z & 0xFFFF) % (unsigned)ph), px = (int)(((z >> 16) & 0xFFFF) % (unsigned)pw);
+                const long long rem = i % per;
+                const int yy = (int)((rem / w) % h), xx = (int)(rem % w);
+                if (yy >= py && yy < py + 32 && xx >= px && xx < px + 32) u8 = 255;
+            }
+        }
+        float f32 = (float)u8;
+        f32 = f32 / 255.0f;
+        f32 = f32 - 0.5f;
+        out[i] = f32 / 0.5f;
+    }
+}
+
+extern "C" int vad_synth_frames(float* out, unsigned long long seed, long long first_frame, long long n,
+                                int c, int h, int w, int anomalies, void* stream) {
+    VAD_REQUIRE(out && n > 0 && c > 0 && h > 0 && w > 0 && first_frame >= 0, "synth_frames: bad arguments");
+    const long long total = n * c * h * w;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(synth_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       out, seed, first_frame, total, c, h, w, anomalies);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}

@@ -1,0 +1,262 @@
+// Whole-model launch sequences (image autoencoder, ConvLSTM video autoencoder) and the per-layer
+// hipEvent timing used by bench.py.  No allocation, no synchronisation on the launch path.
+//
+// Launch order follows ConvAutoencoder.forward / get_reconstruction_error
+// (reference models/autoencoder.py:181-221) and VideoAutoencoder.forward /
+// get_reconstruction_error (reference models/video_autoencoder.py:329-384).
+#include <vector>
+#include "vad_common.h"
+#include "vad_layout.h"
+
+// ------------------------------------------------------------------------------ profiling
+namespace {
+struct ProfRec { int slot; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;      // records since the last reset
+std::vector<hipEvent_t> g_pool;   // recycled events
+size_t g_pool_used = 0;
+
+hipEvent_t prof_event() {
+    if (g_pool_used == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_used++];
+}
+}  // namespace
+
+VadProfScope::VadProfScope(int slot_, hipStream_t stream_) : slot(-1), stream(stream_) {
+    if (!g_prof_on) return;
+    hipEvent_t a = prof_event(), b = prof_event();
+    if (!a || !b) return;
+    slot = slot_;
+    g_recs.push_back({slot_, a, b});
+    (void)hipEventRecord(a, stream);
+}
+VadProfScope::~VadProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_recs.back().b, stream);
+}
+
+extern "C" int vad_prof_enable(int on) { g_prof_on = on != 0; return VAD_OK; }
+extern "C" int vad_prof_reset(void) { g_recs.clear(); g_pool_used = 0; return VAD_OK; }
+extern "C" int vad_prof_read(float* ms, int* launches) {
+    VAD_REQUIRE(ms && launches, "prof_read: null pointer");
+    for (int i = 0; i < VAD_PROF_SLOTS; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    for (const ProfRec& r : g_recs) {
+        VAD_HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        VAD_HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.slot >= 0 && r.slot < VAD_PROF_SLOTS) { ms[r.slot] += t; launches[r.slot] += 1; }
+    }
+    return VAD_OK;
+}
+
+static const char* kImgSlots[] = {"enc1.0", "enc1.3+pool", "enc2.0", "enc2.3+pool", "enc3.0", "enc3.3+pool",
+                                  "enc4.0", "enc4.3+pool", "dec1.0", "dec1.3", "dec2.0", "dec2.3", "dec3.0",
+                                  "dec3.3", "dec4.0", "dec4.3+score", "finalize", "latent_nchw"};
+static const char* kVidSlots[] = {"enc.0+pool", "enc.4+pool", "enc.8+pool", "enc.12+pool", "convlstm", "proj",
+                                  "dec.0", "dec.3", "dec.6", "dec.9+score", "finalize"};
+extern "C" const char* vad_prof_slot_name(int model, int slot) {
+    if (model == 0 && slot >= 0 && slot < (int)(sizeof kImgSlots / sizeof *kImgSlots)) return kImgSlots[slot];
+    if (model == 1 && slot >= 0 && slot < (int)(sizeof kVidSlots / sizeof *kVidSlots)) return kVidSlots[slot];
+    return "";
+}
+
+#define TRY(call) do { int rc_ = (call); if (rc_ != VAD_OK) return rc_; } while (0)
+
+static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------ image model
+static size_t img_act_floats(int h, int w, int latent) {
+    size_t m = (size_t)h * w * 32;                                   // enc1.0 / dec4.0 outputs
+    const size_t e4 = (size_t)(h / 8) * (w / 8) * latent;            // enc4.0 output
+    return e4 > m ? e4 : m;
+}
+
+extern "C" size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent) {
+    if (chunk <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16 || latent <= 0 || latent % 32) return 0;
+    const size_t act = up256(sizeof(float) * chunk * img_act_floats(h, w, latent));
+    const size_t parts = up256(sizeof(float) * chunk * (size_t)vad_score_partials(0, h, w));
+    return 2 * act + parts;
+}
+
+extern "C" int vad_img_score(const float* x, long long b, int h, int w, int latent, const float* packed,
+                             void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
+                             float* recon, float* latent_out, void* stream) {
+    VAD_REQUIRE(x && packed && ws, "img_score: null pointer");
+    VAD_REQUIRE(b > 0 && chunk > 0, "img_score: batch=%lld chunk=%d must be positive", b, chunk);
+    VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
+                "img_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
+    VAD_REQUIRE(latent > 0 && latent % 32 == 0, "img_score: latent_dim=%d must be a positive multiple of 32", latent);
+    VAD_REQUIRE(scores || errmap || recon || latent_out, "img_score: no output requested");
+    const size_t need = vad_img_workspace_bytes(chunk, h, w, latent);
+    if (ws_bytes < need) return vad_fail(VAD_ERR_WS, "img_score: workspace %zu B < required %zu B", ws_bytes, need);
+    VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "img_score: workspace must be 256-B and weights 16-B aligned");
+
+    hipStream_t s = (hipStream_t)stream;
+    const ImgLayout L = img_layout(latent);
+    const size_t act = up256(sizeof(float) * chunk * img_act_floats(h, w, latent));
+    float* A = (float*)ws;
+    float* B = (float*)((char*)ws + act);
+    float* parts = (float*)((char*)ws + 2 * act);
+    const int nparts = vad_score_partials(0, h, w);
+    const bool need_decoder = scores || errmap || recon;
+    const int ch[5] = {3, 32, 64, 128, latent};
+    const int dch[5] = {latent, 128, 64, 32, 32};
+#define W_(i) (packed + L.layer[i].w)
+#define B_(i) (packed + L.layer[i].b)
+
+    for (long long f0 = 0; f0 < b; f0 += chunk) {
+        const int n = (int)((b - f0 < chunk) ? (b - f0) : chunk);
+        const float* xin = x + (size_t)f0 * 3 * h * w;
+        int hh = h, ww = w;
+        // encoder: 4 x [conv-BN-LeakyReLU, conv-BN-LeakyReLU-MaxPool] (models/autoencoder.py:38-79)
+        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3(xin, W_(0), B_(0), A, n, hh, ww, 32, VAD_ACT_LEAKY, 0, s)); }
+        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), B, 0, n, hh, ww, 32, 32, VAD_ACT_LEAKY, 1, s)); }
+        for (int blk = 1; blk < 4; ++blk) {
+            hh /= 2; ww /= 2;
+            { VadProfScope ps(2 * blk, s);
+              TRY(vad_conv3x3(B, 0, W_(2 * blk), B_(2 * blk), A, 0, n, hh, ww, ch[blk], ch[blk + 1], VAD_ACT_LEAKY, 0, s)); }
+            { VadProfScope ps(2 * blk + 1, s);
+              TRY(vad_conv3x3(A, 0, W_(2 * blk + 1), B_(2 * blk + 1), B, 0, n, hh, ww, ch[blk + 1], ch[blk + 1], VAD_ACT_LEAKY, 1, s)); }
+        }
+        hh /= 2; ww /= 2;   // B = latent code [n, H/16, W/16, latent]
+        if (latent_out) {
+            VadProfScope ps(17, s);
+            TRY(vad_nhwc_to_nchw(B, latent_out + (size_t)f0 * latent * hh * ww, n, hh, ww, latent, s));
+        }
+        if (!need_decoder) continue;
+        // decoder: 3 x [convT-BN-ReLU, conv-BN-ReLU] + [convT-BN-ReLU, conv-Tanh] (models/autoencoder.py:103-139)
+        for (int blk = 0; blk < 4; ++blk) {
+            { VadProfScope ps(8 + 2 * blk, s);
+              TRY(vad_convt2x2(B, 0, W_(8 + 2 * blk), B_(8 + 2 * blk), A, 0, n, hh, ww, dch[blk], dch[blk + 1], VAD_ACT_RELU, s)); }
+            hh *= 2; ww *= 2;
+            if (blk < 3) {
+                VadProfScope ps(9 + 2 * blk, s);
+                TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, s));
+            }
+        }
+        { VadProfScope ps(15, s);
+          TRY(vad_conv3x3_to3_score(A, W_(15), B_(15), xin, parts,
+                                    recon ? recon + (size_t)f0 * 3 * h * w : nullptr,
+                                    errmap ? errmap + (size_t)f0 * h * w : nullptr, n, h, w, 32, s)); }
+        if (scores) {
+            VadProfScope ps(16, s);
+            TRY(vad_score_finalize(parts, nparts, n, h, w, scores + f0, nullptr, 1, s));
+        }
+    }
+#undef W_
+#undef B_
+    return VAD_OK;
+}
+
+// ------------------------------------------------------------------------------ video model
+namespace {
+struct VidWs {
+    size_t act, enc, hseq, cst, proj, parts, total;
+};
+VidWs vid_ws(int chunk, int t, int h, int w, int latent, int hid, int layers) {
+    VidWs z{};
+    const size_t n = (size_t)chunk * t, p16 = (size_t)(h / 16) * (w / 16);
+    z.act = up256(sizeof(float) * n * (size_t)h * w * 8);          // [n, H/2, W/2, 32]
+    z.enc = up256(sizeof(float) * n * p16 * latent);
+    z.hseq = up256(sizeof(float) * n * p16 * hid);
+    z.cst = up256(sizeof(float) * (size_t)chunk * p16 * hid);
+    z.proj = (hid != latent) ? z.enc : 0;
+    z.parts = up256(sizeof(float) * n * (size_t)vad_score_partials(1, h, w));
+    z.total = 2 * z.act + z.enc + (layers > 1 ? 2 : 1) * z.hseq + z.cst + z.proj + z.parts;
+    return z;
+}
+}  // namespace
+
+extern "C" size_t vad_vid_workspace_bytes(int chunk, int t, int h, int w, int latent, int hid, int layers) {
+    if (chunk <= 0 || t <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16) return 0;
+    if (vad_vid_packed_floats(latent, hid, layers) == 0) return 0;
+    return vid_ws(chunk, t, h, w, latent, hid, layers).total;
+}
+
+extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
+                             const float* packed, void* ws, size_t ws_bytes, int chunk,
+                             float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
+    VAD_REQUIRE(x && packed && ws, "vid_score: null pointer");
+    VAD_REQUIRE(b > 0 && t > 0 && chunk > 0, "vid_score: clips=%lld T=%d chunk=%d must be positive", b, t, chunk);
+    VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
+                "vid_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
+    if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;   // message already set
+    VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score: no output requested");
+    const VidWs Z = vid_ws(chunk, t, h, w, latent, hid, layers);
+    if (ws_bytes < Z.total) return vad_fail(VAD_ERR_WS, "vid_score: workspace %zu B < required %zu B", ws_bytes, Z.total);
+    VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "vid_score: workspace must be 256-B and weights 16-B aligned");
+
+    hipStream_t s = (hipStream_t)stream;
+    const VidLayout L = vid_layout(latent, hid, layers);
+    char* base = (char*)ws;
+    float* A = (float*)base; base += Z.act;
+    float* Bf = (float*)base; base += Z.act;
+    float* E = (float*)base; base += Z.enc;
+    float* HS[2];
+    HS[0] = (float*)base; base += Z.hseq;
+    HS[1] = HS[0];
+    if (layers > 1) { HS[1] = (float*)base; base += Z.hseq; }
+    float* C = (float*)base; base += Z.cst;
+    float* P = nullptr;
+    if (L.has_proj) { P = (float*)base; base += Z.proj; }
+    float* parts = (float*)base;
+    const int nparts = vad_score_partials(1, h, w);
+    const int h16 = h / 16, w16 = w / 16;
+    const long long fs_lat = (long long)h16 * w16 * latent, fs_hid = (long long)h16 * w16 * hid;
+#define W_(i) (packed + L.layer[i].w)
+#define B_(i) (packed + L.layer[i].b)
+
+    for (long long c0 = 0; c0 < b; c0 += chunk) {
+        const int nc = (int)((b - c0 < chunk) ? (b - c0) : chunk);
+        const int n = nc * t;
+        const float* xin = x + (size_t)c0 * t * 3 * h * w;
+        // VideoEncoder: 4 x conv-BN-LeakyReLU-MaxPool on the B*T flattened frames
+        // (models/video_autoencoder.py:191-215, :222-228)
+        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3(xin, W_(0), B_(0), A, n, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, n, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, n, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, n, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, s)); }
+        // ConvLSTM: layers outer, time inner, zero initial state (models/video_autoencoder.py:144-166)
+        for (int l = 0; l < layers; ++l) {
+            const float* xin_l = (l == 0) ? E : HS[(l - 1) & 1];
+            const long long fs_in = (l == 0) ? fs_lat : fs_hid;
+            const int cin_x = (l == 0) ? latent : hid;
+            float* hs = HS[l & 1];
+            for (int ti = 0; ti < t; ++ti) {
+                VadProfScope ps(4, s);
+                TRY(vad_convlstm_step(xin_l + (size_t)ti * fs_in, (long long)t * fs_in,
+                                      ti ? hs + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
+                                      ti ? C : nullptr, W_(4 + l), B_(4 + l),
+                                      hs + (size_t)ti * fs_hid, (long long)t * fs_hid, C,
+                                      nc, h16, w16, cin_x, hid, s));
+            }
+        }
+        const float* dec_in = HS[(layers - 1) & 1];
+        int li = 4 + layers;
+        if (L.has_proj) {   // models/video_autoencoder.py:346-349
+            VadProfScope ps(5, s);
+            TRY(vad_conv1x1(dec_in, W_(li), B_(li), P, (long long)n * h16 * w16, hid, latent, s));
+            dec_in = P;
+            ++li;
+        }
+        // VideoDecoder: 3 x convT-BN-ReLU + convT-Tanh (models/video_autoencoder.py:242-261)
+        { VadProfScope ps(6, s); TRY(vad_convt2x2(dec_in, 0, W_(li), B_(li), A, 0, n, h16, w16, latent, 128, VAD_ACT_RELU, s)); }
+        { VadProfScope ps(7, s); TRY(vad_convt2x2(A, 0, W_(li + 1), B_(li + 1), Bf, 0, n, h / 8, w / 8, 128, 64, VAD_ACT_RELU, s)); }
+        { VadProfScope ps(8, s); TRY(vad_convt2x2(Bf, 0, W_(li + 2), B_(li + 2), A, 0, n, h / 4, w / 4, 64, 32, VAD_ACT_RELU, s)); }
+        { VadProfScope ps(9, s);
+          TRY(vad_convt2x2_to3_score(A, W_(li + 3), B_(li + 3), xin, parts,
+                                     recon ? recon + (size_t)c0 * t * 3 * h * w : nullptr,
+                                     errmap ? errmap + (size_t)c0 * t * h * w : nullptr, n, h / 2, w / 2, 32, s)); }
+        if (seq_scores || frame_scores) {
+            VadProfScope ps(10, s);
+            TRY(vad_score_finalize(parts, nparts, n, h, w, frame_scores ? frame_scores + (size_t)c0 * t : nullptr,
+                                   seq_scores ? seq_scores + c0 : nullptr, t, s));
+        }
+    }
+#undef W_
+#undef B_
+    return VAD_OK;
+}

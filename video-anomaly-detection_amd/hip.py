@@ -1,0 +1,138 @@
+"""ctypes binding of libvad_hip.so (the C ABI declared in include/vad_hip.h).
+
+This is the reference-side stub a maintainer would add: raw device pointers
+from `tensor.data_ptr()`, the current HIP stream handle, plain ints.  There is NO fallback: if the
+library is missing, `lib()` raises, and every scoring entry point of the package goes through it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_DIR = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libvad_hip.so"
+SOURCES = ["conv_mfma.hip", "tail.hip", "vad_api.hip", "pack.cpp"]
+HEADERS = ["vad_common.h", "vad_layout.h"]
+
+VAD_OK = 0
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+PROF_SLOTS = 32
+
+_lock = threading.Lock()
+_lib = None
+calls = {"img_score": 0, "vid_score": 0}   # tests assert the native path really ran
+
+
+class VadError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile libvad_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + [CSRC / h for h in HEADERS] + [REPO_DIR / "include" / "vad_hip.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           f"-I{REPO_DIR / 'include'}", f"-I{CSRC}", "-o", str(LIB_PATH)] + [str(s) for s in srcs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_ll = C.c_longlong
+_i = C.c_int
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); every symbol of include/vad_hip.h
+SIGNATURES = {
+    "vad_abi_version": (_i, []),
+    "vad_last_error": (C.c_char_p, []),
+    "vad_pack_conv3x3_floats": (_sz, [_i, _i]),
+    "vad_pack_conv3x3": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vad_pack_conv3x3_c3_floats": (_sz, [_i]),
+    "vad_pack_conv3x3_c3": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "vad_pack_convt2x2_floats": (_sz, [_i, _i]),
+    "vad_pack_convt2x2": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vad_pack_conv1x1_floats": (_sz, [_i, _i]),
+    "vad_pack_conv1x1": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "vad_pack_conv3x3_to3_floats": (_sz, [_i]),
+    "vad_pack_conv3x3_to3": (_i, [_vp, _i, _vp]),
+    "vad_conv3x3_c3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_conv3x3": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_convt2x2": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_conv1x1": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "vad_convlstm_step": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vad_score_partials": (_i, [_i, _i, _i]),
+    "vad_conv3x3_to3_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_convt2x2_to3_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_score_finalize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "vad_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_synth_frames": (_i, [_vp, C.c_ulonglong, _ll, _ll, _i, _i, _i, _i, _vp]),
+    "vad_img_packed_floats": (_sz, [_i, _i]),
+    "vad_img_pack": (_i, [_vp, _i, _i, _i, _vp]),
+    "vad_img_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "vad_img_score": (_i, [_vp, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_vid_nparams": (_i, [_i, _i]),
+    "vad_vid_packed_floats": (_sz, [_i, _i, _i]),
+    "vad_vid_pack": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "vad_vid_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_prof_enable": (_i, [_i]),
+    "vad_prof_reset": (_i, []),
+    "vad_prof_read": (_i, [_vp, _vp]),
+    "vad_prof_slot_name": (C.c_char_p, [_i, _i]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load the library (once).  Raises VadError if it has not been built: no silent fallback."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise VadError(
+                    f"{LIB_PATH} is missing: the HIP scoring path has no fallback. "
+                    "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+            l = C.CDLL(str(LIB_PATH))
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(l, name)
+                fn.restype, fn.argtypes = res, args
+            if l.vad_abi_version() != 1:
+                raise VadError("libvad_hip.so ABI version mismatch")
+            _lib = l
+        return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != VAD_OK:
+        msg = lib().vad_last_error().decode("utf-8", "replace")
+        raise VadError(f"{what or 'libvad_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Raw address of a torch tensor / numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pointer_array(arrays) -> "C.Array":
+    return (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])

@@ -1,0 +1,239 @@
+"""Drop-in `VideoAutoencoder` (reference models/video_autoencoder.py:279-384) on the MI355X HIP path.
+
+Module tree, constructor arguments and state_dict keys follow the reference
+(`encoder.encoder.{0,1,4,5,8,9,12,13}`, `convlstm.cells.N.conv`, optional `proj`,
+`decoder.decoder.{0,1,3,4,6,7,9}`).  Inference under `eval()` + `torch.no_grad()` runs only through
+libvad_hip.so; `train()` / autograd keep the stock torch.nn composition the reference's
+train_video.py differentiates through (reference train_video.py:44-65).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .autoencoder import LEAK, _HipScorer, _init_like_reference
+
+
+class ConvLSTMCell(nn.Module):
+    """One gate convolution over cat[x, h] -> (i, f, g, o) (reference models/video_autoencoder.py:24-91)."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, kernel_size: int = 3):
+        super().__init__()
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.conv = nn.Conv2d(input_dim + hidden_dim, 4 * hidden_dim, kernel_size=kernel_size,
+                              padding=kernel_size // 2, bias=True)
+
+    def forward(self, x, hidden_state):
+        h_cur, c_cur = hidden_state
+        i, f, g, o = torch.split(self.conv(torch.cat([x, h_cur], dim=1)), self.hidden_dim, dim=1)
+        c_next = torch.sigmoid(f) * c_cur + torch.sigmoid(i) * torch.tanh(g)
+        h_next = torch.sigmoid(o) * torch.tanh(c_next)
+        return h_next, c_next
+
+    def init_hidden(self, batch_size, height, width, device):
+        shape = (batch_size, self.hidden_dim, height, width)
+        return torch.zeros(shape, device=device), torch.zeros(shape, device=device)
+
+
+class ConvLSTM(nn.Module):
+    """Stacked cells; layers outer, time inner (reference models/video_autoencoder.py:94-179)."""
+
+    def __init__(self, input_dim: int, hidden_dims, kernel_size: int = 3, num_layers: int = 2,
+                 batch_first: bool = True, return_all_layers: bool = False):
+        super().__init__()
+        self.input_dim = input_dim
+        self.hidden_dims = hidden_dims if isinstance(hidden_dims, list) else [hidden_dims] * num_layers
+        self.num_layers = len(self.hidden_dims)
+        self.batch_first = batch_first
+        self.return_all_layers = return_all_layers
+        dims = [input_dim] + self.hidden_dims
+        self.cells = nn.ModuleList(ConvLSTMCell(dims[i], dims[i + 1], kernel_size) for i in range(self.num_layers))
+
+    def forward(self, x, hidden_state=None):
+        if not self.batch_first:
+            x = x.permute(1, 0, 2, 3, 4)
+        b, t, _, h, w = x.size()
+        if hidden_state is None:
+            hidden_state = self._init_hidden(b, h, w, x.device)
+        outputs, finals = [], []
+        cur = x
+        for layer, cell in enumerate(self.cells):
+            hs, cs = hidden_state[layer]
+            steps = []
+            for ti in range(t):
+                hs, cs = cell(cur[:, ti], (hs, cs))
+                steps.append(hs)
+            cur = torch.stack(steps, dim=1)
+            outputs.append(cur)
+            finals.append((hs, cs))
+        if self.return_all_layers:
+            return outputs, finals
+        return outputs[-1], finals[-1]
+
+    def _init_hidden(self, batch_size, height, width, device):
+        return [cell.init_hidden(batch_size, height, width, device) for cell in self.cells]
+
+
+def _per_frame(seq_module: nn.Module, x):
+    """Apply a frame-wise stack to [B,C,H,W] or [B,T,C,H,W] (reference models/video_autoencoder.py:217-231)."""
+    if x.dim() != 5:
+        return seq_module(x)
+    b, t = x.shape[:2]
+    y = seq_module(x.reshape(b * t, *x.shape[2:]))
+    return y.view(b, t, *y.shape[1:])
+
+
+class VideoEncoder(nn.Module):
+    """4 x [conv3x3-BN-LeakyReLU-MaxPool2] per frame (reference models/video_autoencoder.py:182-231)."""
+
+    def __init__(self, in_channels: int = 3, latent_dim: int = 128):
+        super().__init__()
+        widths = [in_channels, 32, 64, 128, latent_dim]
+        layers = []
+        for i in range(4):
+            layers += [nn.Conv2d(widths[i], widths[i + 1], kernel_size=3, padding=1), nn.BatchNorm2d(widths[i + 1]),
+                       nn.LeakyReLU(LEAK, inplace=True), nn.MaxPool2d(2, 2)]
+        self.encoder = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return _per_frame(self.encoder, x)
+
+
+class VideoDecoder(nn.Module):
+    """3 x [convT2x2s2-BN-ReLU] + convT-Tanh per frame (reference models/video_autoencoder.py:234-276)."""
+
+    def __init__(self, out_channels: int = 3, latent_dim: int = 128):
+        super().__init__()
+        widths = [latent_dim, 128, 64, 32]
+        layers = []
+        for i in range(3):
+            layers += [nn.ConvTranspose2d(widths[i], widths[i + 1], kernel_size=2, stride=2),
+                       nn.BatchNorm2d(widths[i + 1]), nn.ReLU(inplace=True)]
+        layers += [nn.ConvTranspose2d(widths[3], out_channels, kernel_size=2, stride=2), nn.Tanh()]
+        self.decoder = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return _per_frame(self.decoder, x)
+
+
+class VideoAutoencoder(nn.Module):
+    """Reference `VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)`
+    (models/video_autoencoder.py:279-384)."""
+
+    #: clips per launch group
+    chunk = 16
+
+    def __init__(self, in_channels: int = 3, latent_dim: int = 128, lstm_hidden_dim: int = 128,
+                 lstm_num_layers: int = 2):
+        super().__init__()
+        self.in_channels = in_channels
+        self.latent_dim = latent_dim
+        self.lstm_hidden_dim = lstm_hidden_dim
+        self.lstm_num_layers = lstm_num_layers
+        self.encoder = VideoEncoder(in_channels, latent_dim)
+        self.convlstm = ConvLSTM(input_dim=latent_dim, hidden_dims=[lstm_hidden_dim] * lstm_num_layers,
+                                 kernel_size=3, num_layers=lstm_num_layers, batch_first=True,
+                                 return_all_layers=False)
+        self.proj = (nn.Conv2d(lstm_hidden_dim, latent_dim, kernel_size=1)
+                     if lstm_hidden_dim != latent_dim else nn.Identity())
+        self.decoder = VideoDecoder(in_channels, latent_dim)
+        _init_like_reference(self)
+        self._hip = _HipScorer()
+
+    # ------------------------------------------------------------------ HIP path
+    def _use_hip(self) -> bool:
+        return not self.training and not torch.is_grad_enabled()
+
+    def _packed(self, device) -> torch.Tensor:
+        key = _HipScorer.state_key(self)
+        if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
+            l = hip.lib()
+            n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
+            if n == 0 or self.in_channels != 3:
+                raise hip.VadError(
+                    f"VideoAutoencoder(in_channels={self.in_channels}, latent_dim={self.latent_dim}, "
+                    f"lstm_hidden_dim={self.lstm_hidden_dim}, lstm_num_layers={self.lstm_num_layers}) is not "
+                    "supported by the HIP path (needs in_channels == 3, latent_dim % 32 == 0, "
+                    "lstm_hidden_dim % 64 == 0, 1 <= layers <= 8)")
+            params = _HipScorer.float_params(self)
+            blob = np.empty(n, dtype=np.float32)
+            hip.check(l.vad_vid_pack(hip.pointer_array(params), len(params), self.latent_dim,
+                                     self.lstm_hidden_dim, self.lstm_num_layers, blob.ctypes.data), "vad_vid_pack")
+            self._hip.packed = torch.from_numpy(blob).to(device)
+            self._hip.key = key
+        return self._hip.packed
+
+    def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False):
+        if x.dim() != 5 or x.shape[2] != 3:
+            raise hip.VadError(f"expected input [B,T,3,H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise hip.VadError(
+                "VideoAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
+                "'cuda' (there is no CPU fallback)")
+        b, t, _, h, w = x.shape
+        x = x.contiguous().float()
+        l = hip.lib()
+        dev = x.device
+        packed = self._packed(dev)
+        chunk = max(1, min(int(self.chunk), b))
+        dims = (self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
+        nbytes = l.vad_vid_workspace_bytes(chunk, t, h, w, *dims)
+        if nbytes == 0:
+            raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
+        ws = self._hip.workspace(nbytes, dev)
+        out = {}
+        if seq:
+            out["seq"] = torch.empty(b, dtype=torch.float32, device=dev)
+        if frame:
+            out["frame"] = torch.empty(b, t, dtype=torch.float32, device=dev)
+        if errmap:
+            out["errmap"] = torch.empty(b, t, 1, h, w, dtype=torch.float32, device=dev)
+        if recon:
+            out["recon"] = torch.empty(b, t, 3, h, w, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            hip.check(l.vad_vid_score(x.data_ptr(), b, t, h, w, *dims, packed.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      chunk, hip.ptr(out.get("seq")), hip.ptr(out.get("frame")),
+                                      hip.ptr(out.get("errmap")), hip.ptr(out.get("recon")), hip.current_stream()),
+                      "vad_vid_score")
+        hip.calls["vid_score"] += 1
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def _torch_forward(self, x):
+        encoded = self.encoder(x)
+        lstm_out, _ = self.convlstm(encoded)
+        b, t, c, h, w = lstm_out.size()
+        projected = self.proj(lstm_out.reshape(b * t, c, h, w)).view(b, t, -1, h, w)
+        return self.decoder(projected)
+
+    def forward(self, x):
+        """[B,T,C,H,W] -> reconstruction of the same shape (reference models/video_autoencoder.py:329-354)."""
+        if self._use_hip():
+            return self._run_hip(x, recon=True)["recon"]
+        return self._torch_forward(x)
+
+    def get_reconstruction_error(self, x, per_frame: bool = False, per_pixel: bool = False):
+        """[B] clip scores, [B,T] frame scores or [B,T,1,H,W] maps; per_pixel wins when both flags are
+        set (reference models/video_autoencoder.py:356-384)."""
+        if self._use_hip():
+            if per_pixel:
+                return self._run_hip(x, errmap=True)["errmap"]
+            if per_frame:
+                return self._run_hip(x, frame=True)["frame"]
+            return self._run_hip(x, seq=True)["seq"]
+        error = (x - self._torch_forward(x)) ** 2
+        if per_pixel:
+            return error.mean(dim=2, keepdim=True)
+        if per_frame:
+            return error.mean(dim=[2, 3, 4])
+        return error.mean(dim=[1, 2, 3, 4])
+
+    def score_all(self, x):
+        """One pass returning recon, error maps, frame and clip scores (the reference's dense video mode
+        runs three forwards per window for these: evaluate_video.py:350-352)."""
+        if not self._use_hip():
+            raise hip.VadError("score_all is an inference entry point: call under eval() and torch.no_grad()")
+        return self._run_hip(x, seq=True, frame=True, errmap=True, recon=True)
