@@ -1,0 +1,148 @@
+"""GPU parity: every layer kernel of libvad_hip.so (called through the C ABI) against the CPU oracle on
+the same seeded inputs.  fp32 tolerances are written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import max_abs
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 3e-5   # outputs are O(1); fp32 accumulation-order noise over K <= 2304 terms
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _conv_params(rng, cout, cin, k=3):
+    w = (rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    bn = [rng.uniform(0.5, 1.5, cout), rng.standard_normal(cout) * 0.1, rng.standard_normal(cout) * 0.1,
+          rng.uniform(0.25, 1.75, cout)]
+    return w, b, [a.astype(np.float32) for a in bn]
+
+
+def _ref_conv(x, w, b, bn, act, pool):
+    y = c_oracle.conv2d(x, w, b, 3)
+    if bn is not None:
+        y = c_oracle.batchnorm_eval(y, *bn)
+    if act == 1:
+        y = np.where(y > 0, y, np.float32(0.2) * y)
+    elif act == 2:
+        y = np.maximum(y, 0)
+    if pool:
+        y = c_oracle.maxpool2(y)
+    return y
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act,pool", [
+    (3, 32, 16, 16, 1, False), (3, 32, 20, 36, 1, True), (3, 32, 19, 23, 2, False), (3, 64, 32, 32, 0, True),
+    (32, 32, 16, 16, 1, True), (32, 32, 18, 22, 2, False), (32, 64, 24, 40, 1, False), (64, 64, 16, 32, 1, True),
+    (64, 128, 8, 8, 1, False), (128, 128, 12, 20, 2, False), (128, 256, 4, 4, 1, False), (256, 256, 6, 10, 1, True),
+    (32, 96, 10, 10, 0, False), (64, 192, 5, 7, 2, False),
+])
+def test_conv3x3(cin, cout, h, w, act, pool):
+    import hip_helpers as H
+    rng = _rng(cin * 1000 + cout + h)
+    x = rng.standard_normal((2, cin, h, w)).astype(np.float32)
+    wt, b, bn = _conv_params(rng, cout, cin)
+    got = H.conv3x3(x, wt, b, bn, act, pool)
+    ref = _ref_conv(x, wt, b, bn, act, pool)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert max_abs(got, ref) < ATOL
+
+
+def test_conv3x3_no_bn_and_frame_strides():
+    import hip_helpers as H
+    rng = _rng(5)
+    x = rng.standard_normal((3, 32, 8, 8)).astype(np.float32)
+    wt, b, _ = _conv_params(rng, 32, 32)
+    assert max_abs(H.conv3x3(x, wt, b, None, 0, False), _ref_conv(x, wt, b, None, 0, False)) < ATOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act", [(256, 128, 4, 4, 2), (128, 64, 8, 6, 2), (64, 32, 16, 16, 2),
+                                              (32, 32, 9, 13, 2), (32, 64, 3, 5, 0), (128, 128, 2, 2, 1)])
+def test_convt2x2(cin, cout, h, w, act):
+    import hip_helpers as H
+    rng = _rng(cin + cout * 7 + h)
+    x = rng.standard_normal((3, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cin, cout, 2, 2)) * np.sqrt(1.0 / cin)).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    bn = [a.astype(np.float32) for a in (rng.uniform(0.5, 1.5, cout), rng.standard_normal(cout) * 0.1,
+                                         rng.standard_normal(cout) * 0.1, rng.uniform(0.25, 1.75, cout))]
+    ref = c_oracle.batchnorm_eval(c_oracle.convt2x2(x, wt, b), *bn)
+    ref = np.where(ref > 0, ref, np.float32(0.2) * ref) if act == 1 else (np.maximum(ref, 0) if act == 2 else ref)
+    got = H.convt2x2(x, wt, b, bn, act)
+    assert np.isfinite(got).all() and max_abs(got, ref) < ATOL
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (128, 128), (64, 96)])
+def test_conv1x1(cin, cout):
+    import hip_helpers as H
+    rng = _rng(cin + cout)
+    x = rng.standard_normal((2, cin, 5, 7)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * np.sqrt(1.0 / cin)).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    assert max_abs(H.conv1x1(x, wt, b), c_oracle.conv2d(x, wt, b, 1)) < ATOL
+
+
+def test_convlstm_step_golden(vad, golden):
+    """One ConvLSTMCell step against the REFERENCE's own output (tests/golden/convlstm_unit.npz)."""
+    import hip_helpers as H
+    g = golden("convlstm_unit.npz")
+    st = vad.synth.synthetic_state({"conv.weight": (256, 96, 3, 3), "conv.bias": (256,)}, 31)
+    h1, c1 = H.convlstm_step(g["x"], g["h"], g["c"], st["conv.weight"], st["conv.bias"])
+    assert max_abs(h1, g["h1"]) < 2e-5 and max_abs(c1, g["c1"]) < 2e-5
+
+
+@pytest.mark.parametrize("cx,hid,h,w,zero_state", [(32, 64, 8, 8, True), (128, 128, 16, 16, False), (64, 64, 5, 9, False)])
+def test_convlstm_step_oracle(cx, hid, h, w, zero_state):
+    import hip_helpers as H
+    rng = _rng(cx + hid + h)
+    x = rng.standard_normal((2, cx, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((4 * hid, cx + hid, 3, 3)) * np.sqrt(1.0 / ((cx + hid) * 9))).astype(np.float32)
+    b = (rng.standard_normal(4 * hid) * 0.1).astype(np.float32)
+    if zero_state:
+        hp = cp = None
+        h0 = c0 = np.zeros((2, hid, h, w), np.float32)
+    else:
+        hp = h0 = (rng.standard_normal((2, hid, h, w)) * 0.5).astype(np.float32)
+        cp = c0 = rng.standard_normal((2, hid, h, w)).astype(np.float32)
+    rh, rc = c_oracle.convlstm_cell(x, h0, c0, wt, b)
+    gh, gc = H.convlstm_step(x, hp, cp, wt, b)
+    assert max_abs(gh, rh) < 2e-5 and max_abs(gc, rc) < 2e-5
+
+
+def test_synth_frames_bit_exact(vad):
+    """Device generator == numpy generator, bit for bit, including the anomaly patches and offsets."""
+    for first, n, h, w, anomalies in [(0, 4, 32, 48, False), (1000, 6, 64, 64, True), (12345, 2, 256, 256, True)]:
+        ref = vad.synth.frames(0xC0FFEE, first, n, 3, h, w, anomalies=anomalies)
+        got = vad.scoring.synth_frames_device(0xC0FFEE, first, n, h, w, anomalies=anomalies).cpu().numpy()
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+
+
+def test_transposes():
+    import hip_helpers as H
+    l = H.hip.lib()
+    rng = _rng(3)
+    x = rng.standard_normal((3, 40, 5, 7)).astype(np.float32)       # NCHW
+    xin = H.dev(x)
+    out = torch.empty(3, 5, 7, 40, device="cuda")
+    H.hip.check(l.vad_nchw_to_nhwc(xin.data_ptr(), out.data_ptr(), 3, 5, 7, 40, H.stream()))
+    assert np.array_equal(out.cpu().numpy(), x.transpose(0, 2, 3, 1))
+    back = torch.empty(3, 40, 5, 7, device="cuda")
+    H.hip.check(l.vad_nhwc_to_nchw(out.data_ptr(), back.data_ptr(), 3, 5, 7, 40, H.stream()))
+    assert np.array_equal(back.cpu().numpy(), x)
+
+
+def test_bad_arguments_are_rejected():
+    import hip_helpers as H
+    l = H.hip.lib()
+    t = torch.zeros(16, device="cuda")
+    assert l.vad_conv3x3(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 1, 4, 4, 24, 32, 0, 0, None) == -1
+    assert b"multiples of 32" in l.vad_last_error()
+    assert l.vad_conv3x3(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 1, 5, 4, 32, 32, 0, 1, None) == -1
+    assert l.vad_img_score(t.data_ptr(), 1, 30, 32, 256, t.data_ptr(), t.data_ptr(), 64, 1, t.data_ptr(), None, None, None, None) == -1
+    assert l.vad_img_score(t.data_ptr(), 1, 32, 32, 256, t.data_ptr(), t.data_ptr(), 64, 1, t.data_ptr(), None, None, None, None) == -3

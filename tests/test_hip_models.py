@@ -1,0 +1,195 @@
+"""GPU parity of the whole scoring path, through the drop-in modules (ctypes -> libvad_hip.so), against
+(1) the golden vectors captured from the reference itself and (2) the CPU oracle on fresh seeded inputs.
+
+Tolerance: BASELINE.json's north_star asks for per-frame scores within 1e-4 relative of the reference CPU
+path; the exact-fp32 MFMA path is held to 1e-5 here."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_synthetic, max_abs, rel_err
+from oracle import torch_oracle
+
+pytestmark = pytest.mark.gpu
+
+SCORE_RTOL = 1e-5
+ACT_ATOL = 5e-5
+
+
+def _img_model(vad, latent, wseed):
+    m = vad.ConvAutoencoder(in_channels=3, latent_dim=latent)
+    st = load_synthetic(vad, m, wseed)
+    return m.cuda().eval(), st
+
+
+def _vid_model(vad, latent, hid, layers, wseed):
+    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid, lstm_num_layers=layers)
+    st = load_synthetic(vad, m, wseed)
+    return m.cuda().eval(), st
+
+
+@pytest.mark.parametrize("name", ["img_l32_32.npz", "img_l256_64.npz"])
+def test_image_matches_reference_golden(vad, golden, name):
+    g = golden(name)
+    m, _ = _img_model(vad, int(g["latent_dim"]), int(g["wseed"]))
+    x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), 3, int(g["hw"]), int(g["hw"]))).cuda()
+    before = vad.hip.calls["img_score"]
+    with torch.no_grad():
+        recon = m(x)
+        emap = m.get_reconstruction_error(x, per_pixel=True)
+        scores = m.get_reconstruction_error(x)
+        lat = m.get_latent(x)
+        allo = m.score_all(x)
+    assert vad.hip.calls["img_score"] == before + 5          # the native path really ran
+    assert recon.shape == x.shape and emap.shape == (x.shape[0], 1, *x.shape[2:]) and scores.shape == (x.shape[0],)
+    assert rel_err(scores.cpu().numpy(), g["scores"]) < SCORE_RTOL
+    assert max_abs(recon.cpu().numpy(), g["recon"]) < ACT_ATOL
+    assert max_abs(emap.cpu().numpy(), g["errmap"]) < ACT_ATOL
+    assert max_abs(lat.cpu().numpy(), g["latent"]) < 2e-4
+    # one pass == three passes, bit for bit
+    assert torch.equal(allo["scores"], scores) and torch.equal(allo["errmap"], emap) and torch.equal(allo["recon"], recon)
+
+
+def test_image_256_frame_matches_reference_golden(vad, golden):
+    g = golden("img_l256_256.npz")
+    m, _ = _img_model(vad, 256, int(g["wseed"]))
+    x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, 1, 3, 256, 256)).cuda()
+    with torch.no_grad():
+        out = m.score_all(x)
+    assert rel_err(out["scores"].cpu().numpy(), g["scores"]) < SCORE_RTOL
+    assert max_abs(out["recon"].cpu().numpy()[:, :, ::8, ::8], g["recon_sub"]) < ACT_ATOL
+    assert max_abs(out["errmap"].cpu().numpy()[:, :, ::8, ::8], g["errmap_sub"]) < ACT_ATOL
+
+
+def test_image_config0_scores_and_auroc(vad, golden):
+    """configs[0] on the GPU: the reference's 64 golden scores (batches of 16, evaluate.py:240) and AUROC."""
+    g = golden("auroc_cfg0.npz")
+    seed = int(g["seed"])
+    m, _ = _img_model(vad, 256, int(g["wseed"]))
+    labels = vad.synth.frame_label(seed, np.arange(64))
+    batches = [{"image": vad.scoring.synth_frames_device(seed, s, 16, anomalies=True), "label": labels[s:s + 16],
+                "defect_type": ["defect" if l else "good" for l in labels[s:s + 16]]} for s in range(0, 64, 16)]
+    auroc, lab, scores, per_defect = vad.scoring.compute_auroc(m, batches, "cuda")
+    assert rel_err(scores, g["scores"]) < SCORE_RTOL
+    assert auroc == pytest.approx(float(g["auroc"]), abs=1e-12)
+    assert set(per_defect) == {"good", "defect"} and per_defect["good"]["count"] + per_defect["defect"]["count"] == 64
+
+
+def test_image_batch_and_chunk_independence(vad):
+    """A frame's score must not depend on batch size, position or chunking: bit-exact (this is what makes
+    multi-GPU sharding parity trivial)."""
+    m, _ = _img_model(vad, 64, 3)
+    x = vad.scoring.synth_frames_device(9, 0, 11, 64, 64)
+    with torch.no_grad():
+        full = m.get_reconstruction_error(x)
+        m.chunk = 4
+        chunked = m.get_reconstruction_error(x)
+        singles = torch.cat([m.get_reconstruction_error(x[i:i + 1]) for i in range(11)])
+        rev = m.get_reconstruction_error(x.flip(0)).flip(0)
+    assert torch.equal(full, chunked) and torch.equal(full, singles) and torch.equal(full, rev)
+
+
+def test_image_fresh_inputs_vs_oracle(vad):
+    m, st = _img_model(vad, 128, 41)
+    x = vad.synth.frames(555, 7, 3, 3, 96, 80)
+    ref = torch_oracle.img_scores({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, torch.from_numpy(x))
+    with torch.no_grad():
+        out = m.score_all(torch.from_numpy(x).cuda())
+    assert rel_err(out["scores"].cpu().numpy(), ref["scores"].numpy()) < SCORE_RTOL
+    assert max_abs(out["recon"].cpu().numpy(), ref["recon"].numpy()) < ACT_ATOL
+
+
+def test_weight_update_invalidates_packed_cache(vad):
+    m, _ = _img_model(vad, 32, 1)
+    x = vad.scoring.synth_frames_device(1, 0, 2, 32, 32)
+    with torch.no_grad():
+        a = m.get_reconstruction_error(x)
+        load_synthetic(vad, m, 2)          # in-place load_state_dict
+        b = m.get_reconstruction_error(x)
+        m.decoder.dec4[3].bias.add_(0.05)  # in-place parameter edit
+        c = m.get_reconstruction_error(x)
+    assert not torch.equal(a, b) and not torch.equal(b, c)
+
+
+def test_inference_requires_gpu_tensor_and_train_mode_uses_autograd(vad):
+    m, _ = _img_model(vad, 32, 1)
+    with torch.no_grad(), pytest.raises(vad.hip.VadError):
+        m.get_reconstruction_error(torch.zeros(1, 3, 32, 32))
+    with torch.no_grad(), pytest.raises(vad.hip.VadError):
+        m.get_reconstruction_error(torch.zeros(1, 3, 40, 32).cuda())
+    x = vad.scoring.synth_frames_device(1, 0, 2, 32, 32)
+    m.train()
+    loss = ((m(x) - x) ** 2).mean()
+    loss.backward()
+    assert m.encoder.enc1[0].weight.grad is not None
+
+
+@pytest.mark.parametrize("name", ["vid_default_64.npz", "vid_proj_32.npz", "vid_l3_32.npz"])
+def test_video_matches_reference_golden(vad, golden, name):
+    g = golden(name)
+    m, _ = _vid_model(vad, int(g["latent_dim"]), int(g["hid"]), int(g["layers"]), int(g["wseed"]))
+    x = torch.from_numpy(vad.synth.clips(int(g["xseed"]), 0, int(g["b"]), int(g["t"]), 3, int(g["hw"]), int(g["hw"]))).cuda()
+    before = vad.hip.calls["vid_score"]
+    with torch.no_grad():
+        recon = m(x)
+        seq = m.get_reconstruction_error(x)
+        frame = m.get_reconstruction_error(x, per_frame=True)
+        emap = m.get_reconstruction_error(x, per_pixel=True)
+        both = m.get_reconstruction_error(x, per_frame=True, per_pixel=True)
+        allo = m.score_all(x)
+    assert vad.hip.calls["vid_score"] == before + 6
+    assert rel_err(seq.cpu().numpy(), g["seq"]) < SCORE_RTOL
+    assert rel_err(frame.cpu().numpy(), g["frame"]) < SCORE_RTOL
+    assert max_abs(recon.cpu().numpy(), g["recon"]) < ACT_ATOL
+    assert max_abs(emap.cpu().numpy(), g["errmap"]) < ACT_ATOL
+    assert torch.equal(both, emap)                                  # per_pixel wins (reference :373)
+    assert torch.equal(allo["seq"], seq) and torch.equal(allo["frame"], frame) and torch.equal(allo["recon"], recon)
+
+
+def test_video_causal_and_clip_independent(vad):
+    """Reference properties: perturbing frames >= k leaves frame scores < k bit-identical;
+    a clip's scores do not depend on the rest of the batch."""
+    m, _ = _vid_model(vad, 64, 64, 2, 5)
+    x = torch.from_numpy(vad.synth.clips(77, 0, 5, 6, 3, 32, 32)).cuda()
+    with torch.no_grad():
+        base = m.get_reconstruction_error(x, per_frame=True)
+        y = x.clone()
+        y[:, 4:] = -y[:, 4:]
+        pert = m.get_reconstruction_error(y, per_frame=True)
+        solo = m.get_reconstruction_error(x[2:3], per_frame=True)
+        m.chunk = 2
+        chunked = m.get_reconstruction_error(x, per_frame=True)
+    assert torch.equal(base[:, :4], pert[:, :4]) and not torch.equal(base[:, 4:], pert[:, 4:])
+    assert torch.equal(base[2:3], solo) and torch.equal(base, chunked)
+
+
+def test_video_fresh_inputs_vs_oracle(vad):
+    m, st = _vid_model(vad, 128, 128, 2, 43)
+    x = vad.synth.clips(321, 3, 2, 5, 3, 48, 64)
+    ref = torch_oracle.vid_scores({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, torch.from_numpy(x), 128, 2)
+    with torch.no_grad():
+        out = m.score_all(torch.from_numpy(x).cuda())
+    assert rel_err(out["seq"].cpu().numpy(), ref["seq"].numpy()) < SCORE_RTOL
+    assert rel_err(out["frame"].cpu().numpy(), ref["frame"].numpy()) < SCORE_RTOL
+    assert max_abs(out["recon"].cpu().numpy(), ref["recon"].numpy()) < ACT_ATOL
+
+
+def test_full_size_properties(vad):
+    """BASELINE configs[1]/[2] frame size (256x256), moderate batch: size-independent checks — score equals the
+    mean of the error map, clip score equals the mean of frame scores, and a strided subset matches the oracle."""
+    m, st = _img_model(vad, 256, 7)
+    x = vad.scoring.synth_frames_device(0xC0FFEE + 1, 0, 48)
+    with torch.no_grad():
+        out = m.score_all(x)
+    s = out["scores"].cpu().numpy()
+    assert rel_err(out["errmap"].mean(dim=(1, 2, 3)).cpu().numpy(), s) < 2e-6
+    assert rel_err(((x - out["recon"]) ** 2).mean(dim=(1, 2, 3)).cpu().numpy(), s) < 2e-6
+    idx = [0, 17, 47]
+    ref = torch_oracle.img_scores({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, x[idx].cpu())
+    assert rel_err(s[idx], ref["scores"].numpy()) < SCORE_RTOL
+    v, _ = _vid_model(vad, 128, 128, 2, 8)
+    xc = vad.scoring.synth_frames_device(0xC0FFEE + 2, 0, 40).view(4, 10, 3, 256, 256)
+    with torch.no_grad():
+        vo = v.score_all(xc)
+    assert rel_err(vo["frame"].mean(dim=1).cpu().numpy(), vo["seq"].cpu().numpy()) < 2e-6
+    assert rel_err(vo["errmap"].mean(dim=(2, 3, 4)).cpu().numpy(), vo["frame"].cpu().numpy()) < 2e-6
