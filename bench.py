@@ -1,0 +1,270 @@
+"""bench.py — frames/s through the anomaly-scoring hot path on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of get_reconstruction_error over one batch already resident in HBM:
+  image (default; BASELINE.json configs[1]): 512 synthetic 256x256x3 frames per GPU;
+  video (--workload video; configs[2]): 64 clips of 10 frames per GPU.
+With N > 1 the frame stream is block-partitioned over ranks (weak scaling, no data-path collective) and each
+step ends with the one all_gather of the score vector (RCCL).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+PEAK_HBM_GBS = 8000.0
+
+# Algorithmic work per 256x256 frame (scaled by H*W/65536 otherwise)
+IMG_FLOP_PER_FRAME = 8_111_783_936
+IMG_BYTES_PER_FRAME = 72_351_748
+VID_FLOP_PER_FRAME = 3_011_510_272      # at T = 10
+VID_BYTES_PER_FRAME = 17_825_796
+
+
+def conv3x3_flops(h, w, cin, cout):
+    return 2.0 * h * w * cin * cout * 9
+
+
+def image_mfma_layer_flops(h, w, latent):
+    """slot -> algorithmic FLOP per frame of the conv3x3 MFMA launches (vad_api.hip slot numbering)."""
+    ch = [3, 32, 64, 128, latent]
+    f = {}
+    hh, ww = h, w
+    f[1] = conv3x3_flops(hh, ww, 32, 32)
+    for blk in range(1, 4):
+        hh, ww = hh // 2, ww // 2
+        f[2 * blk] = conv3x3_flops(hh, ww, ch[blk], ch[blk + 1])
+        f[2 * blk + 1] = conv3x3_flops(hh, ww, ch[blk + 1], ch[blk + 1])
+    hh, ww = hh // 2, ww // 2
+    dch = [latent, 128, 64, 32]
+    for blk in range(3):
+        hh, ww = hh * 2, ww * 2
+        f[9 + 2 * blk] = conv3x3_flops(hh, ww, dch[blk + 1], dch[blk + 1])
+    return f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["image", "video"], default="image")
+    ap.add_argument("--batch", type=int, default=0, help="frames (image) or clips (video) per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="frames/clips per launch group (0 = model default)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--clip-len", type=int, default=10)
+    ap.add_argument("--no-layer-events", action="store_true", help="do not bracket layers with hipEvents")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the scoring path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    vad = importlib.import_module("video-anomaly-detection_amd")
+    hip = vad.hip
+    lib = hip.lib()
+    hw = args.size
+    scale = (hw * hw) / 65536.0
+
+    def synth_load(module, seed):
+        shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+        st = {k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, seed).items()}
+        module.load_state_dict(st, strict=True)
+        return st
+
+    seed = 0xC0FFEE + (1 if args.workload == "image" else 2)
+    if args.workload == "image":
+        per_gpu = args.batch or 512
+        model = vad.ConvAutoencoder(in_channels=3, latent_dim=256)
+        state = synth_load(model, 7)
+        model = model.to(dev).eval()
+        if args.chunk:
+            model.chunk = args.chunk
+        x = vad.scoring.synth_frames_device(seed, rank * per_gpu, per_gpu, hw, hw, device=dev)
+        frames_per_step = per_gpu
+        flop_per_frame, bytes_per_frame = IMG_FLOP_PER_FRAME * scale, IMG_BYTES_PER_FRAME * scale
+
+        def score_block(first, count):
+            return model.get_reconstruction_error(x)
+        width = 1
+        workload = f"configs[1]: image autoencoder scoring, batch {per_gpu} synthetic {hw}x{hw}x3 frames per GPU"
+    else:
+        per_gpu = args.batch or 64
+        t = args.clip_len
+        model = vad.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)
+        state = synth_load(model, 8)
+        model = model.to(dev).eval()
+        if args.chunk:
+            model.chunk = args.chunk
+        x = vad.scoring.synth_frames_device(seed, rank * per_gpu * t, per_gpu * t, hw, hw, device=dev).view(per_gpu, t, 3, hw, hw)
+        frames_per_step = per_gpu * t
+        flop_per_frame, bytes_per_frame = VID_FLOP_PER_FRAME * scale, VID_BYTES_PER_FRAME * scale
+
+        def score_block(first, count):
+            return model.get_reconstruction_error(x, per_frame=True)
+        width = t
+        workload = f"configs[2]: ConvLSTM video autoencoder scoring, {per_gpu} clips x {t} frames of {hw}x{hw}x3 per GPU"
+
+    n_items = per_gpu * world
+
+    def step():
+        with torch.no_grad():
+            return vad.scoring.sharded_scores(score_block, n_items, width=width, rank=rank, world=world, device=dev)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        scores = step()
+    events = not args.no_layer_events
+    fence()
+    if events:
+        lib.vad_prof_reset()
+        lib.vad_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scores = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.vad_prof_enable(0)
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_frames = frames_per_step * world * args.steps
+    fps = total_frames / elapsed
+
+    layers, roofline = None, None
+    if events:
+        import ctypes as C
+        ms = (C.c_float * hip.PROF_SLOTS)()
+        cnt = (C.c_int * hip.PROF_SLOTS)()
+        hip.check(lib.vad_prof_read(ms, cnt), "vad_prof_read")
+        model_id = 0 if args.workload == "image" else 1
+        layers = {lib.vad_prof_slot_name(model_id, i).decode(): {"ms": round(ms[i], 4), "launches": cnt[i]}
+                  for i in range(hip.PROF_SLOTS) if cnt[i]}
+        frames_rank = frames_per_step * args.steps
+        if args.workload == "image":
+            lf = image_mfma_layer_flops(hw, hw, 256)
+            mf_ms = sum(ms[i] for i in lf)
+            mf_launch = sum(cnt[i] for i in lf)
+            mf_flop = sum(lf.values()) * frames_rank
+            for i, fl in lf.items():
+                nm = lib.vad_prof_slot_name(0, i).decode()
+                layers[nm]["tflops"] = round(fl * frames_rank / (ms[i] * 1e-3) / 1e12, 2) if ms[i] > 0 else None
+        else:
+            # dominant kernel of the video path: the same conv3x3 MFMA kernel in its ConvLSTM form
+            h16 = hw // 16
+            step_flop = conv3x3_flops(h16, h16, 256, 512)          # per clip per (layer, t) launch
+            enc = [conv3x3_flops(hw // 2, hw // 2, 32, 64), conv3x3_flops(hw // 4, hw // 4, 64, 128),
+                   conv3x3_flops(hw // 8, hw // 8, 128, 128)]
+            mf_ms = ms[4] + ms[1] + ms[2] + ms[3]
+            mf_launch = cnt[4] + cnt[1] + cnt[2] + cnt[3]
+            mf_flop = step_flop * 2 * frames_rank + sum(enc) * frames_rank
+            layers["convlstm"]["tflops"] = round(step_flop * 2 * frames_rank / (ms[4] * 1e-3) / 1e12, 2) if ms[4] > 0 else None
+        ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fp32 32x32x2 MFMA; all launches)",
+                    "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(mf_ms / max(mf_launch, 1), 4), "launches": mf_launch,
+                    "whole_path_tflops": round(fps / world * flop_per_frame / 1e12, 2),
+                    "whole_path_hbm_gbs": round(fps / world * bytes_per_frame / 1e9, 1),
+                    "whole_path_hbm_frac": round(fps / world * bytes_per_frame / 1e9 / PEAK_HBM_GBS, 4)}
+
+    out = {
+        "metric": "frames/sec/GPU (256x256 autoencoder scoring) + AUROC parity vs reference",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "frames_per_gpu_per_step": frames_per_step, "chunk": int(model.chunk),
+                   "weights": "deterministic synthetic state dict (Xavier scale, randomised BN)",
+                   "collective": "one all_gather of the score vector per step" if world > 1 else "none (1 GPU)"},
+        "frames_per_sec_per_gpu": round(fps / world, 1),
+        "roofline": roofline,
+    }
+    if layers is not None:
+        out["layers"] = layers
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(vad, state, args, scores, seed, hw)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def host_cores() -> int:
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (a 1-GPU box exposes
+    256 logical CPUs but grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(vad, state, args, gpu_scores, seed, hw):
+    """The CPU restatement (oracle/torch_oracle.py — the reference itself cannot travel) on the host cores, on a
+    bounded sample of the same workload, plus the GPU-vs-CPU score parity on that sample."""
+    from oracle import torch_oracle
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        if args.workload == "image":
+            n, bs = 64, 16                                   # configs[0]: 64 frames, batches of 16 (evaluate.py:240)
+            xs = torch.from_numpy(vad.synth.frames(seed, 0, n, 3, hw, hw))
+            torch_oracle.img_scores(state, xs[:bs])          # warm-up
+            t0 = time.perf_counter()
+            ref = torch.cat([torch_oracle.img_scores(state, xs[i:i + bs])["scores"] for i in range(0, n, bs)])
+            dt = time.perf_counter() - t0
+            got = gpu_scores[:n].cpu()
+            frames, sample = n, f"{n} of the step's frames, batches of {bs}, 1 warm-up batch + 1 timed pass"
+        else:
+            nclips, t = 4, args.clip_len
+            xs = torch.from_numpy(vad.synth.clips(seed, 0, nclips, t, 3, hw, hw))
+            torch_oracle.vid_scores(state, xs[:1], 128, 2)
+            t0 = time.perf_counter()
+            ref = torch_oracle.vid_scores(state, xs, 128, 2)["frame"]
+            dt = time.perf_counter() - t0
+            got = gpu_scores[:nclips].cpu()
+            frames, sample = nclips * t, f"{nclips} clips x {t} frames in one batch, 1 warm-up clip + 1 timed pass"
+    rel = float(((got - ref).abs() / ref.abs()).max())
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
+            "gpu_vs_cpu_max_rel_score_err": rel}
+
+
+if __name__ == "__main__":
+    main()

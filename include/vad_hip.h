@@ -93,7 +93,7 @@ int vad_convlstm_step(const float* x, long long x_fs, const float* h_prev, long 
  * recon_nchw (NCHW [N,3,H2,W2]) and errmap ([N,H2,W2], channel mean) may be NULL.
  * Replaces models/autoencoder.py:211-221 and models/video_autoencoder.py:368-384. */
 int vad_score_partials(int kind /*0: conv3x3 tail, 1: convT tail*/, int h2, int w2);
-/* Conv2d(cin->3) weight OIHW (3,cin,3,3) -> [9][cin][4] (4th lane zero) for wave-uniform loads. */
+/* Conv2d(cin->3) weight OIHW (3,cin,3,3) -> [cin/4][9 taps][4 channels][3 outputs] (per-lane weight rows). */
 size_t vad_pack_conv3x3_to3_floats(int cin);
 int vad_pack_conv3x3_to3(const float* w_oihw, int cin, float* w_packed);
 /* Conv2d(32->3) k3 p1 + Tanh (models/autoencoder.py:134-135) on NHWC [N,H2,W2,32]. */

@@ -1,0 +1,109 @@
+"""Time one layer kernel of libvad_hip.so in isolation (developer tool; not part of the product path).
+
+    python tools/layer_bench.py conv3x3 --n 32 --h 256 --w 256 --cin 32 --cout 32 --pool 1
+"""
+import argparse
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+hip = importlib.import_module("video-anomaly-detection_amd.hip")
+
+IMAGE_LAYERS = [  # name, kind, h, cin, cout, pool
+    ("enc1.0", "c3", 256, 3, 32, 0), ("enc1.3", "conv3x3", 256, 32, 32, 1), ("enc2.0", "conv3x3", 128, 32, 64, 0),
+    ("enc2.3", "conv3x3", 128, 64, 64, 1), ("enc3.0", "conv3x3", 64, 64, 128, 0), ("enc3.3", "conv3x3", 64, 128, 128, 1),
+    ("enc4.0", "conv3x3", 32, 128, 256, 0), ("enc4.3", "conv3x3", 32, 256, 256, 1), ("dec1.0", "convt", 16, 256, 128, 0),
+    ("dec1.3", "conv3x3", 32, 128, 128, 0), ("dec2.0", "convt", 32, 128, 64, 0), ("dec2.3", "conv3x3", 64, 64, 64, 0),
+    ("dec3.0", "convt", 64, 64, 32, 0), ("dec3.3", "conv3x3", 128, 32, 32, 0), ("dec4.0", "convt", 128, 32, 32, 0),
+    ("dec4.3", "tail", 256, 32, 3, 0),
+]
+
+
+def run(kind, n, h, w, cin, cout, pool, iters, warm=3):
+    l = hip.lib()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    s = hip.current_stream()
+    rnd = lambda *shape: torch.randn(*shape, device="cuda", generator=g)
+    if kind == "c3":
+        x = rnd(n, 3, h, w); wt = rnd(28 * cout) * 0.2; b = rnd(cout)
+        out = torch.empty(n, h // (2 if pool else 1), w // (2 if pool else 1), cout, device="cuda")
+        fn = lambda: l.vad_conv3x3_c3(x.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), n, h, w, cout, 1, pool, s)
+        flop = 2.0 * n * h * w * 27 * cout
+        byts = 4.0 * (x.numel() + out.numel())
+    elif kind == "conv3x3":
+        x = rnd(n, h, w, cin); wt = rnd(9 * cin * cout) * 0.05; b = rnd(cout)
+        out = torch.empty(n, h // (2 if pool else 1), w // (2 if pool else 1), cout, device="cuda")
+        fn = lambda: l.vad_conv3x3(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 1, pool, s)
+        flop = 2.0 * n * h * w * 9 * cin * cout
+        byts = 4.0 * (x.numel() + out.numel())
+    elif kind == "convt":
+        x = rnd(n, h, w, cin); wt = rnd(4 * cin * cout) * 0.05; b = rnd(cout)
+        out = torch.empty(n, 2 * h, 2 * w, cout, device="cuda")
+        fn = lambda: l.vad_convt2x2(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 2, s)
+        flop = 2.0 * n * h * w * 4 * cin * cout
+        byts = 4.0 * (x.numel() + out.numel())
+    elif kind == "lstm":
+        hid = cout
+        x = rnd(n, h, w, cin); hp = rnd(n, h, w, hid) * 0.3; cp = rnd(n, h, w, hid)
+        wt = rnd(9 * (cin + hid) * 4 * hid) * 0.02; b = rnd(4 * hid)
+        ho = torch.empty(n, h, w, hid, device="cuda"); co = torch.empty(n, h, w, hid, device="cuda")
+        fn = lambda: l.vad_convlstm_step(x.data_ptr(), 0, hp.data_ptr(), 0, cp.data_ptr(), wt.data_ptr(), b.data_ptr(),
+                                         ho.data_ptr(), 0, co.data_ptr(), n, h, w, cin, hid, s)
+        flop = 2.0 * n * h * w * 9 * (cin + hid) * 4 * hid
+        byts = 4.0 * (x.numel() + 4 * ho.numel())
+    elif kind == "tail":
+        x = rnd(n, h, w, 32); wt = rnd(8 * 108) * 0.05; b = rnd(4); img = rnd(n, 3, h, w)
+        nparts = l.vad_score_partials(0, h, w)
+        parts = torch.empty(n * nparts, device="cuda")
+        fn = lambda: l.vad_conv3x3_to3_score(x.data_ptr(), wt.data_ptr(), b.data_ptr(), img.data_ptr(), parts.data_ptr(),
+                                             None, None, n, h, w, 32, s)
+        flop = 2.0 * n * h * w * 9 * 32 * 3
+        byts = 4.0 * (x.numel() + img.numel())
+    elif kind == "tailt":
+        x = rnd(n, h, w, 32); wt = rnd(32 * 12) * 0.05; b = rnd(4); img = rnd(n, 3, 2 * h, 2 * w)
+        nparts = l.vad_score_partials(1, 2 * h, 2 * w)
+        parts = torch.empty(n * nparts, device="cuda")
+        fn = lambda: l.vad_convt2x2_to3_score(x.data_ptr(), wt.data_ptr(), b.data_ptr(), img.data_ptr(), parts.data_ptr(),
+                                              None, None, n, h, w, 32, s)
+        flop = 2.0 * n * h * w * 4 * 32 * 3
+        byts = 4.0 * (x.numel() + img.numel())
+    else:
+        raise SystemExit(f"unknown kind {kind}")
+    for _ in range(warm):
+        hip.check(fn())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, flop / ms / 1e9, byts / ms / 1e6
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kind")
+    ap.add_argument("--n", type=int, default=32)
+    ap.add_argument("--h", type=int, default=256)
+    ap.add_argument("--w", type=int, default=0)
+    ap.add_argument("--cin", type=int, default=32)
+    ap.add_argument("--cout", type=int, default=32)
+    ap.add_argument("--pool", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    if a.kind == "image":
+        tot = 0.0
+        for name, kind, h, cin, cout, pool in IMAGE_LAYERS:
+            ms, tf, gbs = run(kind, a.n, h, h, cin, cout, pool, a.iters)
+            tot += ms
+            print(f"{name:8s} {kind:8s} {ms * 1e3 / a.n:8.2f} us/frame  {tf:7.2f} TFLOP/s  {gbs:8.1f} GB/s")
+        print(f"total {tot * 1e3 / a.n:.2f} us/frame -> {a.n / tot * 1e3:.0f} frames/s")
+    else:
+        ms, tf, gbs = run(a.kind, a.n, a.h, a.w or a.h, a.cin, a.cout, a.pool, a.iters)
+        print(f"{a.kind} n={a.n} {a.h}x{a.w or a.h} {a.cin}->{a.cout} pool={a.pool}: {ms:.4f} ms  {tf:.2f} TFLOP/s  {gbs:.1f} GB/s")

@@ -85,6 +85,25 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
     const size_t wstep = (size_t)p.cout * 8;           // floats per (tap, k8) slab
     const size_t wtap = (size_t)(p.cin / 8) * wstep;   // floats per tap
 
+    // Software pipeline: fragments for step s+1 are loaded (A: ds_read_b128, B: global_load_dwordx4
+    // from L2) before the MFMAs of step s issue; B also runs ahead across the chunk barrier.
+    constexpr int NS = 9 * (CK / 8);                   // (tap, k8) steps per channel chunk
+    static_assert(NS % 2 == 0, "double-buffer parity must be the same in every chunk");
+    f32x4 a[2][MT], b[2][NT];
+#define LOAD_B(buf, chunk, step)                                                                  \
+    {                                                                                             \
+        const size_t woff_ = (size_t)((step) / (CK / 8)) * wtap +                                 \
+                             (size_t)((chunk) * (CK / 8) + (step) % (CK / 8)) * wstep;            \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = *(const f32x4*)(wp[nt] + woff_); \
+    }
+#define LOAD_A(buf, step)                                                                         \
+    {                                                                                             \
+        const int toff_ = ((((step) / (CK / 8)) / 3) * LW + (((step) / (CK / 8)) % 3)) * PS +     \
+                          ((step) % (CK / 8)) * 8;                                                \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *(const f32x4*)&tile[abase[mt] + toff_]; \
+    }
+    LOAD_B(0, 0, 0);
+
     for (int ch = 0; ch < nch; ++ch) {
         const float* src;
         int pstride, coff;
@@ -103,28 +122,29 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
         }
         __syncthreads();
 
-        const size_t kbase = (size_t)(ch * (CK / 8)) * wstep;
+        LOAD_A(0, 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * LW + (tap % 3)) * PS;
-#pragma unroll
-            for (int k8 = 0; k8 < CK / 8; ++k8) {
-                f32x4 a[MT], b[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)&tile[abase[mt] + toff + k8 * 8];
-                const size_t woff = (size_t)tap * wtap + kbase + (size_t)k8 * wstep;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(wp[nt] + woff);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = MFMA32(a[mt][j], b[nt][j], acc[mt][nt]);
+        for (int s = 0; s < NS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < NS) {
+                LOAD_A(nxt, s + 1);
+                LOAD_B(nxt, ch, s + 1);
+            } else if (ch + 1 < nch) {
+                LOAD_B(nxt, ch + 1, 0);
             }
+            // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks each load to its first use)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = MFMA32(a[cur][mt][j], b[cur][nt][j], acc[mt][nt]);
         }
     }
+#undef LOAD_A
+#undef LOAD_B
 
     // ---------------------------------------------------------------- epilogue
     if (MODE == MODE_LSTM) {

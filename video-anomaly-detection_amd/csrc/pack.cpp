@@ -98,16 +98,15 @@ extern "C" int vad_pack_conv1x1(const float* w, const float* bias, int cout, int
     return VAD_OK;
 }
 
-extern "C" size_t vad_pack_conv3x3_to3_floats(int cin) { return (size_t)9 * cin * 4; }
+extern "C" size_t vad_pack_conv3x3_to3_floats(int cin) { return (size_t)(cin / 4) * 108; }
 
+// [cin/4][9 taps][4 channels][3 outputs]: lane cg of the tail kernel reads its 108 weights contiguously
 extern "C" int vad_pack_conv3x3_to3(const float* w, int cin, float* out) {
-    REQ(w && out && cin > 0, "pack_conv3x3_to3: bad arguments");
-    for (int tap = 0; tap < 9; ++tap)
-        for (int ci = 0; ci < cin; ++ci) {
-            float* o = out + ((size_t)tap * cin + ci) * 4;
-            for (int co = 0; co < 3; ++co) o[co] = w[((size_t)co * cin + ci) * 9 + tap];
-            o[3] = 0.f;
-        }
+    REQ(w && out && cin > 0 && cin % 4 == 0, "pack_conv3x3_to3: bad arguments");
+    for (int ci = 0; ci < cin; ++ci)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int co = 0; co < 3; ++co)
+                out[(size_t)(ci / 4) * 108 + tap * 12 + (ci & 3) * 3 + co] = w[((size_t)co * cin + ci) * 9 + tap];
     return VAD_OK;
 }
 

@@ -34,62 +34,149 @@ __device__ __forceinline__ void block_partial(float e, float* red, float* dst) {
     if (threadIdx.x == 0) *dst = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-template <int CIN>
-__global__ __launch_bounds__(256) void conv3x3_to3_score_kernel(TailP p) {
-    constexpr int TH = 8, TW = 32, LH = TH + 2, LW = TW + 2, PS = CIN + 4;
-    __shared__ __attribute__((aligned(16))) float tile[LH * LW * PS];
+// Conv2d(32->3)+Tanh+error, VALU.  A wave is 8 row-groups x 8 channel-groups: lane (g = lane>>3,
+// cg = lane&7) owns output row y0 + 8*wave + g and input channels 4cg..4cg+3, keeps its 108 weights
+// (9 taps x 4 channels x 3 outputs) in registers for the whole tile and slides a 3x3 window along x,
+// loading ONE new column (3 x 16 B; the 8 lanes of a group read one full 128-B pixel row) per step,
+// two columns ahead of its use.  Every 8 steps the 8x3 partial sums are transpose-reduced across
+// the 8 channel-group lanes (7 adds, 21 shuffles for 24 values), which leaves lane cg holding the 3
+// finished outputs of pixel x0 + cg: Tanh, error and the optional stores then run on all 64 lanes
+// with 32-B contiguous accesses per row.
+constexpr int TAIL_T = 32;   // tile side (output pixels) of the conv3x3 tail
+
+__global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
     __shared__ float red[4];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 3, cg = lane & 7;
     unsigned L = blockIdx.x;
     const int tx = L % p.tiles_x; L /= p.tiles_x;
     const int ty = L % p.tiles_y;
     const int n = L / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const float* src = p.in + (size_t)n * p.h * p.w_ * CIN;
-    for (int idx = tid; idx < LH * LW * (CIN / 4); idx += 256) {
-        const int c4 = idx % (CIN / 4), pix = idx / (CIN / 4);
-        const int ly = pix / LW, lx = pix - ly * LW;
-        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
-            v = *(const f32x4*)(src + ((size_t)gy * p.w_ + gx) * CIN + c4 * 4);
-        *(f32x4*)&tile[pix * PS + c4 * 4] = v;
-    }
-    __syncthreads();
+    const int y = ty * TAIL_T + wave * 8 + g, x0 = tx * TAIL_T;
+    const int H = p.h, W = p.w_;
 
-    const int ly = tid / TW, lx = tid % TW;
-    float a0 = p.bias[0], a1 = p.bias[1], a2 = p.bias[2];
-    const f32x4* wv = (const f32x4*)p.w;   // [9][CIN] of (w0, w1, w2, 0): wave-uniform -> scalar loads
+    float w[9][4][3];
+    {
+        const f32x4* wv = (const f32x4*)(p.w + cg * 108);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const float* row = &tile[((ly + tap / 3) * LW + lx + tap % 3) * PS];
+        for (int i = 0; i < 27; ++i) {
+            const f32x4 q = wv[i];
 #pragma unroll
-        for (int c4 = 0; c4 < CIN / 4; ++c4) {
-            const f32x4 a = *(const f32x4*)(row + c4 * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 wq = wv[tap * CIN + c4 * 4 + j];
-                a0 = fmaf(a[j], wq[0], a0);
-                a1 = fmaf(a[j], wq[1], a1);
-                a2 = fmaf(a[j], wq[2], a2);
+            for (int e = 0; e < 4; ++e) {
+                const int f = i * 4 + e;
+                w[f / 12][(f / 3) % 4][f % 3] = q[e];
             }
         }
     }
-    const float r[3] = {tanhf(a0), tanhf(a1), tanhf(a2)};
-    const int y = y0 + ly, x = x0 + lx;
-    float e = 0.f;
-    if (y < p.h && x < p.w_) {
-        const size_t plane = (size_t)p.h * p.w_;
-        const size_t o = (size_t)n * 3 * plane + (size_t)y * p.w_ + x;
+    const float b0 = p.bias[0], b1 = p.bias[1], b2 = p.bias[2];
+
+    // Zero padding in y is folded into the per-lane weights (taps of an outside row are zeroed and the
+    // row address is clamped), so loads need no per-lane predicate; padding in x is wave-uniform.
+    if (y == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float d = p.x[o + c * plane] - r[c];
-            e += d * d;
-            if (p.recon) p.recon[o + c * plane] = r[c];
-        }
-        if (p.errmap) p.errmap[(size_t)n * plane + (size_t)y * p.w_ + x] = e / 3.0f;
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[t][j][0] = w[t][j][1] = w[t][j][2] = 0.f;
     }
-    block_partial(e, red, &p.partials[(size_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx]);
+    if (y >= H - 1) {
+#pragma unroll
+        for (int t = 6; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[t][j][0] = w[t][j][1] = w[t][j][2] = 0.f;
+    }
+    const char* base = (const char*)(p.in + (size_t)n * H * W * 32);   // wave-uniform
+    int voff[3];                                                       // per-lane byte offset of column x0+15
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int yy = y - 1 + r;
+        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+        voff[r] = ((yy * W + x0 + 15) * 32 + cg * 4) * 4;
+    }
+    constexpr int D = 2;                       // prefetch distance in columns
+    f32x4 col[TAIL_T + 2][3];                  // col[k] = input column x0 - 1 + k (registers; static indices)
+    // Columns 1..16 of a tile are always inside the image (W % 16 == 0): immediate offsets, no checks.
+    // Column 0 (x0-1) and columns >= 17 may fall outside: the address is clamped (wave-uniform) and the
+    // two columns that can carry zero padding into a kept output (x = -1 and x = W) are multiplied by 0.
+#define LOAD_COL(k)                                                                          \
+    {                                                                                        \
+        if ((k) >= 1 && (k) <= 16) {                                                         \
+            _Pragma("unroll") for (int r = 0; r < 3; ++r)                                    \
+                col[k][r] = *(const f32x4*)(base + voff[r] + ((k) - 16) * 128);              \
+        } else {                                                                             \
+            const int xx_ = x0 - 1 + (k);                                                    \
+            const int xc_ = xx_ < 0 ? 0 : (xx_ > W - 1 ? W - 1 : xx_);                       \
+            const float mk_ = (xx_ == xc_) ? 1.f : 0.f;                                      \
+            _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                  \
+                f32x4 v_ = *(const f32x4*)(base + voff[r] + (xc_ - x0 - 15) * 128);          \
+                if ((k) == 0 || (k) == 17 || (k) == 33) v_ *= mk_;                           \
+                col[k][r] = v_;                                                              \
+            }                                                                                \
+        }                                                                                    \
+    }
+#pragma unroll
+    for (int k = 0; k < 2 + D; ++k) LOAD_COL(k);
+
+    const size_t plane = (size_t)H * W;
+    float esum = 0.f;
+    float v[8][3];
+#pragma unroll
+    for (int s = 0; s < TAIL_T; ++s) {
+        if (s + 2 + D < TAIL_T + 2) LOAD_COL(s + 2 + D);
+        __builtin_amdgcn_sched_barrier(0);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float in = col[s + dx][dy][j];
+                    a0 = fmaf(in, w[dy * 3 + dx][j][0], a0);
+                    a1 = fmaf(in, w[dy * 3 + dx][j][1], a1);
+                    a2 = fmaf(in, w[dy * 3 + dx][j][2], a2);
+                }
+        v[s & 7][0] = a0; v[s & 7][1] = a1; v[s & 7][2] = a2;
+        if ((s & 7) == 7) {
+            // transpose-reduce over the 8 channel-group lanes: lane cg ends with pixel x0 + (s-7) + cg
+            float r4[4][3], r2[2][3], r1[3];
+            const bool h4 = cg & 4, h2 = cg & 2, h1 = cg & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float keep = h4 ? v[q + 4][c] : v[q][c], send = h4 ? v[q][c] : v[q + 4][c];
+                    r4[q][c] = keep + __shfl_xor(send, 4);
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float keep = h2 ? r4[q + 2][c] : r4[q][c], send = h2 ? r4[q][c] : r4[q + 2][c];
+                    r2[q][c] = keep + __shfl_xor(send, 2);
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float keep = h1 ? r2[1][c] : r2[0][c], send = h1 ? r2[0][c] : r2[1][c];
+                r1[c] = keep + __shfl_xor(send, 1);
+            }
+            const int x = x0 + (s - 7) + cg;
+            if (y < H && x < W) {
+                const float rc[3] = {tanhf(r1[0] + b0), tanhf(r1[1] + b1), tanhf(r1[2] + b2)};
+                const size_t o = (size_t)n * 3 * plane + (size_t)y * W + x;
+                float e = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float d = p.x[o + c * plane] - rc[c];
+                    e += d * d;
+                    if (p.recon) p.recon[o + c * plane] = rc[c];
+                }
+                if (p.errmap) p.errmap[(size_t)n * plane + (size_t)y * W + x] = e / 3.0f;
+                esum += e;
+            }
+        }
+    }
+#undef LOAD_COL
+    block_partial(esum, red, &p.partials[(size_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx]);
 }
 
 template <int CIN>
@@ -172,7 +259,7 @@ __global__ __launch_bounds__(64) void score_finalize_kernel(const float* partial
 }
 
 extern "C" int vad_score_partials(int kind, int h2, int w2) {
-    if (kind == 0) return ((h2 + 7) / 8) * ((w2 + 31) / 32);
+    if (kind == 0) return ((h2 + TAIL_T - 1) / TAIL_T) * ((w2 + TAIL_T - 1) / TAIL_T);
     if (kind == 1) return ((h2 / 2 + 7) / 8) * ((w2 / 2 + 31) / 32);
     return vad_fail(VAD_ERR_ARG, "score_partials: kind must be 0 (conv3x3 tail) or 1 (convT tail)");
 }
@@ -182,11 +269,11 @@ extern "C" int vad_conv3x3_to3_score(const float* in, const float* w_packed, con
                                      int n, int h2, int w2, int cin, void* stream) {
     VAD_REQUIRE(in && w_packed && bias3 && x && partials, "conv3x3_to3_score: null pointer");
     VAD_REQUIRE(cin == 32, "conv3x3_to3_score: cin=%d unsupported (the reference's dec4.3 has 32)", cin);
-    VAD_REQUIRE(n > 0 && h2 > 0 && w2 > 0, "conv3x3_to3_score: bad shape");
-    TailP p{in, w_packed, bias3, x, partials, recon, errmap, h2, w2, (w2 + 31) / 32, (h2 + 7) / 8};
+    VAD_REQUIRE(n > 0 && h2 > 0 && w2 > 0 && w2 % 16 == 0, "conv3x3_to3_score: bad shape (W=%d must be a positive multiple of 16)", w2);
+    TailP p{in, w_packed, bias3, x, partials, recon, errmap, h2, w2, (w2 + TAIL_T - 1) / TAIL_T, (h2 + TAIL_T - 1) / TAIL_T};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_to3_score: grid too large");
-    hipLaunchKernelGGL((conv3x3_to3_score_kernel<32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv3x3_to3_score_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
