@@ -45,7 +45,7 @@ def image_mfma_layer_flops(h, w, latent):
     ch = [3, 32, 64, 128, latent]
     f = {}
     hh, ww = h, w
-    f[1] = conv3x3_flops(hh, ww, 32, 32)
+    f[1] = conv3x3_flops(hh, ww, 32, 32) + conv3x3_flops(hh, ww, 3, 32)   # fused enc1.0 + enc1.3 launch
     for blk in range(1, 4):
         hh, ww = hh // 2, ww // 2
         f[2 * blk] = conv3x3_flops(hh, ww, ch[blk], ch[blk + 1])

@@ -64,6 +64,12 @@ int vad_pack_conv1x1(const float* w_oihw, const float* bias, int cout, int cin,
 int vad_conv3x3_c3(const float* x_nchw, const float* w_packed, const float* bias, float* out_nhwc,
                    int n, int h, int w, int cout, int act, int pool, void* stream);
 
+/* Fused Encoder.enc1 (models/autoencoder.py:38-46): conv3x3(3->32)+BN+LeakyReLU, conv3x3(32->32)+BN+LeakyReLU,
+ * MaxPool2d(2,2) in ONE launch; the 32-channel full-resolution map stays in LDS.  w0/b0 from
+ * vad_pack_conv3x3_c3 (cout 32), w1/b1 from vad_pack_conv3x3 (32,32).  out NHWC [N,H/2,W/2,32]. */
+int vad_conv3x3_c3_fused(const float* x_nchw, const float* w0, const float* b0, const float* w1, const float* b1,
+                         float* out_nhwc, int n, int h, int w, void* stream);
+
 /* NHWC conv3x3 p1 + bias + act (+ MaxPool2d(2,2) when pool != 0).  Cin multiple of 8 (32 for
  * speed), Cout multiple of 32.  pool needs even H, W. */
 int vad_conv3x3(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
@@ -146,6 +152,10 @@ size_t vad_vid_workspace_bytes(int chunk_clips, int t, int h, int w, int latent,
 int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
                   const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips,
                   float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
+
+/* Developer switch for A/B timing in one process: 0 = one tile per work-group, 1 = persistent work-groups with
+ * register prefetch of the next stage (default).  Results are bit-identical. */
+int vad_debug_set_conv_variant(int variant);
 
 /* ------------------------------------------------------------------ per-layer timing
  * When enabled, the model-level calls bracket every layer launch with hipEvents on `stream`.

@@ -121,3 +121,17 @@ def convlstm_step(x, h, c, w, b):
                                   hout.data_ptr(), 0, cout.data_ptr(), n, hh, ww, cx, hid, stream()))
     torch.cuda.synchronize()
     return to_nchw(hout), to_nchw(cout)
+
+
+def conv3x3_c3_fused(x_nchw, w0, b0, bn0, w1, b1, bn1):
+    """Fused enc1 block: conv(3->32)+BN+leaky, conv(32->32)+BN+leaky, maxpool -> NCHW numpy."""
+    l = hip.lib()
+    n, _, h, wd = x_nchw.shape
+    wp0, bo0 = pack_conv3x3(w0, b0, bn0)
+    wp1, bo1 = pack_conv3x3(w1, b1, bn1)
+    xin = dev(x_nchw)
+    out = torch.full((n, h // 2, wd // 2, 32), float("nan"), device="cuda")
+    hip.check(l.vad_conv3x3_c3_fused(xin.data_ptr(), wp0.data_ptr(), bo0.data_ptr(), wp1.data_ptr(), bo1.data_ptr(),
+                                     out.data_ptr(), n, h, wd, stream()))
+    torch.cuda.synchronize()
+    return to_nchw(out)

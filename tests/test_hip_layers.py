@@ -54,6 +54,20 @@ def test_conv3x3(cin, cout, h, w, act, pool):
     assert max_abs(got, ref) < ATOL
 
 
+@pytest.mark.parametrize("h,w", [(16, 16), (32, 48), (22, 18), (64, 64)])
+def test_conv3x3_c3_fused(h, w):
+    """Fused enc1 block == the two separate layers of the oracle (halo recompute, zero padding of conv #2)."""
+    import hip_helpers as H
+    rng = _rng(h * 100 + w)
+    x = rng.uniform(-1, 1, (2, 3, h, w)).astype(np.float32)
+    w0, b0, bn0 = _conv_params(rng, 32, 3)
+    w1, b1, bn1 = _conv_params(rng, 32, 32)
+    ref = _ref_conv(_ref_conv(x, w0, b0, bn0, 1, False), w1, b1, bn1, 1, True)
+    got = H.conv3x3_c3_fused(x, w0, b0, bn0, w1, b1, bn1)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert max_abs(got, ref) < ATOL
+
+
 def test_conv3x3_no_bn_and_frame_strides():
     import hip_helpers as H
     rng = _rng(5)

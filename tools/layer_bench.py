@@ -14,7 +14,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 hip = importlib.import_module("video-anomaly-detection_amd.hip")
 
 IMAGE_LAYERS = [  # name, kind, h, cin, cout, pool
-    ("enc1.0", "c3", 256, 3, 32, 0), ("enc1.3", "conv3x3", 256, 32, 32, 1), ("enc2.0", "conv3x3", 128, 32, 64, 0),
+    ("enc1", "c3fused", 256, 3, 32, 1), ("enc2.0", "conv3x3", 128, 32, 64, 0),
     ("enc2.3", "conv3x3", 128, 64, 64, 1), ("enc3.0", "conv3x3", 64, 64, 128, 0), ("enc3.3", "conv3x3", 64, 128, 128, 1),
     ("enc4.0", "conv3x3", 32, 128, 256, 0), ("enc4.3", "conv3x3", 32, 256, 256, 1), ("dec1.0", "convt", 16, 256, 128, 0),
     ("dec1.3", "conv3x3", 32, 128, 128, 0), ("dec2.0", "convt", 32, 128, 64, 0), ("dec2.3", "conv3x3", 64, 64, 64, 0),
@@ -33,6 +33,13 @@ def run(kind, n, h, w, cin, cout, pool, iters, warm=3):
         out = torch.empty(n, h // (2 if pool else 1), w // (2 if pool else 1), cout, device="cuda")
         fn = lambda: l.vad_conv3x3_c3(x.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), n, h, w, cout, 1, pool, s)
         flop = 2.0 * n * h * w * 27 * cout
+        byts = 4.0 * (x.numel() + out.numel())
+    elif kind == "c3fused":
+        x = rnd(n, 3, h, w); w0 = rnd(28 * 32) * 0.2; b0 = rnd(32); w1 = rnd(9 * 32 * 32) * 0.05; b1 = rnd(32)
+        out = torch.empty(n, h // 2, w // 2, 32, device="cuda")
+        fn = lambda: l.vad_conv3x3_c3_fused(x.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                            out.data_ptr(), n, h, w, s)
+        flop = 2.0 * n * h * w * (27 * 32 + 9 * 32 * 32)
         byts = 4.0 * (x.numel() + out.numel())
     elif kind == "conv3x3":
         x = rnd(n, h, w, cin); wt = rnd(9 * cin * cout) * 0.05; b = rnd(cout)
@@ -96,7 +103,17 @@ if __name__ == "__main__":
     ap.add_argument("--cout", type=int, default=32)
     ap.add_argument("--pool", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--stamps", type=int, default=0, help="diagnostic build only (VAD_LIB=...stamps.so)")
+    ap.add_argument("--variant", type=int, default=-1, help="conv kernel variant (0 one tile per WG, 1 persistent)")
     a = ap.parse_args()
+    if a.variant >= 0:
+        hip.lib().vad_debug_set_conv_variant(a.variant)
+    dbg = None
+    if a.stamps:
+        import ctypes
+        hip.lib().vad_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+        dbg = torch.zeros(1024 * 4 * 8, dtype=torch.int64, device="cuda")
+        hip.lib().vad_debug_set_stamp_buffer(dbg.data_ptr())
     if a.kind == "image":
         tot = 0.0
         for name, kind, h, cin, cout, pool in IMAGE_LAYERS:
@@ -107,3 +124,11 @@ if __name__ == "__main__":
     else:
         ms, tf, gbs = run(a.kind, a.n, a.h, a.w or a.h, a.cin, a.cout, a.pool, a.iters)
         print(f"{a.kind} n={a.n} {a.h}x{a.w or a.h} {a.cin}->{a.cout} pool={a.pool}: {ms:.4f} ms  {tf:.2f} TFLOP/s  {gbs:.1f} GB/s")
+        if dbg is not None:
+            d = dbg.cpu().numpy().reshape(-1, 8)
+            d = d[d[:, 7] > 0]
+            per = d[:, :7] / d[:, 7:8]
+            names = ["epi->top", "barrier1", "lds write", "barrier2", "issue+first loads", "36 steps", "epilogue"]
+            print(f"waves {len(d)}, stages/wave {d[:, 7].mean():.1f}")
+            for i, nm in enumerate(names):
+                print(f"  {nm:20s} mean {per[:, i].mean():9.0f}  p10 {np.percentile(per[:, i], 10):9.0f}  p90 {np.percentile(per[:, i], 90):9.0f} cycles/stage")

@@ -52,7 +52,7 @@ extern "C" int vad_prof_read(float* ms, int* launches) {
     return VAD_OK;
 }
 
-static const char* kImgSlots[] = {"enc1.0", "enc1.3+pool", "enc2.0", "enc2.3+pool", "enc3.0", "enc3.3+pool",
+static const char* kImgSlots[] = {"enc1.0", "enc1.0+enc1.3+pool", "enc2.0", "enc2.3+pool", "enc3.0", "enc3.3+pool",
                                   "enc4.0", "enc4.3+pool", "dec1.0", "dec1.3", "dec2.0", "dec2.3", "dec3.0",
                                   "dec3.3", "dec4.0", "dec4.3+score", "finalize", "latent_nchw"};
 static const char* kVidSlots[] = {"enc.0+pool", "enc.4+pool", "enc.8+pool", "enc.12+pool", "convlstm", "proj",
@@ -112,8 +112,7 @@ extern "C" int vad_img_score(const float* x, long long b, int h, int w, int late
         const float* xin = x + (size_t)f0 * 3 * h * w;
         int hh = h, ww = w;
         // encoder: 4 x [conv-BN-LeakyReLU, conv-BN-LeakyReLU-MaxPool] (models/autoencoder.py:38-79)
-        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3(xin, W_(0), B_(0), A, n, hh, ww, 32, VAD_ACT_LEAKY, 0, s)); }
-        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), B, 0, n, hh, ww, 32, 32, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(1, s); TRY(vad_conv3x3_c3_fused(xin, W_(0), B_(0), W_(1), B_(1), B, n, hh, ww, s)); }
         for (int blk = 1; blk < 4; ++blk) {
             hh /= 2; ww /= 2;
             { VadProfScope ps(2 * blk, s);

@@ -15,7 +15,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
-LIB_PATH = PKG_DIR / "libvad_hip.so"
+LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
 SOURCES = ["conv_mfma.hip", "tail.hip", "vad_api.hip", "pack.cpp"]
 HEADERS = ["vad_common.h", "vad_layout.h"]
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "vad_pack_conv3x3_to3_floats": (_sz, [_i]),
     "vad_pack_conv3x3_to3": (_i, [_vp, _i, _vp]),
     "vad_conv3x3_c3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_conv3x3_c3_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "vad_conv3x3": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_convt2x2": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_conv1x1": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
@@ -88,6 +89,7 @@ SIGNATURES = {
     "vad_vid_pack": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "vad_vid_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_debug_set_conv_variant": (_i, [_i]),
     "vad_prof_enable": (_i, [_i]),
     "vad_prof_reset": (_i, []),
     "vad_prof_read": (_i, [_vp, _vp]),
