@@ -112,7 +112,7 @@ if __name__ == "__main__":
     if a.stamps:
         import ctypes
         hip.lib().vad_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
-        dbg = torch.zeros(1024 * 4 * 8, dtype=torch.int64, device="cuda")
+        dbg = torch.zeros(1024 * 4 * 12, dtype=torch.int64, device="cuda")
         hip.lib().vad_debug_set_stamp_buffer(dbg.data_ptr())
     if a.kind == "image":
         tot = 0.0
@@ -125,10 +125,12 @@ if __name__ == "__main__":
         ms, tf, gbs = run(a.kind, a.n, a.h, a.w or a.h, a.cin, a.cout, a.pool, a.iters)
         print(f"{a.kind} n={a.n} {a.h}x{a.w or a.h} {a.cin}->{a.cout} pool={a.pool}: {ms:.4f} ms  {tf:.2f} TFLOP/s  {gbs:.1f} GB/s")
         if dbg is not None:
-            d = dbg.cpu().numpy().reshape(-1, 8)
-            d = d[d[:, 7] > 0]
-            per = d[:, :7] / d[:, 7:8]
-            names = ["epi->top", "barrier1", "lds write", "barrier2", "issue+first loads", "36 steps", "epilogue"]
-            print(f"waves {len(d)}, stages/wave {d[:, 7].mean():.1f}")
+            d = dbg.cpu().numpy().reshape(-1, 12)
+            d = d[d[:, 11] > 0]
+            per = d[:, :10] / d[:, 11:12]
+            names = ["epi->top", "barrier1", "lds write", "barrier2", "issue+first loads", "36 steps", "epilogue",
+                     "fused: issue x", "fused: c3 stage", "fused: barrier3"]
+            print(f"waves {len(d)}, stages/wave {d[:, 11].mean():.1f}, shader clock {d[:, 10].mean() / 1e6:.3f} GHz, "
+                  f"sum of segments {per.sum(axis=1).mean():.0f} cycles/stage")
             for i, nm in enumerate(names):
                 print(f"  {nm:20s} mean {per[:, i].mean():9.0f}  p10 {np.percentile(per[:, i], 10):9.0f}  p90 {np.percentile(per[:, i], 90):9.0f} cycles/stage")

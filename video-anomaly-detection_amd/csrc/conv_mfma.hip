@@ -18,6 +18,7 @@
 // (models/autoencoder.py:38-79,103-139; models/video_autoencoder.py:191-215), ConvLSTMCell
 // (models/video_autoencoder.py:54-85), nn.ConvTranspose2d(k2,s2)+BN+ReLU
 // (models/autoencoder.py:104-131; models/video_autoencoder.py:244-256).
+#include <type_traits>
 #include "vad_common.h"
 
 enum { MODE_PLAIN = 0, MODE_POOL = 1, MODE_LSTM = 2 };
@@ -29,7 +30,7 @@ struct Conv3P {
     float* out;       long long out_fs;
     const float* c_prev; float* c_out;               // MODE_LSTM
     const float* w0; const float* b0;                // FUSE_C3: first-layer (3->32) weights [28][32], bias
-    int h, w_, cin, cout, hid;
+    int n, h, w_, cin, cout, hid;
     int tiles_x, tiles_y, cblocks;
     unsigned nblocks;
     unsigned long long* dbg;                         // VAD_STAMPS diagnostic build only
@@ -211,11 +212,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
                     const float cp = p.c_prev ? p.c_prev[(size_t)n * cfs + pix * p.hid + hc] : 0.f;
                     const float gi = vad_sigmoid(acc[mt][0][r]);
                     const float gf = vad_sigmoid(acc[mt][1][r]);
-                    const float gg = tanhf(acc[mt][2][r]);
+                    const float gg = vad_tanh(acc[mt][2][r]);
                     const float go = vad_sigmoid(acc[mt][3][r]);
                     const float cn = gf * cp + gi * gg;
                     p.c_out[(size_t)n * cfs + pix * p.hid + hc] = cn;
-                    p.out[(size_t)n * p.out_fs + pix * p.hid + hc] = go * tanhf(cn);
+                    p.out[(size_t)n * p.out_fs + pix * p.hid + hc] = go * vad_tanh(cn);
                 }
             }
         }
@@ -250,275 +251,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Persistent form of the same convolution: a work-group walks tiles b, b+G, b+2G, ... and treats
-// (tile, 32-channel chunk) pairs as a flat sequence of stages.  The NEXT stage's input tile is
-// fetched global -> registers right after the barrier that publishes the current one (async-stage
-// split: issue early, ds_write late), so its HBM/L2 latency runs under ~36 MFMA steps instead of
-// stalling every wave of the CU at once; the epilogue stores of a tile drain under the next tile.
-template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
-    static_assert(WM * WN == 4, "4 waves per work-group");
-    static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
-    constexpr int TH = 2 * MT * WM, LH = TH + 2, LW = 18, PS = CK + 4;
-    constexpr int TOT = LH * LW * (CK / 4), NPF = (TOT + 255) / 256;
-    constexpr int NS = 9 * (CK / 8);
-    static_assert(NS % 2 == 0, "double-buffer parity must be the same in every chunk");
-    static_assert(256 % (CK / 4) == 0, "a thread keeps the same channel quad in every staging slot");
-    __shared__ __attribute__((aligned(16))) float tile[LH * LW * PS];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-    const int prow = (li >> 1) & 1, pcol = 2 * (li >> 2) + (li & 1);
-    int abase[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        abase[mt] = ((2 * (wm * MT + mt) + prow) * LW + pcol) * PS + 4 * lh;
-
-    const int nch_a = p.cin_a / CK;
-    const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
-    // All addressing below is 32-bit (byte offsets from wave-uniform bases; 24-bit multiplies): the host
-    // checks that every tensor of one frame and the weight blob stay below 2^31 bytes.
-    const unsigned wstep = (unsigned)p.cout * 32u;                 // bytes per (tap, k8) slab
-    const unsigned wtap = (unsigned)(p.cin / 8) * wstep;           // bytes per tap
-    const char* wbase = (const char*)p.w;
-
-    // staging slots of this thread: slot i covers float4 index tid + 256 i = (pixel, channel quad c4)
-    const int c4 = tid % (CK / 4);
-    int slot_yx[NPF];                                              // (ly << 8) | lx, or -1 past the end
-#pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-        const int idx = tid + 256 * i, pix = idx / (CK / 4);
-        const int ly = pix / LW, lx = pix - ly * LW;
-        slot_yx[i] = idx < TOT ? ((ly << 8) | lx) : -1;
-    }
-
-    f32x4 pf[NPF];   // next stage's input, in flight
-#define DECODE(Lg, cb_, n_, y0_, x0_)                                  \
-    {                                                                  \
-        unsigned L_ = vad_xcd_remap((Lg), p.nblocks);                  \
-        cb_ = L_ % p.cblocks; L_ /= p.cblocks;                         \
-        x0_ = (L_ % p.tiles_x) * 16; L_ /= p.tiles_x;                  \
-        y0_ = (L_ % p.tiles_y) * TH; n_ = L_ / p.tiles_y;              \
-    }
-#define ISSUE(n_, y0_, x0_, ch_)                                                                         \
-    {                                                                                                    \
-        const char* src_; int pstride_, coff_;                                                           \
-        if ((ch_) < nch_a) { src_ = (const char*)(p.in + (size_t)(n_) * p.in_fs); pstride_ = p.cin_a; coff_ = (ch_) * CK; } \
-        else { src_ = (const char*)(p.in2 + (size_t)(n_) * p.in2_fs); pstride_ = p.cin - p.cin_a; coff_ = (ch_) * CK - p.cin_a; } \
-        const int lane_c_ = coff_ + c4 * 4;                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                             \
-            const int gy_ = (y0_) - 1 + (slot_yx[i_] >> 8), gx_ = (x0_) - 1 + (slot_yx[i_] & 255);       \
-            f32x4 v_ = {0.f, 0.f, 0.f, 0.f};                                                             \
-            if (slot_yx[i_] >= 0 && gy_ >= 0 && gy_ < p.h && gx_ >= 0 && gx_ < p.w_) {                   \
-                const unsigned off_ = (unsigned)(__mul24(__mul24(gy_, p.w_) + gx_, pstride_) + lane_c_) * 4u; \
-                v_ = *(const f32x4*)(src_ + off_);                                                       \
-            }                                                                                            \
-            pf[i_] = v_;                                                                                 \
-        }                                                                                                \
-    }
-
-#ifdef VAD_STAMPS
-    // Diagnostic build: per-wave cycle sums between stamps (st_sum[k] = time from stamp k-1 to stamp k).
-    unsigned long long st_sum[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_n = 0;
-#define STAMP(k)                                                                                      \
-    {                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        unsigned long long t_;                                                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        if (st_prev) st_sum[k] += t_ - st_prev;                                                       \
-        st_prev = t_;                                                                                 \
-        if ((k) == 5) ++st_n;                                                                         \
-    }
-#else
-#define STAMP(k)
-#endif
-    unsigned Lg = blockIdx.x;
-    int cb, n, y0, x0;
-    DECODE(Lg, cb, n, y0, x0);
-    ISSUE(n, y0, x0, 0);
-
-    // per-lane byte offset of this lane's weight row inside a (tap, k8) slab, and its bias, for cout block cb_
-#define LANE_CO(cb_, nt_) ((MODE == MODE_LSTM) ? (nt_) * p.hid + ((cb_) * WN + wn) * 32 + li : (((cb_) * WN + wn) * NT + (nt_)) * 32 + li)
-    f32x4 a[2][MT], b[2][NT];
-    unsigned wl[NT];
-    float bv[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = LANE_CO(cb, nt);
-        wl[nt] = (unsigned)co * 32u + 16u * lh;
-        bv[nt] = p.bias[co];
-    }
-#define LOAD_B(buf, chunk, step)                                                                  \
-    {                                                                                             \
-        const unsigned woff_ = (unsigned)((step) / (CK / 8)) * wtap +                             \
-                               (unsigned)((chunk) * (CK / 8) + (step) % (CK / 8)) * wstep;        \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = *(const f32x4*)(wbase + (wl[nt] + woff_)); \
-    }
-#define LOAD_A(buf, step)                                                                         \
-    {                                                                                             \
-        const int toff_ = ((((step) / (CK / 8)) / 3) * LW + (((step) / (CK / 8)) % 3)) * PS +     \
-                          ((step) % (CK / 8)) * 8;                                                \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *(const f32x4*)&tile[abase[mt] + toff_]; \
-    }
-    LOAD_B(0, 0, 0);
-
-    while (true) {
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
-
-        const unsigned Lnext = Lg + gridDim.x;
-        const bool has_next = Lnext < p.nblocks;
-        int cbn = 0, nn = 0, y0n = 0, x0n = 0;
-        if (has_next) DECODE(Lnext, cbn, nn, y0n, x0n);
-
-        for (int ch = 0; ch < nch; ++ch) {
-            STAMP(0);
-            __syncthreads();                       // every wave is done reading the previous stage
-            STAMP(1);
-#pragma unroll
-            for (int i = 0; i < NPF; ++i)
-                if (slot_yx[i] >= 0)
-                    *(f32x4*)&tile[__mul24(__mul24(slot_yx[i] >> 8, LW) + (slot_yx[i] & 255), PS) + c4 * 4] = pf[i];
-            STAMP(2);
-            __syncthreads();
-            STAMP(3);
-            if (ch + 1 < nch) { ISSUE(n, y0, x0, ch + 1); }
-            else if (has_next) { ISSUE(nn, y0n, x0n, 0); }
-            LOAD_A(0, 0);
-            STAMP(4);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s + 1 < NS) {
-                    LOAD_A(nxt, s + 1);
-                    LOAD_B(nxt, ch, s + 1);
-                } else if (ch + 1 < nch) {
-                    LOAD_B(nxt, ch + 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = MFMA32(a[cur][mt][j], b[cur][nt][j], acc[mt][nt]);
-            }
-            STAMP(5);
-        }
-
-        // The next tile's first B fragments and bias are requested BEFORE this tile's stores: vmcnt retires in
-        // order, so loads issued behind the stores would hold the next tile's first MFMAs until every store is
-        // acknowledged.
-        const int cb_done = cb;
-        float bvn[NT];
-        if (has_next) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = LANE_CO(cbn, nt);
-                wl[nt] = (unsigned)co * 32u + 16u * lh;
-                bvn[nt] = p.bias[co];
-            }
-            LOAD_B(0, 0, 0);
-        }
-
-        // ------------------------------------------------------------ epilogue of this tile
-        if (MODE == MODE_LSTM) {
-            const int hc = (cb_done * WN + wn) * 32 + li;
-            const unsigned cfs = (unsigned)(p.h * p.w_) * (unsigned)p.hid;
-            const float* cprev = p.c_prev ? p.c_prev + (size_t)n * cfs : nullptr;
-            float* cout_ = p.c_out + (size_t)n * cfs;
-            float* hout_ = p.out + (size_t)n * p.out_fs;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int wq = 2 * (r >> 2) + lh, pos = r & 3;
-                    const int y = y0 + 2 * (wm * MT + mt) + (pos >> 1), x = x0 + 2 * wq + (pos & 1);
-                    if (y < p.h && x < p.w_) {
-                        const unsigned o = (unsigned)(__mul24(__mul24(y, p.w_) + x, p.hid) + hc);
-                        const float cp = cprev ? cprev[o] : 0.f;
-                        const float gi = vad_sigmoid(acc[mt][0][r]);
-                        const float gf = vad_sigmoid(acc[mt][1][r]);
-                        const float gg = tanhf(acc[mt][2][r]);
-                        const float go = vad_sigmoid(acc[mt][3][r]);
-                        const float cn = gf * cp + gi * gg;
-                        cout_[o] = cn;
-                        hout_[o] = go * tanhf(cn);
-                    }
-                }
-            }
-        } else {
-            float* outn = p.out + (size_t)n * p.out_fs;
-            const int cobase = (cb_done * WN + wn) * NT * 32 + li;
-            if (MODE == MODE_POOL) {
-                const int wo = p.w_ >> 1, ho = p.h >> 1;
-                const int oy0 = (y0 >> 1) + wm * MT, ox0 = (x0 >> 1) + lh;
-                const int lane0 = __mul24(__mul24(oy0, wo) + ox0, p.cout) + cobase;   // element offset of (mt 0, q 0, nt 0)
-                const int rowstep = __mul24(wo, p.cout);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool ok = (oy0 + mt) < ho && (ox0 + 2 * q) < wo;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            float v[4];
-#pragma unroll
-                            for (int pos = 0; pos < 4; ++pos) v[pos] = vad_act(acc[mt][nt][4 * q + pos], ACT);
-                            const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                            if (ok) outn[(unsigned)(lane0 + mt * rowstep + 2 * q * p.cout + nt * 32)] = m;
-                        }
-                    }
-                }
-            } else {
-                const int yb = y0 + 2 * wm * MT, xb = x0 + 2 * lh;
-                const int lane0 = __mul24(__mul24(yb, p.w_) + xb, p.cout) + cobase;
-                const int rowstep = __mul24(p.w_, p.cout);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                        for (int pos = 0; pos < 4; ++pos) {
-                            const int dy = 2 * mt + (pos >> 1), dx = 4 * q + (pos & 1);
-                            const bool ok = (yb + dy) < p.h && (xb + dx) < p.w_;
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                if (ok) outn[(unsigned)(lane0 + dy * rowstep + dx * p.cout + nt * 32)] = vad_act(acc[mt][nt][4 * q + pos], ACT);
-                        }
-                    }
-                }
-            }
-        }
-        STAMP(6);
-        if (!has_next) break;
-        Lg = Lnext; cb = cbn; n = nn; y0 = y0n; x0 = x0n;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = bvn[nt];
-    }
-#undef LOAD_A
-#undef LOAD_B
-#undef LANE_CO
-#undef ISSUE
-#undef DECODE
-#ifdef VAD_STAMPS
-    if (p.dbg && lane == 0) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
-        for (int i = 0; i < 7; ++i) d[i] = st_sum[i];
-        d[7] = st_n;
-    }
-#endif
-#undef STAMP
-}
+#include "conv_pkernel.h"
 
 unsigned long long* g_vad_dbg = nullptr;
 extern "C" int vad_debug_set_stamp_buffer(void* p) { g_vad_dbg = (unsigned long long*)p; return VAD_OK; }
@@ -531,7 +264,7 @@ extern "C" int vad_debug_set_conv_variant(int v) {
 }
 
 template <typename K>
-static unsigned persistent_grid(K kernel, unsigned nblocks) {
+static unsigned persistent_grid(K kernel, unsigned nblocks, int max_per_cu = 2) {
     int per_cu = 0, dev = 0;
     static int ncu = 0;
     if (!ncu) {
@@ -540,9 +273,21 @@ static unsigned persistent_grid(K kernel, unsigned nblocks) {
         if (ncu <= 0) ncu = 256;
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;   // two resident work-groups per CU keep the matrix pipe fed; more only adds LDS/L2 pressure
+    // Use EVERY resident slot the hardware offers: with fewer work-groups than slots the dispatcher packs some CUs
+    // to their limit and leaves others with one group, and a persistent grid then runs at the pace of the fullest CU.
+    (void)max_per_cu;
     const unsigned g = (unsigned)ncu * (unsigned)per_cu;
     return nblocks < g ? nblocks : g;
+}
+
+// Persistent grid: (tiles per frame x cout blocks) work-group positions, replicated over `fgroups` frame groups
+// so that about (CUs x resident work-groups per CU) groups run; group g of a position walks frames g, g+fgroups, ...
+static unsigned persistent_grid_for(const Conv3P& p, unsigned cap) {
+    const unsigned per_frame = (unsigned)(p.tiles_x * p.tiles_y * p.cblocks);
+    unsigned fgroups = cap / per_frame;
+    if (fgroups < 1) fgroups = 1;
+    if (fgroups > (unsigned)p.n) fgroups = (unsigned)p.n;
+    return per_frame * fgroups;
 }
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT>
@@ -552,11 +297,9 @@ static void launch_conv3_act(const Conv3P& p, hipStream_t s) {
     } else {
         static unsigned grid_cap = 0;   // per instantiation
         if (!grid_cap) grid_cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>, ~0u);
-        const unsigned g = p.nblocks < grid_cap ? p.nblocks : grid_cap;
         Conv3P q = p;
         q.dbg = g_vad_dbg;
-        // half of one stage: 9*(CK/8) steps x MT*NT*4 MFMAs x 64 cycles / 2, in units of s_sleep(127) = 8128 cycles
-        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(g), dim3(256), 0, s, q);
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(persistent_grid_for(p, grid_cap)), dim3(256), 0, s, q);
     }
 }
 
@@ -569,6 +312,11 @@ static int launch_conv3(Conv3P& p, int n, int act, hipStream_t s) {
     const long long nb = (long long)n * p.tiles_x * p.tiles_y * p.cblocks;
     VAD_REQUIRE(nb > 0 && nb < (1ll << 31), "conv3x3: grid of %lld blocks out of range", nb);
     p.nblocks = (unsigned)nb;
+    p.n = n;
+    // 32-bit addressing inside the kernels: one frame of any tensor and the weight blob must stay below 2^31 bytes
+    const long long chmax = p.cin > p.cout ? p.cin : p.cout;
+    VAD_REQUIRE((long long)p.h * p.w_ * chmax * 4 < (1ll << 31) && 9ll * p.cin * p.cout * 4 < (1ll << 31),
+                "conv3x3: frame %dx%dx%lld or weights %dx%d too large for 32-bit offsets", p.h, p.w_, chmax, p.cin, p.cout);
     if (MODE == MODE_LSTM || act == VAD_ACT_NONE) launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_NONE>(p, s);
     else if (act == VAD_ACT_LEAKY) launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_LEAKY>(p, s);
     else launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_RELU>(p, s);
@@ -624,8 +372,17 @@ extern "C" int vad_conv3x3_c3_fused(const float* x, const float* w0, const float
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3_fused: grid too large");
     p.nblocks = (unsigned)nb;
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>), dim3((unsigned)nb), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    p.n = n;
+    if (g_vad_conv_variant == 0) {
+        hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>), dim3((unsigned)nb), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    } else {
+        static unsigned grid_cap = 0;
+        if (!grid_cap) grid_cap = persistent_grid(conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>, ~0u, g_vad_conv64 ? 3 : 2);
+        p.dbg = g_vad_dbg;
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>), dim3(persistent_grid_for(p, grid_cap)), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    }
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -645,7 +402,12 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
     p.out_fs = h_out_fs ? h_out_fs : (long long)h * wd * hid;
     p.c_prev = c_prev; p.c_out = c_out;
     p.h = h; p.w_ = wd; p.cin = cin_x + hid; p.cout = 4 * hid; p.hid = hid;
-    return launch_conv3<32, 1, 4, 2, 2, MODE_LSTM>(p, n, VAD_ACT_NONE, (hipStream_t)stream);
+    // the persistent kernel shares one set of staging offsets between x and h: needs cin_x == hid
+    const int saved = g_vad_conv_variant;
+    if (cin_x != hid) g_vad_conv_variant = 0;
+    const int rc = launch_conv3<32, 1, 4, 2, 2, MODE_LSTM>(p, n, VAD_ACT_NONE, (hipStream_t)stream);
+    g_vad_conv_variant = saved;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,402 @@
+// Persistent form of the 3x3 implicit-GEMM convolution (included by conv_mfma.hip; same operand
+// layouts as conv3x3_mfma_kernel there).
+//
+// A work-group owns ONE spatial tile position and ONE output-channel block and walks the frames
+// n = g, g + G, g + 2G, ... of the batch.  Everything that depends on geometry only (which pixels
+// of the halo tile exist, their offsets inside a frame, the lane's weight rows and bias, the
+// epilogue's store offsets) is computed once; per frame only a base pointer moves.
+// (frame, 32-channel chunk) pairs form a flat sequence of stages:
+//   * the NEXT stage's input tile is fetched global -> registers right after the barrier that
+//     publishes the current one (issue early, ds_write late), so its HBM/L2 latency runs under
+//     ~36 MFMA steps instead of stalling every wave of the CU at once;
+//   * fragments for step s+1 are loaded before the MFMAs of step s (sched_barrier keeps hipcc
+//     from sinking the loads back to their first use);
+//   * the next frame's first B fragments are requested BEFORE this frame's stores, because vmcnt
+//     retires in order and loads issued behind the stores would wait for every store to be acked.
+// All addressing is 32-bit (24-bit multiplies, byte offsets from wave-uniform bases); the host
+// checks that a frame of any tensor and the weight blob stay below 2^31 bytes.
+#pragma once
+
+__device__ __forceinline__ void pf_set(float& d, float v) { d = v; }
+__device__ __forceinline__ void pf_set(float& d, f32x4 v) { d = v[0]; }
+__device__ __forceinline__ void pf_set(f32x4& d, f32x4 v) { d = v; }
+__device__ __forceinline__ void pf_set(f32x4& d, float v) { d = f32x4{v, v, v, v}; }
+__device__ __forceinline__ float pf_get_f(float v) { return v; }
+__device__ __forceinline__ float pf_get_f(f32x4 v) { return v[0]; }
+__device__ __forceinline__ f32x4 pf_get_v(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 pf_get_v(float v) { return f32x4{v, v, v, v}; }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor for [p, p + bytes): loads past the end return 0 and stores past the end are dropped, which
+// is how zero padding and partial tiles are handled without branches (invalid elements get offset 0x80000000).
+// The pointer halves go through readfirstlane so hipcc can prove the descriptor wave-uniform (no waterfall loops).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vad_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 vad_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float vad_bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void vad_bstore1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+constexpr unsigned VAD_OOB = 0x80000000u;   // byte offset no frame reaches (host checks frames < 2^31 bytes)
+
+#ifdef VAD_STAMPS
+#define STAMP(k)                                                                                      \
+    {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (st_prev) st_sum[k] += t_ - st_prev;                                                       \
+        st_prev = t_;                                                                                 \
+        if ((k) == 5) ++st_n;                                                                         \
+    }
+#else
+#define STAMP(k)
+#endif
+
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
+    static_assert(WM * WN == 4, "4 waves per work-group");
+    static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
+    static_assert(!FUSE_C3 || CK == 32, "fused first layer produces exactly one 32-channel chunk");
+    static_assert(CK == 32, "staging slots assume 8 channel quads per pixel");
+    constexpr int TH = 2 * MT * WM, LH = TH + 2, LW = 18, PS = CK + 4;
+    // FUSE_C3: the staged data are the 3 NCHW input planes of the tile with a 2-pixel halo (scalar floats);
+    // otherwise float4 channel quads of the NHWC tile with a 1-pixel halo.
+    constexpr int XH = LH + 2, XW = 20, XS = 24;
+    constexpr int NPIX = LH * LW, NT0 = (NPIX + 31) / 32;
+    constexpr int TOT = FUSE_C3 ? 3 * XH * XW : NPIX * (CK / 4), NPF = (TOT + 255) / 256;
+    constexpr int NS = 9 * (CK / 8);
+    static_assert(NS % 2 == 0, "double-buffer parity must be the same in every chunk");
+    __shared__ __attribute__((aligned(16))) float tile[(FUSE_C3 ? NT0 * 32 : NPIX) * PS];
+    __shared__ float xin[FUSE_C3 ? 3 * XH * XS : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int prow = (li >> 1) & 1, pcol = 2 * (li >> 2) + (li & 1);
+
+    // ---- geometry of this work-group (fixed for its whole life)
+    const unsigned per_frame = (unsigned)(p.tiles_x * p.tiles_y * p.cblocks);
+    unsigned L = vad_xcd_remap(blockIdx.x % per_frame, per_frame);
+    const int fg = blockIdx.x / per_frame, fgroups = gridDim.x / per_frame;
+    const int cb = L % p.cblocks; L /= p.cblocks;
+    const int x0 = (L % p.tiles_x) * 16, y0 = (L / p.tiles_x) * TH;
+    const int H = p.h, W = p.w_;
+
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        abase[mt] = ((2 * (wm * MT + mt) + prow) * LW + pcol) * PS + 4 * lh;
+
+    const int nch_a = p.cin_a / CK;
+    const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
+    const unsigned wstep = (unsigned)p.cout * 32u;                 // bytes per (tap, k8) slab
+    const unsigned wtap = (unsigned)(p.cin / 8) * wstep;           // bytes per tap
+    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 9u * wtap);
+
+    // staging slots: slot i of this thread is float4 (or float) number tid + 256 i of the staged tile.
+    // svo[i] = byte offset of the slot inside one frame of the source (channel chunk 0), or VAD_OOB when the
+    // slot is zero padding / past the end of the tile: the buffer load then returns 0 by itself.
+    unsigned svo[NPF];
+    int slds0;                                                     // LDS float offset of slot 0; slot i adds a constant
+    const int c4 = tid & 7;
+    if (FUSE_C3) {
+        slds0 = 0;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + 256 * i;
+            const int lx = idx % XW, t = idx / XW, ly = t % XH, c = t / XH;
+            const int gy = y0 - 2 + ly, gx = x0 - 2 + lx;
+            const bool ok = idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            svo[i] = ok ? (unsigned)(__mul24(c, __mul24(H, W)) + __mul24(gy, W) + gx) * 4u : VAD_OOB;
+        }
+    } else {
+        const int pix0 = tid >> 3;
+        slds0 = pix0 * PS + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int pix = pix0 + 32 * i;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            svo[i] = ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, p.cin_a) + c4 * 4) * 4u : VAD_OOB;
+        }
+    }
+
+    typedef typename std::conditional<FUSE_C3 != 0, float, f32x4>::type pf_t;
+    pf_t pf[NPF];    // next stage's input, in flight
+
+    // both sources of a two-source (ConvLSTM) launch have the same channel count (host-checked), so svo serves both
+    const unsigned in_bytes = FUSE_C3 ? (unsigned)(3 * H * W) * 4u : (unsigned)(H * W) * (unsigned)p.cin_a * 4u;
+#define ISSUE(n_, ch_)                                                                                   \
+    {                                                                                                    \
+        if constexpr (FUSE_C3) {                                                                         \
+            const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(p.in + (size_t)(n_) * p.in_fs, in_bytes);         \
+            _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf_set(pf[i_], vad_bload1(r_, svo[i_], 0)); \
+        } else {                                                                                         \
+            const float* src_ = ((ch_) < nch_a) ? p.in + (size_t)(n_) * p.in_fs + (ch_) * CK             \
+                                                : p.in2 + (size_t)(n_) * p.in2_fs + ((ch_) - nch_a) * CK; \
+            const unsigned skip_ = (unsigned)(((ch_) < nch_a) ? (ch_) : (ch_) - nch_a) * CK * 4u;        \
+            const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(src_, in_bytes - skip_);                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf_set(pf[i_], vad_bload4(r_, svo[i_], 0)); \
+        }                                                                                                \
+    }
+
+#ifdef VAD_STAMPS
+    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_n = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    int n = fg;
+    if (n >= p.n) return;                                          // (grid never exceeds the work; defensive)
+    ISSUE(n, 0);
+
+    // per-lane weight rows / bias of this cout block
+    f32x4 a[2][MT], b[2][NT];
+    unsigned wl[NT];
+    float bv[NT];
+    int cofs[NT];                                                  // output channel (element offset) of N-tile nt
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (MODE == MODE_LSTM) ? nt * p.hid + (cb * WN + wn) * 32 + li : ((cb * WN + wn) * NT + nt) * 32 + li;
+        cofs[nt] = co;
+        wl[nt] = (unsigned)co * 32u + 16u * lh;
+        bv[nt] = p.bias[co];
+    }
+#define LOAD_B(buf, chunk, step)                                                                  \
+    {                                                                                             \
+        const unsigned woff_ = (unsigned)((step) / (CK / 8)) * wtap +                             \
+                               (unsigned)((chunk) * (CK / 8) + (step) % (CK / 8)) * wstep;        \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = vad_bload4(rw, wl[nt], woff_); \
+    }
+#define LOAD_A(buf, step)                                                                         \
+    {                                                                                             \
+        const int toff_ = ((((step) / (CK / 8)) / 3) * LW + (((step) / (CK / 8)) % 3)) * PS +     \
+                          ((step) % (CK / 8)) * 8;                                                \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *(const f32x4*)&tile[abase[mt] + toff_]; \
+    }
+    LOAD_B(0, 0, 0);
+
+    float b0w[FUSE_C3 ? 14 : 1];
+    float bias0 = 0.f;
+    bool interior = false;
+    if constexpr (FUSE_C3) {
+#pragma unroll
+        for (int s0 = 0; s0 < 14; ++s0) b0w[s0] = p.w0[(s0 * 2 + lh) * 32 + li];
+        bias0 = p.b0[li];
+        interior = y0 > 0 && x0 > 0 && y0 + TH < H && x0 + 16 < W;
+    }
+    // Touch the per-lane constants so hipcc retires their loads BEFORE the frame loop: otherwise it guards
+    // MFMAs inside the loop with descending vmcnt waits that also drain the freshly issued prefetch.
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bv[nt]));
+    if constexpr (FUSE_C3) {
+#pragma unroll
+        for (int s0 = 0; s0 < 14; ++s0) asm volatile("" ::"v"(b0w[s0]));
+        asm volatile("" ::"v"(bias0));
+    }
+
+    // epilogue geometry: per-lane byte offset of (mt 0, q 0, pos 0) for each N-tile, plus wave-uniform strides
+    const bool full_tile = (y0 + TH <= H) && (x0 + 16 <= W);
+    const int ech = (MODE == MODE_LSTM) ? p.hid : p.cout;
+    const int ow = (MODE == MODE_POOL) ? (W >> 1) : W, oh = (MODE == MODE_POOL) ? (H >> 1) : H;
+    const int ey0 = (MODE == MODE_POOL) ? (y0 >> 1) + wm * MT : y0 + 2 * wm * MT;      // first output row of this lane
+    const int ex0 = (MODE == MODE_POOL) ? (x0 >> 1) + lh : x0 + 2 * lh;                // first output column
+    const unsigned erow = (unsigned)__mul24(ow, ech) * 4u, ecol = (unsigned)ech * 4u;  // bytes per output row / pixel
+    unsigned eoff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) eoff[nt] = (unsigned)(__mul24(__mul24(ey0, ow) + ex0, ech) + cofs[nt]) * 4u;
+    const unsigned out_bytes = (unsigned)__mul24(oh, ow) * (unsigned)ech * 4u;
+
+    while (true) {
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
+
+        const int nn = n + fgroups;
+        const bool has_next = nn < p.n;
+
+        for (int ch = 0; ch < nch; ++ch) {
+            STAMP(0);
+            __syncthreads();                       // every wave is done reading the previous stage
+            STAMP(1);
+            if constexpr (FUSE_C3) {
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const int idx = tid + 256 * i;
+                    const int lx = idx % XW, t = idx / XW;   // t = c * XH + ly
+                    if (idx < TOT) xin[t * XS + lx] = pf_get_f(pf[i]);
+                }
+                STAMP(2);
+                __syncthreads();
+                STAMP(3);
+                if (has_next) { ISSUE(nn, 0); }
+                STAMP(7);
+                // Fused first layer: Conv2d(3->32)+BN+LeakyReLU of the tile AND its halo, K = 27 padded to 28
+                // (14 MFMAs per 32 pixels), written straight into the LDS tile the 32->32 convolution reads.
+                for (int t = wave; t < NT0; t += 4) {
+                    const int q = t * 32 + li, qc = q < NPIX ? q : NPIX - 1;
+                    const int abase0 = (qc / LW) * XS + (qc % LW);
+                    f32x16 c0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c0[r] = bias0;
+                    float av[14];   // all 14 gathered A values first (hipcc otherwise waits on each ds_read before its MFMA)
+#pragma unroll
+                    for (int s0 = 0; s0 < 14; ++s0) {
+                        const int k0 = 2 * s0, k1 = 2 * s0 + 1;
+                        const int o0 = ((k0 / 9) * XH + (k0 % 9) / 3) * XS + (k0 % 3);
+                        const int o1 = (k1 < 27) ? ((k1 / 9) * XH + (k1 % 9) / 3) * XS + (k1 % 3) : 0;
+                        av[s0] = xin[abase0 + (lh ? o1 : o0)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s0 = 0; s0 < 14; ++s0) c0 = MFMA32(av[s0], b0w[s0], c0);
+                    // straight-line stores (the tile is padded to NT0*32 pixels); only border tiles need the
+                    // per-pixel inside test that provides conv #2's zero padding
+                    const int qb = (t * 32 + 4 * lh) * PS + li;
+                    if (interior) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = vad_act(c0[r], VAD_ACT_LEAKY);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int q2 = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const int ly2 = q2 / LW, lx2 = q2 - ly2 * LW;
+                            const bool inside = (unsigned)(y0 - 1 + ly2) < (unsigned)H && (unsigned)(x0 - 1 + lx2) < (unsigned)W;
+                            const float v = vad_act(c0[r], VAD_ACT_LEAKY);
+                            tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = inside ? v : 0.f;
+                        }
+                    }
+                }
+                STAMP(8);
+                __syncthreads();
+                STAMP(9);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPF; ++i)
+                    if ((tid >> 3) + 32 * i < NPIX) *(f32x4*)&tile[slds0 + i * 32 * PS] = pf_get_v(pf[i]);
+                STAMP(2);
+                __syncthreads();
+                STAMP(3);
+                if (ch + 1 < nch) { ISSUE(n, ch + 1); }
+                else if (has_next) { ISSUE(nn, 0); }
+            }
+            LOAD_A(0, 0);
+            STAMP(4);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s + 1 < NS) {
+                    LOAD_A(nxt, s + 1);
+                    LOAD_B(nxt, ch, s + 1);
+                } else if (ch + 1 < nch) {
+                    LOAD_B(nxt, ch + 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = MFMA32(a[cur][mt][j], b[cur][nt][j], acc[mt][nt]);
+            }
+            STAMP(5);
+        }
+
+        // next frame's first B fragments go out BEFORE this frame's stores (in-order vmcnt)
+        if (has_next) LOAD_B(0, 0, 0);
+
+        // ------------------------------------------------------------ epilogue of this frame's tile
+        // Stores go through a buffer descriptor of this frame's output: offset = lane part (VGPR) + wave-uniform
+        // (row, column) part (SGPR); elements outside a partial tile get offset VAD_OOB and are dropped.
+        if (MODE == MODE_LSTM) {
+            const __amdgpu_buffer_rsrc_t rc_in = vad_rsrc(p.c_prev ? p.c_prev + (size_t)n * (out_bytes / 4) : p.c_out, p.c_prev ? out_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t rc_out = vad_rsrc(p.c_out + (size_t)n * (out_bytes / 4), out_bytes);
+            const __amdgpu_buffer_rsrc_t rh_out = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dy = 2 * mt + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1);
+                    const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + dx) < ow);
+                    const unsigned vo = ok ? eoff[0] : VAD_OOB;                 // gate 0's channel == hidden channel
+                    const unsigned so = dy * erow + dx * ecol;
+                    const float cp = vad_bload1(rc_in, vo, so);                  // zero-sized descriptor -> 0 (initial state)
+                    const float gi = vad_sigmoid(acc[mt][0][r]);
+                    const float gf = vad_sigmoid(acc[mt][1][r]);
+                    const float gg = vad_tanh(acc[mt][2][r]);
+                    const float go = vad_sigmoid(acc[mt][3][r]);
+                    const float cn = gf * cp + gi * gg;
+                    vad_bstore1(cn, rc_out, vo, so);
+                    vad_bstore1(go * vad_tanh(cn), rh_out, vo, so);
+                }
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
+            if (MODE == MODE_POOL) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = full_tile || ((ey0 + mt) < oh && (ex0 + 2 * q) < ow);
+                        const unsigned so = mt * erow + 2 * q * ecol;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            float v[4];
+#pragma unroll
+                            for (int pos = 0; pos < 4; ++pos) v[pos] = vad_act(acc[mt][nt][4 * q + pos], ACT);
+                            vad_bstore1(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), ro, ok ? eoff[nt] : VAD_OOB, so);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int pos = 0; pos < 4; ++pos) {
+                            const int dy = 2 * mt + (pos >> 1), dx = 4 * q + (pos & 1);
+                            const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + dx) < ow);
+                            const unsigned so = dy * erow + dx * ecol;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                vad_bstore1(vad_act(acc[mt][nt][4 * q + pos], ACT), ro, ok ? eoff[nt] : VAD_OOB, so);
+                        }
+                    }
+                }
+            }
+        }
+        STAMP(6);
+        if (!has_next) break;
+        n = nn;
+    }
+#undef LOAD_A
+#undef LOAD_B
+#undef ISSUE
+#ifdef VAD_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+        for (int i = 0; i < 10; ++i) d[i] = st_sum[i];
+        // shader clock in kHz over this wave's life: cycles / (100 MHz ticks) * 1e5
+        d[10] = (__builtin_amdgcn_s_memtime() - st_t0) * 100000ull / (__builtin_amdgcn_s_memrealtime() - st_r0);
+        d[11] = st_n;
+    }
+#endif
+}
+#undef STAMP
