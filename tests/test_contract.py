@@ -1,0 +1,229 @@
+"""CPU-only checks of the drop-in boundary: module tree / state_dict contract against the reference's own
+key list (captured in tests/golden), the C ABI surface, host-side weight packing, and the harness helpers."""
+import ctypes as C
+import importlib
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_synthetic, rel_err
+
+
+def test_import_surface_matches_reference():
+    """`from models import ConvAutoencoder`, `from models.video_autoencoder import VideoAutoencoder`,
+    `from utils import CombinedLoss, SSIMLoss` (reference evaluate.py:22, evaluate_video.py:25, train.py:24)."""
+    import models
+    import models.video_autoencoder as mv
+    import utils
+    assert set(models.__all__) >= {"ConvAutoencoder", "Encoder", "Decoder"}
+    for name in ("ConvLSTMCell", "ConvLSTM", "VideoEncoder", "VideoDecoder", "VideoAutoencoder"):
+        assert hasattr(mv, name)
+    assert utils.SSIMLoss and utils.CombinedLoss
+
+
+def test_state_dict_contract_image(vad, golden):
+    g = golden("init.npz")
+    m = vad.ConvAutoencoder()
+    assert list(m.state_dict().keys()) == list(g["img_keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["img_nparams"]) == 1_546_147
+    for name in ("img_l32_32.npz", "img_l256_64.npz"):
+        f = golden(name)
+        mm = vad.ConvAutoencoder(in_channels=3, latent_dim=int(f["latent_dim"]))
+        sd = mm.state_dict()
+        assert list(sd.keys()) == list(f["keys"])
+        assert [",".join(map(str, v.shape)) for v in sd.values()] == list(f["shapes"])
+        load_synthetic(vad, mm, 1)   # strict load of a full state dict
+
+
+def test_state_dict_contract_video(vad, golden):
+    g = golden("init.npz")
+    m = vad.VideoAutoencoder()
+    assert list(m.state_dict().keys()) == list(g["vid_keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["vid_nparams"]) == 2_709_411
+    for name in ("vid_default_64.npz", "vid_proj_32.npz", "vid_l3_32.npz"):
+        f = golden(name)
+        mm = vad.VideoAutoencoder(in_channels=3, latent_dim=int(f["latent_dim"]), lstm_hidden_dim=int(f["hid"]),
+                                  lstm_num_layers=int(f["layers"]))
+        sd = mm.state_dict()
+        assert list(sd.keys()) == list(f["keys"])
+        assert [",".join(map(str, v.shape)) for v in sd.values()] == list(f["shapes"])
+    assert isinstance(vad.VideoAutoencoder(latent_dim=128, lstm_hidden_dim=128).proj, torch.nn.Identity)
+    assert isinstance(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=64).proj, torch.nn.Conv2d)
+
+
+def test_init_follows_reference(vad):
+    """Xavier-normal conv weights, zero biases, identity BN (reference models/autoencoder.py:170-179)."""
+    torch.manual_seed(0)
+    m = vad.ConvAutoencoder()
+    w = m.encoder.enc2[3].weight
+    assert abs(float(w.std()) - (2.0 / ((64 + 64) * 9)) ** 0.5) < 2e-3
+    assert float(m.encoder.enc2[3].bias.abs().max()) == 0.0
+    bn = m.decoder.dec1[1]
+    assert torch.all(bn.weight == 1) and torch.all(bn.bias == 0)
+
+
+def test_torch_training_path_matches_oracle_on_cpu(vad, golden):
+    """train()/autograd keeps the stock torch.nn composition; in eval mode WITH grad enabled it is the same
+    composition and must agree with the reference's golden scores (this is not the HIP path)."""
+    g = golden("img_l32_32.npz")
+    m = vad.ConvAutoencoder(latent_dim=32)
+    load_synthetic(vad, m, int(g["wseed"]))
+    m.eval()
+    x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), 3, 32, 32))
+    s = m.get_reconstruction_error(x)           # grad enabled -> torch composition
+    assert s.requires_grad and rel_err(s.detach().numpy(), g["scores"]) < 2e-6
+    v = golden("vid_l3_32.npz")
+    mv = vad.VideoAutoencoder(latent_dim=64, lstm_hidden_dim=64, lstm_num_layers=3)
+    load_synthetic(vad, mv, int(v["wseed"]))
+    mv.eval()
+    xv = torch.from_numpy(vad.synth.clips(int(v["xseed"]), 0, int(v["b"]), int(v["t"]), 3, 32, 32))
+    assert rel_err(mv.get_reconstruction_error(xv, per_frame=True).detach().numpy(), v["frame"]) < 2e-6
+
+
+def test_inference_has_no_cpu_fallback(vad):
+    m = vad.ConvAutoencoder(latent_dim=32).eval()
+    with torch.no_grad(), pytest.raises(vad.hip.VadError, match="no CPU fallback"):
+        m.get_reconstruction_error(torch.zeros(1, 3, 32, 32))
+    v = vad.VideoAutoencoder(latent_dim=64, lstm_hidden_dim=64).eval()
+    with torch.no_grad(), pytest.raises(vad.hip.VadError, match="no CPU fallback"):
+        v(torch.zeros(1, 2, 3, 32, 32))
+
+
+def test_losses_match_reference(vad, golden):
+    g = golden("losses.npz")
+    x = torch.from_numpy(vad.synth.frames(77, 0, 2, 3, 32, 32))
+    y = torch.from_numpy(vad.synth.frames(78, 0, 2, 3, 32, 32)) * 0.25 + x * 0.75
+    assert abs(float(vad.SSIMLoss()(y, x)) - float(g["ssim"])) < 1e-6
+    assert abs(float(vad.CombinedLoss(alpha=0.5)(y, x)) - float(g["combined"])) < 1e-6
+    assert abs(float(vad.CombinedLoss(alpha=0.3, window_size=7)(y, x)) - float(g["combined_03"])) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+def _declared_symbols():
+    text = (REPO / "include" / "vad_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vad_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(vad):
+    """libvad_hip.so loads on a machine without a GPU and exports exactly the header's surface."""
+    lib = vad.hip.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vad_hip.h but not exported"
+        assert name in vad.hip.SIGNATURES, f"{name} has no ctypes signature in hip.py"
+    assert set(vad.hip.SIGNATURES) == set(declared)
+    assert lib.vad_abi_version() == 1
+
+
+def test_argument_errors_without_gpu(vad):
+    lib = vad.hip.lib()
+    assert lib.vad_img_packed_floats(3, 256) > 1_500_000
+    assert lib.vad_img_packed_floats(1, 256) == 0 and lib.vad_img_packed_floats(3, 100) == 0
+    assert lib.vad_vid_packed_floats(128, 128, 2) > 2_600_000
+    assert lib.vad_vid_packed_floats(128, 100, 2) == 0
+    assert lib.vad_img_workspace_bytes(16, 250, 256, 256) == 0
+    assert lib.vad_img_workspace_bytes(16, 256, 256, 256) >= 2 * 16 * 256 * 256 * 32 * 4
+    assert lib.vad_vid_nparams(2, 0) == 48 and lib.vad_vid_nparams(1, 1) == 48
+    assert lib.vad_score_partials(0, 256, 256) == 64 and lib.vad_score_partials(1, 256, 256) == 64
+    assert lib.vad_score_partials(7, 256, 256) < 0 and b"kind" in lib.vad_last_error()
+
+
+def test_bn_folding_and_packing_layout(vad):
+    """vad_pack_conv3x3: out[tap][cin/8][cout][8] = w[co][ci][tap] * gamma/sqrt(var+eps); bias folded in fp64."""
+    lib = vad.hip.lib()
+    rng = np.random.default_rng(0)
+    cout, cin = 32, 64
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    bn = [rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32),
+          rng.standard_normal(cout).astype(np.float32), rng.uniform(0.2, 2.0, cout).astype(np.float32)]
+    out = np.empty(lib.vad_pack_conv3x3_floats(cout, cin), np.float32)
+    bo = np.empty(cout, np.float32)
+    ptrs = (C.c_void_p * 4)(*[a.ctypes.data for a in bn])
+    vad.hip.check(lib.vad_pack_conv3x3(w.ctypes.data, b.ctypes.data, ptrs, cout, cin, out.ctypes.data, bo.ctypes.data))
+    s = bn[0].astype(np.float64) / np.sqrt(bn[3].astype(np.float64) + 1e-5)
+    ref = (w.astype(np.float64) * s[:, None, None, None]).reshape(cout, cin // 8, 8, 9).transpose(3, 1, 0, 2)
+    assert np.array_equal(out.reshape(9, cin // 8, cout, 8), ref.astype(np.float32))
+    assert np.array_equal(bo, ((b.astype(np.float64) - bn[2]) * s + bn[1]).astype(np.float32))
+    # no BN: plain re-ordering
+    vad.hip.check(lib.vad_pack_conv3x3(w.ctypes.data, b.ctypes.data, None, cout, cin, out.ctypes.data, bo.ctypes.data))
+    assert np.array_equal(out.reshape(9, cin // 8, cout, 8), w.reshape(cout, cin // 8, 8, 9).transpose(3, 1, 0, 2))
+    assert np.array_equal(bo, b)
+    # convT: [q][cin/8][cout][8] from IOHW
+    wt = rng.standard_normal((64, 32, 2, 2)).astype(np.float32)
+    ot = np.empty(lib.vad_pack_convt2x2_floats(64, 32), np.float32)
+    bt = np.empty(32, np.float32)
+    vad.hip.check(lib.vad_pack_convt2x2(wt.ctypes.data, b.ctypes.data, None, 64, 32, ot.ctypes.data, bt.ctypes.data))
+    assert np.array_equal(ot.reshape(4, 8, 32, 8), wt.reshape(8, 8, 32, 4).transpose(3, 0, 2, 1))
+
+
+def test_model_pack_consumes_state_dict_in_order(vad):
+    lib = vad.hip.lib()
+    m = vad.ConvAutoencoder(latent_dim=64)
+    load_synthetic(vad, m, 3)
+    params = importlib.import_module("video-anomaly-detection_amd.autoencoder")._HipScorer.float_params(m)
+    assert len(params) == 92
+    blob = np.full(lib.vad_img_packed_floats(3, 64), np.nan, np.float32)
+    vad.hip.check(lib.vad_img_pack(vad.hip.pointer_array(params), 92, 3, 64, blob.ctypes.data))
+    assert np.isfinite(blob).all()
+    assert lib.vad_img_pack(vad.hip.pointer_array(params[:-1]), 91, 3, 64, blob.ctypes.data) == -1
+    v = vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=64, lstm_num_layers=1)
+    load_synthetic(vad, v, 4)
+    vp = importlib.import_module("video-anomaly-detection_amd.autoencoder")._HipScorer.float_params(v)
+    assert len(vp) == lib.vad_vid_nparams(1, 1)
+    vb = np.full(lib.vad_vid_packed_floats(32, 64, 1), np.nan, np.float32)
+    vad.hip.check(lib.vad_vid_pack(vad.hip.pointer_array(vp), len(vp), 32, 64, 1, vb.ctypes.data))
+    assert np.isfinite(vb).all()
+
+
+# ------------------------------------------------------------------------------------------ harness
+def test_synth_is_counter_based(vad):
+    a = vad.synth.frames(5, 10, 4, 3, 16, 16)
+    b = vad.synth.frames(5, 12, 2, 3, 16, 16)
+    assert np.array_equal(a[2:], b) and a.dtype == np.float32 and a.min() >= -1 and a.max() <= 1
+    u8 = vad.synth.frames_u8(0xC0FFEE, 0, 1, 3, 4, 4)
+    assert u8.dtype == np.uint8 and u8[0, 0, 0, :4].tolist() == vad.synth.frames_u8(0xC0FFEE, 0, 1, 3, 4, 4)[0, 0, 0, :4].tolist()
+    assert np.array_equal(vad.synth.clips(9, 1, 2, 3, 3, 8, 8).reshape(6, 3, 8, 8), vad.synth.frames(9, 3, 6, 3, 8, 8))
+    lab = vad.synth.frame_label(1, np.arange(1000))
+    assert 400 < lab.sum() < 600
+    an = vad.synth.frames_u8(1, 0, 8, 3, 64, 64, anomalies=True)
+    for i in range(8):
+        assert ((an[i] == 255).all(axis=0).sum() >= 32 * 32) == bool(lab[i])
+
+
+def test_roc_auc_matches_sklearn(vad):
+    from sklearn.metrics import roc_auc_score
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        y = rng.integers(0, 2, 200)
+        s = np.round(rng.standard_normal(200) + y * 0.7, 1)       # rounding creates ties
+        assert abs(vad.scoring.roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
+    with pytest.raises(ValueError):
+        vad.scoring.roc_auc([1, 1], [0.1, 0.2])
+
+
+def test_compute_auroc_contract(vad):
+    """Same call shape and result tuple as the reference's evaluate.compute_auroc (evaluate.py:46-91)."""
+    class Fake:
+        def get_reconstruction_error(self, images, per_pixel=False):
+            return images.mean(dim=(1, 2, 3))
+    batches = [{"image": torch.full((4, 3, 2, 2), float(i)) + torch.arange(4).view(4, 1, 1, 1), "label": np.array([0, 0, 1, 1]),
+                "defect_type": ["good", "good", "scratch", "spot"]} for i in range(2)]
+    auroc, labels, scores, per = vad.scoring.compute_auroc(Fake(), batches, "cpu")
+    assert labels.tolist() == [0, 0, 1, 1] * 2 and scores.shape == (8,)
+    assert set(per) == {"good", "scratch", "spot"} and per["good"]["count"] == 4 and per["spot"]["is_anomaly"] == 1
+    assert 0.5 < auroc <= 1.0
+
+
+def test_block_partition(vad):
+    bp = vad.scoring.block_partition
+    assert bp(100_000, 8, 0) == (0, 12_500, 12_500) and bp(100_000, 8, 7) == (87_500, 12_500, 12_500)
+    assert bp(10, 4, 3) == (9, 1, 3) and bp(10, 4, 2) == (6, 3, 3) and bp(2, 4, 3) == (2, 0, 1)
+    for n, w in [(1, 1), (7, 3), (64, 8), (65, 8), (3, 8)]:
+        got = [i for r in range(w) for i in range(bp(n, w, r)[0], bp(n, w, r)[0] + bp(n, w, r)[1])]
+        assert got == list(range(n))
