@@ -190,8 +190,12 @@ def main():
                    conv3x3_flops(hw // 8, hw // 8, 128, 128)]
             mf_ms = ms[4] + ms[1] + ms[2] + ms[3]
             mf_launch = cnt[4] + cnt[1] + cnt[2] + cnt[3]
-            mf_flop = step_flop * 2 * frames_rank + sum(enc) * frames_rank
-            layers["convlstm"]["tflops"] = round(step_flop * 2 * frames_rank / (ms[4] * 1e-3) / 1e12, 2) if ms[4] > 0 else None
+            # ConvLSTM FLOPs actually executed: at t = 0 the state is exactly zero and the h half of K is skipped
+            # (the reference multiplies by zeros there), so a clip costs 2 layers x (T - 1/2) full steps.
+            clips_rank = per_gpu * args.steps
+            lstm_flop = step_flop * 2 * (args.clip_len - 0.5) * clips_rank
+            mf_flop = lstm_flop + sum(enc) * frames_rank
+            layers["convlstm"]["tflops"] = round(lstm_flop / (ms[4] * 1e-3) / 1e12, 2) if ms[4] > 0 else None
         ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fp32 32x32x2 MFMA; all launches)",
                     "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",

@@ -109,8 +109,9 @@ class _HipScorer:
 class ConvAutoencoder(nn.Module):
     """Reference `ConvAutoencoder(in_channels=3, latent_dim=256)` (models/autoencoder.py:149-221)."""
 
-    #: frames per launch group; intermediates of one chunk (chunk * 8.4 MB at 256x256) stay cache resident
-    chunk = 32
+    #: frames per launch group (workspace = 2 x chunk x 8.4 MB at 256x256); large enough that every layer launches
+    #: several work-groups per resident slot
+    chunk = 128
 
     def __init__(self, in_channels: int = 3, latent_dim: int = 256):
         super().__init__()

@@ -124,7 +124,7 @@ class VideoAutoencoder(nn.Module):
     (models/video_autoencoder.py:279-384)."""
 
     #: clips per launch group
-    chunk = 16
+    chunk = 64
 
     def __init__(self, in_channels: int = 3, latent_dim: int = 128, lstm_hidden_dim: int = 128,
                  lstm_num_layers: int = 2):
