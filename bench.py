@@ -197,9 +197,16 @@ def main():
             mf_flop = lstm_flop + sum(enc) * frames_rank
             layers["convlstm"]["tflops"] = round(lstm_flop / (ms[4] * 1e-3) / 1e12, 2) if ms[4] > 0 else None
         ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+        # (tools/pmc_traffic.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); only valid for the default shape.
+        traffic = None
+        pmc = REPO / "profiles" / f"r01_pmc_traffic_{args.workload}.json"
+        if pmc.exists() and hw == 256 and not args.batch and int(model.chunk) == (128 if args.workload == "image" else 64):
+            traffic = round(json.loads(pmc.read_text())["traffic_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fp32 32x32x2 MFMA; all launches)",
                     "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_flop_per_launch": round(mf_flop / max(mf_launch, 1)),
                     "avg_launch_ms": round(mf_ms / max(mf_launch, 1), 4), "launches": mf_launch,
                     "whole_path_tflops": round(fps / world * flop_per_frame / 1e12, 2),
                     "whole_path_hbm_gbs": round(fps / world * bytes_per_frame / 1e9, 1),
