@@ -219,12 +219,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
 
     while (true) {
         f32x16 acc[MT][NT];
+        if constexpr (!FUSE_C3) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
+        }
 
         const int nn = n + fgroups;
         const bool has_next = nn < p.n;
@@ -247,44 +249,65 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
                 STAMP(7);
                 // Fused first layer: Conv2d(3->32)+BN+LeakyReLU of the tile AND its halo, K = 27 padded to 28
                 // (14 MFMAs per 32 pixels), written straight into the LDS tile the 32->32 convolution reads.
-                for (int t = wave; t < NT0; t += 4) {
-                    const int q = t * 32 + li, qc = q < NPIX ? q : NPIX - 1;
-                    const int abase0 = (qc / LW) * XS + (qc % LW);
-                    f32x16 c0;
+                // Each wave owns M-tiles wave, wave+4, wave+8 of the halo tile and runs their 14-step chains
+                // INTERLEAVED (independent accumulators) at raised priority: a single dependent chain on a pipe
+                // shared with another work-group's main loop advances one MFMA per two pipe slots.
+                constexpr int TPW = (NT0 + 3) / 4;
+                f32x16 c0[TPW];
+                float av[TPW][14];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) c0[r] = bias0;
-                    float av[14];   // all 14 gathered A values first (hipcc otherwise waits on each ds_read before its MFMA)
+                for (int u = 0; u < TPW; ++u) {
+                    const int q = (wave + 4 * u) * 32 + li, qc = q < NPIX ? q : NPIX - 1;
+                    const int abase0 = (qc / LW) * XS + (qc % LW);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c0[u][r] = bias0;
 #pragma unroll
                     for (int s0 = 0; s0 < 14; ++s0) {
                         const int k0 = 2 * s0, k1 = 2 * s0 + 1;
                         const int o0 = ((k0 / 9) * XH + (k0 % 9) / 3) * XS + (k0 % 3);
                         const int o1 = (k1 < 27) ? ((k1 / 9) * XH + (k1 % 9) / 3) * XS + (k1 % 3) : 0;
-                        av[s0] = xin[abase0 + (lh ? o1 : o0)];
+                        av[u][s0] = xin[abase0 + (lh ? o1 : o0)];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int s0 = 0; s0 < 14; ++s0) c0 = MFMA32(av[s0], b0w[s0], c0);
-                    // straight-line stores (the tile is padded to NT0*32 pixels); only border tiles need the
-                    // per-pixel inside test that provides conv #2's zero padding
-                    const int qb = (t * 32 + 4 * lh) * PS + li;
-                    if (interior) {
+                for (int s0 = 0; s0 < 14; ++s0)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = vad_act(c0[r], VAD_ACT_LEAKY);
-                    } else {
+                    for (int u = 0; u < TPW; ++u) c0[u] = MFMA32(av[u][s0], b0w[s0], c0[u]);
+                __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int q2 = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            const int ly2 = q2 / LW, lx2 = q2 - ly2 * LW;
-                            const bool inside = (unsigned)(y0 - 1 + ly2) < (unsigned)H && (unsigned)(x0 - 1 + lx2) < (unsigned)W;
-                            const float v = vad_act(c0[r], VAD_ACT_LEAKY);
-                            tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = inside ? v : 0.f;
+                for (int u = 0; u < TPW; ++u) {
+                    const int t = wave + 4 * u;
+                    if (t < NT0) {   // wave-uniform
+                        // straight-line stores (the tile is padded to NT0*32 pixels); only border tiles need the
+                        // per-pixel inside test that provides conv #2's zero padding
+                        const int qb = (t * 32 + 4 * lh) * PS + li;
+                        if (interior) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = vad_act(c0[u][r], VAD_ACT_LEAKY);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int q2 = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                const int ly2 = q2 / LW, lx2 = q2 - ly2 * LW;
+                                const bool inside = (unsigned)(y0 - 1 + ly2) < (unsigned)H && (unsigned)(x0 - 1 + lx2) < (unsigned)W;
+                                const float v = vad_act(c0[u][r], VAD_ACT_LEAKY);
+                                tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = inside ? v : 0.f;
+                            }
                         }
                     }
                 }
                 STAMP(8);
                 __syncthreads();
                 STAMP(9);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)     // accumulators start after the fused stage: its registers are dead now
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
             } else {
 #pragma unroll
                 for (int i = 0; i < NPF; ++i)
