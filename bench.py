@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--clip-len", type=int, default=10)
     ap.add_argument("--no-layer-events", action="store_true", help="do not bracket layers with hipEvents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tail-group", type=int, default=0, help="frames per dec4.0 -> tail sub-group (0 = auto)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,19 +82,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the scoring path has no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     vad = importlib.import_module("video-anomaly-detection_amd")
     hip = vad.hip
     lib = hip.lib()
     hw = args.size
     scale = (hw * hw) / 65536.0
+    if args.tail_group:
+        lib.vad_debug_set_tail_group(args.tail_group)
 
     def synth_load(module, seed):
         shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}

@@ -156,6 +156,8 @@ int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, 
 /* Developer switch for A/B timing in one process: 0 = one tile per work-group, 1 = persistent work-groups with
  * register prefetch of the next stage (default).  Results are bit-identical. */
 int vad_debug_set_conv_variant(int variant);
+/* Frames per dec4.0 -> scoring-tail sub-group inside vad_img_score (0 = whole launch group). */
+int vad_debug_set_tail_group(int frames);
 
 /* ------------------------------------------------------------------ per-layer timing
  * When enabled, the model-level calls bracket every layer launch with hipEvents on `stream`.

@@ -65,6 +65,9 @@ extern "C" const char* vad_prof_slot_name(int model, int slot) {
 
 #define TRY(call) do { int rc_ = (call); if (rc_ != VAD_OK) return rc_; } while (0)
 
+int g_vad_tail_group = 0;   // frames per dec4.0 -> tail sub-group (0 = the whole launch group)
+extern "C" int vad_debug_set_tail_group(int frames) { g_vad_tail_group = frames; return VAD_OK; }
+
 static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ------------------------------------------------------------------------------ image model
@@ -127,19 +130,28 @@ extern "C" int vad_img_score(const float* x, long long b, int h, int w, int late
         }
         if (!need_decoder) continue;
         // decoder: 3 x [convT-BN-ReLU, conv-BN-ReLU] + [convT-BN-ReLU, conv-Tanh] (models/autoencoder.py:103-139)
-        for (int blk = 0; blk < 4; ++blk) {
+        for (int blk = 0; blk < 3; ++blk) {
             { VadProfScope ps(8 + 2 * blk, s);
               TRY(vad_convt2x2(B, 0, W_(8 + 2 * blk), B_(8 + 2 * blk), A, 0, n, hh, ww, dch[blk], dch[blk + 1], VAD_ACT_RELU, s)); }
             hh *= 2; ww *= 2;
-            if (blk < 3) {
-                VadProfScope ps(9 + 2 * blk, s);
-                TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, s));
-            }
+            { VadProfScope ps(9 + 2 * blk, s);
+              TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, s)); }
         }
-        { VadProfScope ps(15, s);
-          TRY(vad_conv3x3_to3_score(A, W_(15), B_(15), xin, parts,
-                                    recon ? recon + (size_t)f0 * 3 * h * w : nullptr,
-                                    errmap ? errmap + (size_t)f0 * h * w : nullptr, n, h, w, 32, s)); }
+        // dec4.0 (convT 32->32, writes 8.4 MB per 256x256 frame) and the scoring tail that reads it back can run in
+        // sub-groups (vad_debug_set_tail_group) so that map stays in the 256 MiB Infinity Cache; measured on MI355X
+        // this does NOT pay (15.2 k frames/s whole group vs 14.9 k at 16 frames), so the default is the whole group.
+        const size_t in_f = (size_t)hh * ww * 32;
+        const int sub = g_vad_tail_group > 0 ? g_vad_tail_group : n;
+        for (int f1 = 0; f1 < n; f1 += sub) {
+            const int m = (n - f1 < sub) ? (n - f1) : sub;
+            { VadProfScope ps(14, s);
+              TRY(vad_convt2x2(B + (size_t)f1 * in_f, 0, W_(14), B_(14), A, 0, m, hh, ww, 32, 32, VAD_ACT_RELU, s)); }
+            { VadProfScope ps(15, s);
+              const size_t fo = (size_t)(f0 + f1);
+              TRY(vad_conv3x3_to3_score(A, W_(15), B_(15), xin + (size_t)f1 * 3 * h * w, parts + (size_t)f1 * nparts,
+                                        recon ? recon + fo * 3 * h * w : nullptr,
+                                        errmap ? errmap + fo * h * w : nullptr, m, h, w, 32, s)); }
+        }
         if (scores) {
             VadProfScope ps(16, s);
             TRY(vad_score_finalize(parts, nparts, n, h, w, scores + f0, nullptr, 1, s));

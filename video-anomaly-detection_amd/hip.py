@@ -90,6 +90,7 @@ SIGNATURES = {
     "vad_vid_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_debug_set_conv_variant": (_i, [_i]),
+    "vad_debug_set_tail_group": (_i, [_i]),
     "vad_prof_enable": (_i, [_i]),
     "vad_prof_reset": (_i, []),
     "vad_prof_read": (_i, [_vp, _vp]),
