@@ -63,7 +63,7 @@ constexpr unsigned VAD_OOB = 0x80000000u;   // byte offset no frame reaches (hos
 #endif
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
+__global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
     static_assert(WM * WN == 4, "4 waves per work-group");
     static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
     static_assert(!FUSE_C3 || CK == 32, "fused first layer produces exactly one 32-channel chunk");
@@ -71,12 +71,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
     constexpr int TH = 2 * MT * WM, LH = TH + 2, LW = 18, PS = CK + 4;
     // FUSE_C3: the staged data are the 3 NCHW input planes of the tile with a 2-pixel halo (scalar floats);
     // otherwise float4 channel quads of the NHWC tile with a 1-pixel halo.
-    constexpr int XH = LH + 2, XW = 20, XS = 24;
+    constexpr int XH = LH + 2, XW = 20, XS = 20;
     constexpr int NPIX = LH * LW, NT0 = (NPIX + 31) / 32;
     constexpr int TOT = FUSE_C3 ? 3 * XH * XW : NPIX * (CK / 4), NPF = (TOT + 255) / 256;
     constexpr int NS = 9 * (CK / 8);
     static_assert(NS % 2 == 0, "double-buffer parity must be the same in every chunk");
-    __shared__ __attribute__((aligned(16))) float tile[(FUSE_C3 ? NT0 * 32 : NPIX) * PS];
+    __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
     __shared__ float xin[FUSE_C3 ? 3 * XH * XS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
                         // straight-line stores (the tile is padded to NT0*32 pixels); only border tiles need the
                         // per-pixel inside test that provides conv #2's zero padding
                         const int qb = (t * 32 + 4 * lh) * PS + li;
-                        if (interior) {
+                        if (interior && t < NT0 - 1) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
                                 tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = vad_act(c0[u][r], VAD_ACT_LEAKY);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_pkernel(Conv3P p) {
                                 const int ly2 = q2 / LW, lx2 = q2 - ly2 * LW;
                                 const bool inside = (unsigned)(y0 - 1 + ly2) < (unsigned)H && (unsigned)(x0 - 1 + lx2) < (unsigned)W;
                                 const float v = vad_act(c0[u][r], VAD_ACT_LEAKY);
-                                tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = inside ? v : 0.f;
+                                if (q2 < NPIX) tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = inside ? v : 0.f;
                             }
                         }
                     }
