@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["image", "video"], default="image")
+    ap.add_argument("--workload", choices=["image", "video", "dense"], default="image")
+    ap.add_argument("--stride", type=int, default=1, help="dense workload: window stride")
     ap.add_argument("--batch", type=int, default=0, help="frames (image) or clips (video) per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="frames/clips per launch group (0 = model default)")
     ap.add_argument("--size", type=int, default=256)
@@ -125,6 +126,26 @@ def main():
             return model.get_reconstruction_error(x)
         width = 1
         workload = f"configs[1]: image autoencoder scoring, batch {per_gpu} synthetic {hw}x{hw}x3 frames per GPU"
+    elif args.workload == "dense":
+        # Row f-2: dense sliding windows over ONE video per GPU (reference evaluate_video.py:322-352 with
+        # sequence_length T, stride): per_gpu windows, every frame encoded once.
+        per_gpu = args.batch or 512
+        t = args.clip_len if args.clip_len != 10 else 16
+        nfr = (per_gpu - 1) * args.stride + t
+        model = vad.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)
+        state = synth_load(model, 8)
+        model = model.to(dev).eval()
+        if args.chunk:
+            model.window_chunk = args.chunk
+        x = vad.scoring.synth_frames_device(seed, rank * nfr, nfr, hw, hw, device=dev)
+        frames_per_step = per_gpu * t
+        flop_per_frame, bytes_per_frame = VID_FLOP_PER_FRAME * scale, VID_BYTES_PER_FRAME * scale
+
+        def score_block(first, count):
+            return model.score_windows(x, sequence_length=t, stride=args.stride)["frame"]
+        width = t
+        workload = (f"row f-2: dense sliding windows, {per_gpu} windows of {t} frames (stride {args.stride}) over one "
+                    f"{nfr}-frame {hw}x{hw}x3 video per GPU; value counts window-frames (windows x T)")
     else:
         per_gpu = args.batch or 64
         t = args.clip_len
@@ -203,8 +224,10 @@ def main():
             # ConvLSTM FLOPs actually executed: at t = 0 the state is exactly zero and the h half of K is skipped
             # (the reference multiplies by zeros there), so a clip costs 2 layers x (T - 1/2) full steps.
             clips_rank = per_gpu * args.steps
-            lstm_flop = step_flop * 2 * (args.clip_len - 0.5) * clips_rank
-            mf_flop = lstm_flop + sum(enc) * frames_rank
+            lstm_flop = step_flop * 2 * (t - 0.5) * clips_rank
+            # frames that pass through the encoder: every (clip, t) frame, or each source frame once for dense windows
+            enc_frames = ((per_gpu - 1) * args.stride + t) * args.steps if args.workload == "dense" else frames_rank
+            mf_flop = lstm_flop + sum(enc) * enc_frames
             layers["convlstm"]["tflops"] = round(lstm_flop / (ms[4] * 1e-3) / 1e12, 2) if ms[4] > 0 else None
         ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
@@ -227,7 +250,8 @@ def main():
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "frames_per_gpu_per_step": frames_per_step, "chunk": int(model.chunk),
+        "config": {"workload": workload, "frames_per_gpu_per_step": frames_per_step,
+                   "chunk": int(model.window_chunk if args.workload == "dense" else model.chunk),
                    "weights": "deterministic synthetic state dict (Xavier scale, randomised BN)",
                    "collective": "one all_gather of the score vector per step" if world > 1 else "none (1 GPU)"},
         "frames_per_sec_per_gpu": round(fps / world, 1),
@@ -236,7 +260,9 @@ def main():
     if layers is not None:
         out["layers"] = layers
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if args.workload == "dense":
+        out["unique_frames_per_sec"] = round(((per_gpu - 1) * args.stride + t) * world * args.steps / elapsed, 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "dense":
         out["cpu_baseline"] = cpu_baseline(vad, state, args, scores, seed, hw)
     if rank == 0:
         print(json.dumps(out))

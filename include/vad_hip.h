@@ -108,10 +108,12 @@ int vad_conv3x3_to3_score(const float* in_nhwc, const float* w_packed /*vad_pack
                           float* recon_nchw, float* errmap, int n, int h2, int w2, int cin,
                           void* stream);
 /* ConvTranspose2d(32->3) k2 s2 + Tanh (models/video_autoencoder.py:259-260) on NHWC [N,H,W,32]. */
+/* t, clip_stride: activation frame n is scored against x frame (n / t) * clip_stride + n % t (sliding windows
+ * over one video); t == 0 or t == clip_stride means frame n (independent clips). */
 int vad_convt2x2_to3_score(const float* in_nhwc, const float* w_iohw /*[cin][3][2][2]*/,
                            const float* bias3, const float* x_nchw, float* partials,
                            float* recon_nchw, float* errmap, int n, int h, int w, int cin,
-                           void* stream);
+                           int t, int clip_stride, void* stream);
 /* frame_scores[N] = sum(partials[n][:]) / (3*H2*W2) in a fixed order (bit-exact under any
  * batching); if seq_scores != NULL also seq_scores[N/t] = mean over t consecutive frames. */
 int vad_score_finalize(const float* partials, int nparts, int n, int h2, int w2,
@@ -158,6 +160,17 @@ int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, 
 int vad_debug_set_conv_variant(int variant);
 /* Frames per dec4.0 -> scoring-tail sub-group inside vad_img_score (0 = whole launch group). */
 int vad_debug_set_tail_group(int frames);
+
+/* Dense sliding-window scoring of ONE video: window k = frames [k*stride, k*stride + T), 0 < stride <= T,
+ * vad_vid_num_windows(F, T, stride) = (F - T) / stride + 1 windows.  Same results as scoring every window as its own
+ * clip with vad_vid_score (what the reference does: evaluate_video.py:322-352 builds VideoFileDataset(sequence_length,
+ * stride=1) and runs 3 forwards per window), but every frame is encoded once instead of once per window containing it.
+ * frames [F,3,H,W].  Outputs (any may be NULL): seq [NW]; frame [NW,T]; errmap [NW,T,H,W]; recon [NW,T,3,H,W]. */
+long long vad_vid_num_windows(long long frames, int t, int stride);
+size_t vad_vid_windows_workspace_bytes(int chunk_windows, int t, int stride, int h, int w, int latent, int hid, int layers);
+int vad_vid_score_windows(const float* frames, long long nframes, int t, int stride, int h, int w, int latent, int hid,
+                          int layers, const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_windows,
+                          float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
 
 /* ------------------------------------------------------------------ per-layer timing
  * When enabled, the model-level calls bracket every layer launch with hipEvents on `stream`.

@@ -163,6 +163,28 @@ def test_video_causal_and_clip_independent(vad):
     assert torch.equal(base[2:3], solo) and torch.equal(base, chunked)
 
 
+@pytest.mark.parametrize("t,stride,chunk", [(4, 1, 64), (6, 3, 2), (5, 5, 3)])
+def test_video_dense_windows_equal_per_window_clips(vad, t, stride, chunk):
+    """Row f-2: sliding windows over one video with the encoder shared between overlapping windows give bit-identical
+    scores / maps / reconstructions to scoring every window as its own clip (reference evaluate_video.py:322-352)."""
+    m, st = _vid_model(vad, 64, 64, 2, 6)
+    f = 17
+    frames = torch.from_numpy(vad.synth.frames(99, 0, f, 3, 32, 48)).cuda()
+    nw = (f - t) // stride + 1
+    clips = torch.stack([frames[k * stride:k * stride + t] for k in range(nw)])
+    with torch.no_grad():
+        ref = m.score_all(clips)
+        m.window_chunk = chunk
+        got = m.score_windows(frames, sequence_length=t, stride=stride, errmap=True, recon=True)
+    assert got["seq"].shape == (nw,) and got["frame"].shape == (nw, t)
+    for k in ("seq", "frame", "errmap", "recon"):
+        assert torch.equal(got[k], ref[k]), k
+    o = torch_oracle.vid_scores({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, clips[-1:].cpu(), 64, 2)
+    assert rel_err(got["frame"][-1:].cpu().numpy(), o["frame"].numpy()) < SCORE_RTOL
+    with torch.no_grad(), pytest.raises(vad.hip.VadError):
+        m.score_windows(frames[:3], sequence_length=4)
+
+
 def test_video_fresh_inputs_vs_oracle(vad):
     m, st = _vid_model(vad, 128, 128, 2, 43)
     x = vad.synth.clips(321, 3, 2, 5, 3, 48, 64)

@@ -75,7 +75,7 @@ def run(kind, n, h, w, cin, cout, pool, iters, warm=3):
         nparts = l.vad_score_partials(1, 2 * h, 2 * w)
         parts = torch.empty(n * nparts, device="cuda")
         fn = lambda: l.vad_convt2x2_to3_score(x.data_ptr(), wt.data_ptr(), b.data_ptr(), img.data_ptr(), parts.data_ptr(),
-                                              None, None, n, h, w, 32, s)
+                                              None, None, n, h, w, 32, 0, 0, s)
         flop = 2.0 * n * h * w * 4 * 32 * 3
         byts = 4.0 * (x.numel() + img.numel())
     else:

@@ -18,6 +18,7 @@ struct TailP {
     float* errmap;        // [N,H2,W2] or NULL
     int h, w_;            // spatial size of `in`
     int tiles_x, tiles_y;
+    int xt, xs;           // x frame of activation frame n is (n / xt) * xs + n % xt (xt == 0: n)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
     const int ty = L % p.tiles_y;
     const int n = L / p.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
+    const int nx = p.xt ? (n / p.xt) * p.xs + n % p.xt : n;   // source frame this activation frame is scored against
     const float* src = p.in + (size_t)n * p.h * p.w_ * CIN;
     for (int idx = tid; idx < TH * TW * (CIN / 4); idx += 256) {
         const int c4 = idx % (CIN / 4), pix = idx / (CIN / 4);
@@ -223,9 +225,10 @@ __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
         for (int a = 0; a < 2; ++a) {
             float ea[2] = {0.f, 0.f};
             const size_t o = (size_t)n * 3 * plane + (size_t)(2 * y + a) * w2 + 2 * x;
+            const size_t ox = (size_t)nx * 3 * plane + (size_t)(2 * y + a) * w2 + 2 * x;
 #pragma unroll
             for (int co = 0; co < 3; ++co) {
-                const float2 xv = *(const float2*)(p.x + o + co * plane);
+                const float2 xv = *(const float2*)(p.x + ox + co * plane);
                 const float r0 = tanhf(acc[co * 4 + a * 2 + 0]), r1 = tanhf(acc[co * 4 + a * 2 + 1]);
                 const float d0 = xv.x - r0, d1 = xv.y - r1;
                 ea[0] += d0 * d0;
@@ -270,7 +273,7 @@ extern "C" int vad_conv3x3_to3_score(const float* in, const float* w_packed, con
     VAD_REQUIRE(in && w_packed && bias3 && x && partials, "conv3x3_to3_score: null pointer");
     VAD_REQUIRE(cin == 32, "conv3x3_to3_score: cin=%d unsupported (the reference's dec4.3 has 32)", cin);
     VAD_REQUIRE(n > 0 && h2 > 0 && w2 > 0 && w2 % 16 == 0, "conv3x3_to3_score: bad shape (W=%d must be a positive multiple of 16)", w2);
-    TailP p{in, w_packed, bias3, x, partials, recon, errmap, h2, w2, (w2 + TAIL_T - 1) / TAIL_T, (h2 + TAIL_T - 1) / TAIL_T};
+    TailP p{in, w_packed, bias3, x, partials, recon, errmap, h2, w2, (w2 + TAIL_T - 1) / TAIL_T, (h2 + TAIL_T - 1) / TAIL_T, 0, 0};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_to3_score: grid too large");
     hipLaunchKernelGGL(conv3x3_to3_score_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
@@ -280,11 +283,12 @@ extern "C" int vad_conv3x3_to3_score(const float* in, const float* w_packed, con
 
 extern "C" int vad_convt2x2_to3_score(const float* in, const float* w_iohw, const float* bias3,
                                       const float* x, float* partials, float* recon, float* errmap,
-                                      int n, int h, int w, int cin, void* stream) {
+                                      int n, int h, int w, int cin, int t, int clip_stride, void* stream) {
     VAD_REQUIRE(in && w_iohw && bias3 && x && partials, "convt2x2_to3_score: null pointer");
     VAD_REQUIRE(cin == 32, "convt2x2_to3_score: cin=%d unsupported (the reference's decoder.9 has 32)", cin);
     VAD_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_to3_score: bad shape");
-    TailP p{in, w_iohw, bias3, x, partials, recon, errmap, h, w, (w + 31) / 32, (h + 7) / 8};
+    VAD_REQUIRE(t >= 0 && clip_stride >= 0 && (t == 0 || clip_stride > 0), "convt2x2_to3_score: bad window mapping");
+    TailP p{in, w_iohw, bias3, x, partials, recon, errmap, h, w, (w + 31) / 32, (h + 7) / 8, (t == clip_stride) ? 0 : t, clip_stride};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "convt2x2_to3_score: grid too large");
     hipLaunchKernelGGL((convt2x2_to3_score_kernel<32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);

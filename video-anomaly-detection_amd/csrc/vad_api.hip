@@ -163,44 +163,37 @@ extern "C" int vad_img_score(const float* x, long long b, int h, int w, int late
 }
 
 // ------------------------------------------------------------------------------ video model
+// One code path serves both clip batches and dense sliding windows: "clip" c covers source frames
+// [c*cs, c*cs + T).  cs == T: independent clips [B,T,...] (evaluate_video.py:138-154).  cs == stride < T:
+// overlapping windows of ONE video (evaluate_video.py:322-352, VideoFileDataset(sequence_length, stride)); every
+// source frame is then encoded ONCE instead of once per window that contains it, and the ConvLSTM reads window
+// c's frame t straight from that shared feature buffer (its state still restarts from zero per window, as in
+// models/video_autoencoder.py:144-145).
 namespace {
 struct VidWs {
     size_t act, enc, hseq, cst, proj, parts, total;
 };
-VidWs vid_ws(int chunk, int t, int h, int w, int latent, int hid, int layers) {
+VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent, int hid, int layers) {
     VidWs z{};
-    const size_t n = (size_t)chunk * t, p16 = (size_t)(h / 16) * (w / 16);
-    z.act = up256(sizeof(float) * n * (size_t)h * w * 8);          // [n, H/2, W/2, 32]
-    z.enc = up256(sizeof(float) * n * p16 * latent);
+    const size_t n = (size_t)chunk * t, nf = (size_t)(chunk - 1) * cs + t, p16 = (size_t)(h / 16) * (w / 16);
+    const size_t nmax = n > nf ? n : nf;
+    z.act = up256(sizeof(float) * nmax * (size_t)h * w * 8);       // [frames, H/2, W/2, 32]
+    z.enc = up256(sizeof(float) * nf * p16 * latent);
     z.hseq = up256(sizeof(float) * n * p16 * hid);
     z.cst = up256(sizeof(float) * (size_t)chunk * p16 * hid);
-    z.proj = (hid != latent) ? z.enc : 0;
+    z.proj = (hid != latent) ? up256(sizeof(float) * n * p16 * latent) : 0;
     z.parts = up256(sizeof(float) * n * (size_t)vad_score_partials(1, h, w));
     z.total = 2 * z.act + z.enc + (layers > 1 ? 2 : 1) * z.hseq + z.cst + z.proj + z.parts;
     return z;
 }
-}  // namespace
 
-extern "C" size_t vad_vid_workspace_bytes(int chunk, int t, int h, int w, int latent, int hid, int layers) {
-    if (chunk <= 0 || t <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16) return 0;
-    if (vad_vid_packed_floats(latent, hid, layers) == 0) return 0;
-    return vid_ws(chunk, t, h, w, latent, hid, layers).total;
-}
-
-extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
-                             const float* packed, void* ws, size_t ws_bytes, int chunk,
-                             float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
-    VAD_REQUIRE(x && packed && ws, "vid_score: null pointer");
-    VAD_REQUIRE(b > 0 && t > 0 && chunk > 0, "vid_score: clips=%lld T=%d chunk=%d must be positive", b, t, chunk);
-    VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
-                "vid_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
-    if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;   // message already set
-    VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score: no output requested");
-    const VidWs Z = vid_ws(chunk, t, h, w, latent, hid, layers);
-    if (ws_bytes < Z.total) return vad_fail(VAD_ERR_WS, "vid_score: workspace %zu B < required %zu B", ws_bytes, Z.total);
-    VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "vid_score: workspace must be 256-B and weights 16-B aligned");
-
-    hipStream_t s = (hipStream_t)stream;
+// clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
+int vid_run(const float* x, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
+            const float* packed, void* ws, size_t ws_bytes, int chunk, float* seq_scores, float* frame_scores,
+            float* errmap, float* recon, hipStream_t s, const char* who) {
+    const VidWs Z = vid_ws(chunk, t, cs, h, w, latent, hid, layers);
+    if (ws_bytes < Z.total) return vad_fail(VAD_ERR_WS, "%s: workspace %zu B < required %zu B", who, ws_bytes, Z.total);
+    VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "%s: workspace must be 256-B and weights 16-B aligned", who);
     const VidLayout L = vid_layout(latent, hid, layers);
     char* base = (char*)ws;
     float* A = (float*)base; base += Z.act;
@@ -220,25 +213,27 @@ extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, i
 #define W_(i) (packed + L.layer[i].w)
 #define B_(i) (packed + L.layer[i].b)
 
-    for (long long c0 = 0; c0 < b; c0 += chunk) {
-        const int nc = (int)((b - c0 < chunk) ? (b - c0) : chunk);
-        const int n = nc * t;
-        const float* xin = x + (size_t)c0 * t * 3 * h * w;
-        // VideoEncoder: 4 x conv-BN-LeakyReLU-MaxPool on the B*T flattened frames
+    for (long long c0 = 0; c0 < nclips; c0 += chunk) {
+        const int nc = (int)((nclips - c0 < chunk) ? (nclips - c0) : chunk);
+        const int n = nc * t;                       // (clip, t) frames that are decoded and scored
+        const int nf = (nc - 1) * cs + t;           // distinct source frames that are encoded
+        const float* xin = x + (size_t)c0 * cs * 3 * h * w;
+        // VideoEncoder: 4 x conv-BN-LeakyReLU-MaxPool on the flattened frames
         // (models/video_autoencoder.py:191-215, :222-228)
-        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3(xin, W_(0), B_(0), A, n, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
-        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, n, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, s)); }
-        { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, n, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, s)); }
-        { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, n, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3(xin, W_(0), B_(0), A, nf, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, s)); }
         // ConvLSTM: layers outer, time inner, zero initial state (models/video_autoencoder.py:144-166)
         for (int l = 0; l < layers; ++l) {
             const float* xin_l = (l == 0) ? E : HS[(l - 1) & 1];
             const long long fs_in = (l == 0) ? fs_lat : fs_hid;
+            const long long clip_in = (l == 0) ? (long long)cs * fs_lat : (long long)t * fs_hid;   // layer 0 reads the shared features
             const int cin_x = (l == 0) ? latent : hid;
             float* hs = HS[l & 1];
             for (int ti = 0; ti < t; ++ti) {
                 VadProfScope ps(4, s);
-                TRY(vad_convlstm_step(xin_l + (size_t)ti * fs_in, (long long)t * fs_in,
+                TRY(vad_convlstm_step(xin_l + (size_t)ti * fs_in, clip_in,
                                       ti ? hs + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
                                       ti ? C : nullptr, W_(4 + l), B_(4 + l),
                                       hs + (size_t)ti * fs_hid, (long long)t * fs_hid, C,
@@ -260,7 +255,8 @@ extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, i
         { VadProfScope ps(9, s);
           TRY(vad_convt2x2_to3_score(A, W_(li + 3), B_(li + 3), xin, parts,
                                      recon ? recon + (size_t)c0 * t * 3 * h * w : nullptr,
-                                     errmap ? errmap + (size_t)c0 * t * h * w : nullptr, n, h / 2, w / 2, 32, s)); }
+                                     errmap ? errmap + (size_t)c0 * t * h * w : nullptr, n, h / 2, w / 2, 32,
+                                     t, cs, s)); }
         if (seq_scores || frame_scores) {
             VadProfScope ps(10, s);
             TRY(vad_score_finalize(parts, nparts, n, h, w, frame_scores ? frame_scores + (size_t)c0 * t : nullptr,
@@ -270,4 +266,49 @@ extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, i
 #undef W_
 #undef B_
     return VAD_OK;
+}
+}  // namespace
+
+extern "C" size_t vad_vid_workspace_bytes(int chunk, int t, int h, int w, int latent, int hid, int layers) {
+    if (chunk <= 0 || t <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16) return 0;
+    if (vad_vid_packed_floats(latent, hid, layers) == 0) return 0;
+    return vid_ws(chunk, t, t, h, w, latent, hid, layers).total;
+}
+
+extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
+                             const float* packed, void* ws, size_t ws_bytes, int chunk,
+                             float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
+    VAD_REQUIRE(x && packed && ws, "vid_score: null pointer");
+    VAD_REQUIRE(b > 0 && t > 0 && chunk > 0, "vid_score: clips=%lld T=%d chunk=%d must be positive", b, t, chunk);
+    VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
+                "vid_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
+    if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;   // message already set
+    VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score: no output requested");
+    return vid_run(x, b, t, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap,
+                   recon, (hipStream_t)stream, "vid_score");
+}
+
+extern "C" long long vad_vid_num_windows(long long frames, int t, int stride) {
+    if (frames < t || t <= 0 || stride <= 0) return 0;
+    return (frames - t) / stride + 1;
+}
+
+extern "C" size_t vad_vid_windows_workspace_bytes(int chunk, int t, int stride, int h, int w, int latent, int hid, int layers) {
+    if (chunk <= 0 || t <= 0 || stride <= 0 || stride > t || h <= 0 || w <= 0 || h % 16 || w % 16) return 0;
+    if (vad_vid_packed_floats(latent, hid, layers) == 0) return 0;
+    return vid_ws(chunk, t, stride, h, w, latent, hid, layers).total;
+}
+
+extern "C" int vad_vid_score_windows(const float* frames, long long nframes, int t, int stride, int h, int w,
+                                     int latent, int hid, int layers, const float* packed, void* ws, size_t ws_bytes,
+                                     int chunk, float* seq_scores, float* frame_scores, float* errmap, float* recon,
+                                     void* stream) {
+    VAD_REQUIRE(frames && packed && ws, "vid_score_windows: null pointer");
+    VAD_REQUIRE(t > 0 && stride > 0 && stride <= t && chunk > 0, "vid_score_windows: need 0 < stride <= T (got T=%d stride=%d) and chunk > 0", t, stride);
+    VAD_REQUIRE(nframes >= t, "vid_score_windows: %lld frames are fewer than one window of %d", nframes, t);
+    VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0, "vid_score_windows: H=%d W=%d must be positive multiples of 16", h, w);
+    if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;
+    VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score_windows: no output requested");
+    return vid_run(frames, vad_vid_num_windows(nframes, t, stride), t, stride, h, w, latent, hid, layers, packed, ws,
+                   ws_bytes, chunk, seq_scores, frame_scores, errmap, recon, (hipStream_t)stream, "vid_score_windows");
 }

@@ -75,7 +75,7 @@ SIGNATURES = {
     "vad_convlstm_step": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
     "vad_score_partials": (_i, [_i, _i, _i]),
     "vad_conv3x3_to3_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "vad_convt2x2_to3_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_convt2x2_to3_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_score_finalize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "vad_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -91,6 +91,9 @@ SIGNATURES = {
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_debug_set_conv_variant": (_i, [_i]),
     "vad_debug_set_tail_group": (_i, [_i]),
+    "vad_vid_num_windows": (_ll, [_ll, _i, _i]),
+    "vad_vid_windows_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "vad_vid_score_windows": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_prof_enable": (_i, [_i]),
     "vad_prof_reset": (_i, []),
     "vad_prof_read": (_i, [_vp, _vp]),

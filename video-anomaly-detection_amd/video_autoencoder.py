@@ -231,6 +231,51 @@ class VideoAutoencoder(nn.Module):
             return error.mean(dim=[2, 3, 4])
         return error.mean(dim=[1, 2, 3, 4])
 
+    #: windows per launch group of `score_windows`
+    window_chunk = 64
+
+    def score_windows(self, frames: torch.Tensor, sequence_length: int = 16, stride: int = 1,
+                      errmap: bool = False, recon: bool = False):
+        """Dense sliding-window scoring of ONE video `frames [F,3,H,W]`: window k = frames[k*stride : k*stride+T].
+        Returns {'seq': [NW], 'frame': [NW,T]} (+ 'errmap' [NW,T,1,H,W], 'recon' [NW,T,3,H,W] on request), identical
+        to calling `get_reconstruction_error` on every window as its own clip — which is what the reference's
+        `generate_video_output` does with batch size 1 and three forwards per window (evaluate_video.py:322-352) —
+        but each frame goes through the encoder once instead of once per window that contains it."""
+        if not self._use_hip():
+            raise hip.VadError("score_windows is an inference entry point: call under eval() and torch.no_grad()")
+        if frames.dim() != 4 or frames.shape[1] != 3:
+            raise hip.VadError(f"expected frames [F,3,H,W], got {tuple(frames.shape)}")
+        if not frames.is_cuda:
+            raise hip.VadError("score_windows runs only on the MI355X HIP path (there is no CPU fallback)")
+        f, _, h, w = frames.shape
+        t = int(sequence_length)
+        l = hip.lib()
+        nw = l.vad_vid_num_windows(f, t, int(stride))
+        if nw <= 0 or stride > t:
+            raise hip.VadError(f"need F >= T and 0 < stride <= T (F={f}, T={t}, stride={stride})")
+        frames = frames.contiguous().float()
+        dev = frames.device
+        packed = self._packed(dev)
+        chunk = max(1, min(int(self.window_chunk), nw))
+        dims = (self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
+        nbytes = l.vad_vid_windows_workspace_bytes(chunk, t, int(stride), h, w, *dims)
+        if nbytes == 0:
+            raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
+        ws = self._hip.workspace(nbytes, dev)
+        out = {"seq": torch.empty(nw, dtype=torch.float32, device=dev),
+               "frame": torch.empty(nw, t, dtype=torch.float32, device=dev)}
+        if errmap:
+            out["errmap"] = torch.empty(nw, t, 1, h, w, dtype=torch.float32, device=dev)
+        if recon:
+            out["recon"] = torch.empty(nw, t, 3, h, w, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            hip.check(l.vad_vid_score_windows(frames.data_ptr(), f, t, int(stride), h, w, *dims, packed.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), chunk, out["seq"].data_ptr(),
+                                              out["frame"].data_ptr(), hip.ptr(out.get("errmap")),
+                                              hip.ptr(out.get("recon")), hip.current_stream()), "vad_vid_score_windows")
+        hip.calls["vid_score"] += 1
+        return out
+
     def score_all(self, x):
         """One pass returning recon, error maps, frame and clip scores (the reference's dense video mode
         runs three forwards per window for these: evaluate_video.py:350-352)."""
