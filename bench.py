@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["image", "video", "dense"], default="image")
     ap.add_argument("--stride", type=int, default=1, help="dense workload: window stride")
+    ap.add_argument("--ingest", choices=["f32", "u8"], default="f32",
+                    help="row f-3: u8 = raw uint8 NHWC frames, normalised inside the kernels (image workload)")
     ap.add_argument("--batch", type=int, default=0, help="frames (image) or clips (video) per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="frames/clips per launch group (0 = model default)")
     ap.add_argument("--size", type=int, default=256)
@@ -119,6 +121,9 @@ def main():
         if args.chunk:
             model.chunk = args.chunk
         x = vad.scoring.synth_frames_device(seed, rank * per_gpu, per_gpu, hw, hw, device=dev)
+        if args.ingest == "u8":   # the same frames as uint8 NHWC (what a decoder hands over): 4x fewer input bytes
+            u8 = vad.synth.frames_u8(seed, rank * per_gpu, per_gpu, 3, hw, hw)
+            x = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1))).to(dev)
         frames_per_step = per_gpu
         flop_per_frame, bytes_per_frame = IMG_FLOP_PER_FRAME * scale, IMG_BYTES_PER_FRAME * scale
 
@@ -126,6 +131,8 @@ def main():
             return model.get_reconstruction_error(x)
         width = 1
         workload = f"configs[1]: image autoencoder scoring, batch {per_gpu} synthetic {hw}x{hw}x3 frames per GPU"
+        if args.ingest == "u8":
+            workload += " (row f-3: uint8 NHWC ingest, normalised in-kernel)"
     elif args.workload == "dense":
         # Row f-2: dense sliding windows over ONE video per GPU (reference evaluate_video.py:322-352 with
         # sequence_length T, stride): per_gpu windows, every frame encoded once.

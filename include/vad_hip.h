@@ -161,6 +161,26 @@ int vad_debug_set_conv_variant(int variant);
 /* Frames per dec4.0 -> scoring-tail sub-group inside vad_img_score (0 = whole launch group). */
 int vad_debug_set_tail_group(int frames);
 
+/* Row f-3 — raw-frame ingest.  The *_x forms take the original frames in either format:
+ *   VAD_X_F32_NCHW (0): float32 [N,3,H,W] already normalised to [-1,1] (same as the plain entry points);
+ *   VAD_X_U8_NHWC  (1): uint8 [N,H,W,3] as decoded from an image / video file.  ToTensor + Normalize(0.5, 0.5)
+ *                       (reference utils/dataset.py:65-70, utils/video_dataset.py:62-66) is applied inside the first
+ *                       convolution's staging load and inside the scoring tail, bit-identically to the fp32 path, so
+ *                       the normalised fp32 frames (4x the bytes) never exist in memory.
+ * All other arguments and outputs are those of vad_img_score / vad_vid_score / vad_vid_score_windows. */
+#define VAD_X_F32_NCHW 0
+#define VAD_X_U8_NHWC 1
+int vad_img_score_x(const void* x, int x_format, long long b, int h, int w, int latent, const float* packed_dev,
+                    void* workspace, size_t workspace_bytes, int chunk, float* scores, float* errmap, float* recon_nchw,
+                    float* latent_nchw, void* stream);
+int vad_vid_score_x(const void* x, int x_format, long long b, int t, int h, int w, int latent, int hid, int layers,
+                    const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips, float* seq_scores,
+                    float* frame_scores, float* errmap, float* recon, void* stream);
+int vad_vid_score_windows_x(const void* frames, int x_format, long long nframes, int t, int stride, int h, int w,
+                            int latent, int hid, int layers, const float* packed_dev, void* workspace,
+                            size_t workspace_bytes, int chunk_windows, float* seq_scores, float* frame_scores,
+                            float* errmap, float* recon, void* stream);
+
 /* Dense sliding-window scoring of ONE video: window k = frames [k*stride, k*stride + T), 0 < stride <= T,
  * vad_vid_num_windows(F, T, stride) = (F - T) / stride + 1 windows.  Same results as scoring every window as its own
  * clip with vad_vid_score (what the reference does: evaluate_video.py:322-352 builds VideoFileDataset(sequence_length,

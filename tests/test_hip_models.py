@@ -185,6 +185,27 @@ def test_video_dense_windows_equal_per_window_clips(vad, t, stride, chunk):
         m.score_windows(frames[:3], sequence_length=4)
 
 
+def test_uint8_ingest_is_bit_identical(vad):
+    """Row f-3: raw uint8 NHWC frames, normalised inside the kernels (reference transform utils/dataset.py:65-70),
+    give bit-identical scores / maps / reconstructions to feeding the normalised fp32 NCHW tensor."""
+    u8 = vad.synth.frames_u8(31, 5, 6, 3, 48, 64, anomalies=True)                    # [N,3,H,W] uint8
+    xf = torch.from_numpy(vad.synth.u8_to_unit(u8)).cuda()
+    xu = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1))).cuda()     # [N,H,W,3]
+    m, _ = _img_model(vad, 64, 9)
+    with torch.no_grad():
+        a, b = m.score_all(xf), m.score_all(xu)
+        assert torch.equal(m.get_latent(xf), m.get_latent(xu))
+    for k in ("scores", "errmap", "recon"):
+        assert torch.equal(a[k], b[k]), k
+    v, _ = _vid_model(vad, 64, 64, 2, 10)
+    with torch.no_grad():
+        c, d = v.score_all(xf.view(2, 3, 3, 48, 64)), v.score_all(xu.view(2, 3, 48, 64, 3))
+        e, f = v.score_windows(xf, sequence_length=4, stride=1), v.score_windows(xu, sequence_length=4, stride=1)
+    for k in ("seq", "frame", "errmap", "recon"):
+        assert torch.equal(c[k], d[k]), k
+    assert torch.equal(e["frame"], f["frame"]) and torch.equal(e["seq"], f["seq"])
+
+
 def test_video_fresh_inputs_vs_oracle(vad):
     m, st = _vid_model(vad, 128, 128, 2, 43)
     x = vad.synth.clips(321, 3, 2, 5, 3, 48, 64)

@@ -144,14 +144,19 @@ class ConvAutoencoder(nn.Module):
         return self._hip.packed
 
     def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False):
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise hip.VadError(f"expected input [B,3,H,W], got {tuple(x.shape)}")
+        u8 = x.dtype == torch.uint8       # raw decoded frames [B,H,W,3]: normalised inside the kernels (row f-3)
+        if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != 3:
+            raise hip.VadError(f"expected float input [B,3,H,W] or uint8 input [B,H,W,3], got {x.dtype} {tuple(x.shape)}")
         if not x.is_cuda:
             raise hip.VadError(
                 "ConvAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
                 "'cuda' (there is no CPU fallback)")
-        b, _, h, w = x.shape
-        x = x.contiguous().float()
+        if u8:
+            b, h, w, _ = x.shape
+            x = x.contiguous()
+        else:
+            b, _, h, w = x.shape
+            x = x.contiguous().float()
         l = hip.lib()
         dev = x.device
         packed = self._packed(dev)
@@ -170,9 +175,10 @@ class ConvAutoencoder(nn.Module):
         if latent:
             out["latent"] = torch.empty(b, self.latent_dim, h // 16, w // 16, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(l.vad_img_score(x.data_ptr(), b, h, w, self.latent_dim, packed.data_ptr(), ws.data_ptr(),
-                                      ws.numel(), chunk, hip.ptr(out.get("scores")), hip.ptr(out.get("errmap")),
-                                      hip.ptr(out.get("recon")), hip.ptr(out.get("latent")), hip.current_stream()),
+            hip.check(l.vad_img_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, b, h, w,
+                                        self.latent_dim, packed.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), chunk, hip.ptr(out.get("scores")), hip.ptr(out.get("errmap")),
+                                        hip.ptr(out.get("recon")), hip.ptr(out.get("latent")), hip.current_stream()),
                       "vad_img_score")
         hip.calls["img_score"] += 1
         return out

@@ -30,6 +30,7 @@ struct Conv3P {
     float* out;       long long out_fs;
     const float* c_prev; float* c_out;               // MODE_LSTM
     const float* w0; const float* b0;                // FUSE_C3: first-layer (3->32) weights [28][32], bias
+    int xu8;                                         // FUSE_C3: `in` is uint8 NHWC [N,H,W,3] (normalised in the kernel)
     int n, h, w_, cin, cout, hid;
     int tiles_x, tiles_y, cblocks;
     unsigned nblocks;
@@ -360,12 +361,19 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
 // (reference models/autoencoder.py:38-46) in one launch; x is NCHW [N,3,H,W], out NHWC [N,H/2,W/2,32].
 extern "C" int vad_conv3x3_c3_fused(const float* x, const float* w0, const float* b0, const float* w1,
                                     const float* b1, float* out, int n, int h, int wd, void* stream) {
+    return vad_conv3x3_c3_fused_fmt(x, VAD_X_F32_NCHW, w0, b0, w1, b1, out, n, h, wd, stream);
+}
+
+int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1,
+                             const float* b1, float* out, int n, int h, int wd, void* stream) {
     VAD_REQUIRE(x && w0 && b0 && w1 && b1 && out, "conv3x3_c3_fused: null pointer");
+    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || (fmt == VAD_X_U8_NHWC && g_vad_conv_variant != 0),
+                "conv3x3_c3_fused: input format %d unsupported (uint8 input needs the persistent kernel)", fmt);
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && h % 2 == 0 && wd % 2 == 0, "conv3x3_c3_fused: bad shape %dx%d", h, wd);
     Conv3P p{};
-    p.in = x; p.in_fs = (long long)3 * h * wd; p.cin_a = 32;
+    p.in = (const float*)x; p.in_fs = (long long)3 * h * wd; p.cin_a = 32;   // frame stride in ELEMENTS of the input type
     p.w = w1; p.bias = b1; p.out = out; p.out_fs = (long long)(h / 2) * (wd / 2) * 32;
-    p.w0 = w0; p.b0 = b0;
+    p.w0 = w0; p.b0 = b0; p.xu8 = fmt == VAD_X_U8_NHWC;
     p.h = h; p.w_ = wd; p.cin = 32; p.cout = 32; p.hid = 0;
     constexpr int TH = 16;
     p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + TH - 1) / TH; p.cblocks = 1;
@@ -417,6 +425,7 @@ struct ConvC3P {
     const float* x; const float* w; const float* bias; float* out;
     int h, w_, cout, tiles_x, tiles_y;
     unsigned nblocks;
+    int xu8;                 // x is uint8 NHWC [N,H,W,3]
 };
 
 template <int MT, int POOL, int ACT>
@@ -432,11 +441,13 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
     const int y0 = ty * TH, x0 = tx * 16;
 
     const float* xin = p.x + (size_t)n * 3 * p.h * p.w_;
+    const unsigned char* xin8 = (const unsigned char*)p.x + (size_t)n * 3 * p.h * p.w_;
     for (int idx = tid; idx < 3 * LH * 18; idx += 256) {
         const int lx = idx % 18, t = idx / 18, ly = t % LH, c = t / LH;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
         float v = 0.f;
-        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_) v = xin[((size_t)c * p.h + gy) * p.w_ + gx];
+        if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
+            v = p.xu8 ? vad_norm_u8(xin8[((size_t)gy * p.w_ + gx) * 3 + c]) : xin[((size_t)c * p.h + gy) * p.w_ + gx];
         tile[(c * LH + ly) * RS + lx] = v;
     }
     __syncthreads();
@@ -492,11 +503,17 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
 
 extern "C" int vad_conv3x3_c3(const float* x, const float* w, const float* bias, float* out,
                               int n, int h, int wd, int cout, int act, int pool, void* stream) {
+    return vad_conv3x3_c3_fmt(x, VAD_X_F32_NCHW, w, bias, out, n, h, wd, cout, act, pool, stream);
+}
+
+int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias, float* out,
+                       int n, int h, int wd, int cout, int act, int pool, void* stream) {
     VAD_REQUIRE(x && w && bias && out, "conv3x3_c3: null pointer");
+    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || fmt == VAD_X_U8_NHWC, "conv3x3_c3: bad input format %d", fmt);
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && cout > 0 && cout % 32 == 0, "conv3x3_c3: bad shape");
     VAD_REQUIRE(!pool || (h % 2 == 0 && wd % 2 == 0), "conv3x3_c3: pooling needs even H,W");
     VAD_REQUIRE(act == VAD_ACT_LEAKY || act == VAD_ACT_RELU || act == VAD_ACT_NONE, "conv3x3_c3: bad act");
-    ConvC3P p{x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 15) / 16, 0};
+    ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 15) / 16, 0, fmt == VAD_X_U8_NHWC};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");
     p.nblocks = (unsigned)nb;

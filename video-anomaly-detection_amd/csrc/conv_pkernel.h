@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
             const int lx = idx % XW, t = idx / XW, ly = t % XH, c = t / XH;
             const int gy = y0 - 2 + ly, gx = x0 - 2 + lx;
             const bool ok = idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            svo[i] = ok ? (unsigned)(__mul24(c, __mul24(H, W)) + __mul24(gy, W) + gx) * 4u : VAD_OOB;
+            svo[i] = !ok ? VAD_OOB
+                         : p.xu8 ? (unsigned)(__mul24(__mul24(gy, W) + gx, 3) + c)                      // uint8 NHWC, bytes
+                                 : (unsigned)(__mul24(c, __mul24(H, W)) + __mul24(gy, W) + gx) * 4u;   // float NCHW
         }
     } else {
         const int pix0 = tid >> 3;
@@ -136,12 +138,20 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
     pf_t pf[NPF];    // next stage's input, in flight
 
     // both sources of a two-source (ConvLSTM) launch have the same channel count (host-checked), so svo serves both
-    const unsigned in_bytes = FUSE_C3 ? (unsigned)(3 * H * W) * 4u : (unsigned)(H * W) * (unsigned)p.cin_a * 4u;
+    const unsigned in_bytes = FUSE_C3 ? (unsigned)(3 * H * W) * (p.xu8 ? 1u : 4u) : (unsigned)(H * W) * (unsigned)p.cin_a * 4u;
 #define ISSUE(n_, ch_)                                                                                   \
     {                                                                                                    \
         if constexpr (FUSE_C3) {                                                                         \
-            const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(p.in + (size_t)(n_) * p.in_fs, in_bytes);         \
-            _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf_set(pf[i_], vad_bload1(r_, svo[i_], 0)); \
+            if (p.xu8) {   /* uint8 frames: normalise here; padding must be 0.0 AFTER normalisation */          \
+                const __amdgpu_buffer_rsrc_t r_ = vad_rsrc((const unsigned char*)p.in + (size_t)(n_) * p.in_fs, in_bytes); \
+                _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                     \
+                    const unsigned b_ = __builtin_amdgcn_raw_buffer_load_b8(r_, (int)svo[i_], 0, 0);     \
+                    pf_set(pf[i_], svo[i_] == VAD_OOB ? 0.f : vad_norm_u8(b_ & 255u));                   \
+                }                                                                                        \
+            } else {                                                                                     \
+                const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(p.in + (size_t)(n_) * p.in_fs, in_bytes);     \
+                _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf_set(pf[i_], vad_bload1(r_, svo[i_], 0)); \
+            }                                                                                            \
         } else {                                                                                         \
             const float* src_ = ((ch_) < nch_a) ? p.in + (size_t)(n_) * p.in_fs + (ch_) * CK             \
                                                 : p.in2 + (size_t)(n_) * p.in2_fs + ((ch_) - nch_a) * CK; \

@@ -19,7 +19,14 @@ struct TailP {
     int h, w_;            // spatial size of `in`
     int tiles_x, tiles_y;
     int xt, xs;           // x frame of activation frame n is (n / xt) * xs + n % xt (xt == 0: n)
+    int xu8;              // x is uint8 NHWC [N,H2,W2,3]
 };
+
+// original-input value of (frame nx, channel c, pixel y,x)
+__device__ __forceinline__ float tail_x(const TailP& p, size_t nx, int c, int y, int x, int h2, int w2) {
+    if (p.xu8) return vad_norm_u8(((const unsigned char*)p.x)[(nx * h2 * w2 + (size_t)y * w2 + x) * 3 + c]);
+    return p.x[(nx * 3 + c) * (size_t)h2 * w2 + (size_t)y * w2 + x];
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
                 float e = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float d = p.x[o + c * plane] - rc[c];
+                    const float d = tail_x(p, n, c, y, x, H, W) - rc[c];
                     e += d * d;
                     if (p.recon) p.recon[o + c * plane] = rc[c];
                 }
@@ -228,7 +235,9 @@ __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
             const size_t ox = (size_t)nx * 3 * plane + (size_t)(2 * y + a) * w2 + 2 * x;
 #pragma unroll
             for (int co = 0; co < 3; ++co) {
-                const float2 xv = *(const float2*)(p.x + ox + co * plane);
+                float2 xv;
+                if (p.xu8) xv = make_float2(tail_x(p, nx, co, 2 * y + a, 2 * x, h2, w2), tail_x(p, nx, co, 2 * y + a, 2 * x + 1, h2, w2));
+                else xv = *(const float2*)(p.x + ox + co * plane);
                 const float r0 = tanhf(acc[co * 4 + a * 2 + 0]), r1 = tanhf(acc[co * 4 + a * 2 + 1]);
                 const float d0 = xv.x - r0, d1 = xv.y - r1;
                 ea[0] += d0 * d0;
@@ -270,10 +279,16 @@ extern "C" int vad_score_partials(int kind, int h2, int w2) {
 extern "C" int vad_conv3x3_to3_score(const float* in, const float* w_packed, const float* bias3,
                                      const float* x, float* partials, float* recon, float* errmap,
                                      int n, int h2, int w2, int cin, void* stream) {
+    return vad_conv3x3_to3_score_fmt(in, w_packed, bias3, x, VAD_X_F32_NCHW, partials, recon, errmap, n, h2, w2, cin, stream);
+}
+
+int vad_conv3x3_to3_score_fmt(const float* in, const float* w_packed, const float* bias3, const void* x, int fmt,
+                              float* partials, float* recon, float* errmap, int n, int h2, int w2, int cin, void* stream) {
     VAD_REQUIRE(in && w_packed && bias3 && x && partials, "conv3x3_to3_score: null pointer");
+    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || fmt == VAD_X_U8_NHWC, "conv3x3_to3_score: bad input format %d", fmt);
     VAD_REQUIRE(cin == 32, "conv3x3_to3_score: cin=%d unsupported (the reference's dec4.3 has 32)", cin);
     VAD_REQUIRE(n > 0 && h2 > 0 && w2 > 0 && w2 % 16 == 0, "conv3x3_to3_score: bad shape (W=%d must be a positive multiple of 16)", w2);
-    TailP p{in, w_packed, bias3, x, partials, recon, errmap, h2, w2, (w2 + TAIL_T - 1) / TAIL_T, (h2 + TAIL_T - 1) / TAIL_T, 0, 0};
+    TailP p{in, w_packed, bias3, (const float*)x, partials, recon, errmap, h2, w2, (w2 + TAIL_T - 1) / TAIL_T, (h2 + TAIL_T - 1) / TAIL_T, 0, 0, fmt == VAD_X_U8_NHWC};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_to3_score: grid too large");
     hipLaunchKernelGGL(conv3x3_to3_score_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
@@ -284,11 +299,18 @@ extern "C" int vad_conv3x3_to3_score(const float* in, const float* w_packed, con
 extern "C" int vad_convt2x2_to3_score(const float* in, const float* w_iohw, const float* bias3,
                                       const float* x, float* partials, float* recon, float* errmap,
                                       int n, int h, int w, int cin, int t, int clip_stride, void* stream) {
+    return vad_convt2x2_to3_score_fmt(in, w_iohw, bias3, x, VAD_X_F32_NCHW, partials, recon, errmap, n, h, w, cin, t, clip_stride, stream);
+}
+
+int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float* bias3, const void* x, int fmt,
+                               float* partials, float* recon, float* errmap, int n, int h, int w, int cin, int t,
+                               int clip_stride, void* stream) {
     VAD_REQUIRE(in && w_iohw && bias3 && x && partials, "convt2x2_to3_score: null pointer");
+    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || fmt == VAD_X_U8_NHWC, "convt2x2_to3_score: bad input format %d", fmt);
     VAD_REQUIRE(cin == 32, "convt2x2_to3_score: cin=%d unsupported (the reference's decoder.9 has 32)", cin);
     VAD_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_to3_score: bad shape");
     VAD_REQUIRE(t >= 0 && clip_stride >= 0 && (t == 0 || clip_stride > 0), "convt2x2_to3_score: bad window mapping");
-    TailP p{in, w_iohw, bias3, x, partials, recon, errmap, h, w, (w + 31) / 32, (h + 7) / 8, (t == clip_stride) ? 0 : t, clip_stride};
+    TailP p{in, w_iohw, bias3, (const float*)x, partials, recon, errmap, h, w, (w + 31) / 32, (h + 7) / 8, (t == clip_stride) ? 0 : t, clip_stride, fmt == VAD_X_U8_NHWC};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "convt2x2_to3_score: grid too large");
     hipLaunchKernelGGL((convt2x2_to3_score_kernel<32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);

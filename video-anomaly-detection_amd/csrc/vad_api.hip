@@ -87,7 +87,17 @@ extern "C" size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent) {
 extern "C" int vad_img_score(const float* x, long long b, int h, int w, int latent, const float* packed,
                              void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
                              float* recon, float* latent_out, void* stream) {
-    VAD_REQUIRE(x && packed && ws, "img_score: null pointer");
+    return vad_img_score_x(x, VAD_X_F32_NCHW, b, h, w, latent, packed, ws, ws_bytes, chunk, scores, errmap, recon,
+                           latent_out, stream);
+}
+
+extern "C" int vad_img_score_x(const void* xv, int x_format, long long b, int h, int w, int latent, const float* packed,
+                               void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
+                               float* recon, float* latent_out, void* stream) {
+    VAD_REQUIRE(xv && packed && ws, "img_score: null pointer");
+    VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "img_score: unknown input format %d", x_format);
+    const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
+    const char* x = (const char*)xv;
     VAD_REQUIRE(b > 0 && chunk > 0, "img_score: batch=%lld chunk=%d must be positive", b, chunk);
     VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
                 "img_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
@@ -112,10 +122,10 @@ extern "C" int vad_img_score(const float* x, long long b, int h, int w, int late
 
     for (long long f0 = 0; f0 < b; f0 += chunk) {
         const int n = (int)((b - f0 < chunk) ? (b - f0) : chunk);
-        const float* xin = x + (size_t)f0 * 3 * h * w;
+        const char* xin = x + (size_t)f0 * 3 * h * w * xelem;
         int hh = h, ww = w;
         // encoder: 4 x [conv-BN-LeakyReLU, conv-BN-LeakyReLU-MaxPool] (models/autoencoder.py:38-79)
-        { VadProfScope ps(1, s); TRY(vad_conv3x3_c3_fused(xin, W_(0), B_(0), W_(1), B_(1), B, n, hh, ww, s)); }
+        { VadProfScope ps(1, s); TRY(vad_conv3x3_c3_fused_fmt(xin, x_format, W_(0), B_(0), W_(1), B_(1), B, n, hh, ww, s)); }
         for (int blk = 1; blk < 4; ++blk) {
             hh /= 2; ww /= 2;
             { VadProfScope ps(2 * blk, s);
@@ -148,7 +158,7 @@ extern "C" int vad_img_score(const float* x, long long b, int h, int w, int late
               TRY(vad_convt2x2(B + (size_t)f1 * in_f, 0, W_(14), B_(14), A, 0, m, hh, ww, 32, 32, VAD_ACT_RELU, s)); }
             { VadProfScope ps(15, s);
               const size_t fo = (size_t)(f0 + f1);
-              TRY(vad_conv3x3_to3_score(A, W_(15), B_(15), xin + (size_t)f1 * 3 * h * w, parts + (size_t)f1 * nparts,
+              TRY(vad_conv3x3_to3_score_fmt(A, W_(15), B_(15), xin + (size_t)f1 * 3 * h * w * xelem, x_format, parts + (size_t)f1 * nparts,
                                         recon ? recon + fo * 3 * h * w : nullptr,
                                         errmap ? errmap + fo * h * w : nullptr, m, h, w, 32, s)); }
         }
@@ -188,9 +198,12 @@ VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent, int hid, int la
 }
 
 // clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
-int vid_run(const float* x, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
+int vid_run(const void* xv, int x_format, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
             const float* packed, void* ws, size_t ws_bytes, int chunk, float* seq_scores, float* frame_scores,
             float* errmap, float* recon, hipStream_t s, const char* who) {
+    VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "%s: unknown input format %d", who, x_format);
+    const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
+    const char* x = (const char*)xv;
     const VidWs Z = vid_ws(chunk, t, cs, h, w, latent, hid, layers);
     if (ws_bytes < Z.total) return vad_fail(VAD_ERR_WS, "%s: workspace %zu B < required %zu B", who, ws_bytes, Z.total);
     VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "%s: workspace must be 256-B and weights 16-B aligned", who);
@@ -217,10 +230,10 @@ int vid_run(const float* x, long long nclips, int t, int cs, int h, int w, int l
         const int nc = (int)((nclips - c0 < chunk) ? (nclips - c0) : chunk);
         const int n = nc * t;                       // (clip, t) frames that are decoded and scored
         const int nf = (nc - 1) * cs + t;           // distinct source frames that are encoded
-        const float* xin = x + (size_t)c0 * cs * 3 * h * w;
+        const char* xin = x + (size_t)c0 * cs * 3 * h * w * xelem;
         // VideoEncoder: 4 x conv-BN-LeakyReLU-MaxPool on the flattened frames
         // (models/video_autoencoder.py:191-215, :222-228)
-        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3(xin, W_(0), B_(0), A, nf, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3_fmt(xin, x_format, W_(0), B_(0), A, nf, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
         { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, s)); }
         { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, s)); }
         { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, s)); }
@@ -253,7 +266,7 @@ int vid_run(const float* x, long long nclips, int t, int cs, int h, int w, int l
         { VadProfScope ps(7, s); TRY(vad_convt2x2(A, 0, W_(li + 1), B_(li + 1), Bf, 0, n, h / 8, w / 8, 128, 64, VAD_ACT_RELU, s)); }
         { VadProfScope ps(8, s); TRY(vad_convt2x2(Bf, 0, W_(li + 2), B_(li + 2), A, 0, n, h / 4, w / 4, 64, 32, VAD_ACT_RELU, s)); }
         { VadProfScope ps(9, s);
-          TRY(vad_convt2x2_to3_score(A, W_(li + 3), B_(li + 3), xin, parts,
+          TRY(vad_convt2x2_to3_score_fmt(A, W_(li + 3), B_(li + 3), xin, x_format, parts,
                                      recon ? recon + (size_t)c0 * t * 3 * h * w : nullptr,
                                      errmap ? errmap + (size_t)c0 * t * h * w : nullptr, n, h / 2, w / 2, 32,
                                      t, cs, s)); }
@@ -278,13 +291,20 @@ extern "C" size_t vad_vid_workspace_bytes(int chunk, int t, int h, int w, int la
 extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
                              const float* packed, void* ws, size_t ws_bytes, int chunk,
                              float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
+    return vad_vid_score_x(x, VAD_X_F32_NCHW, b, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores,
+                           frame_scores, errmap, recon, stream);
+}
+
+extern "C" int vad_vid_score_x(const void* x, int x_format, long long b, int t, int h, int w, int latent, int hid, int layers,
+                               const float* packed, void* ws, size_t ws_bytes, int chunk,
+                               float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
     VAD_REQUIRE(x && packed && ws, "vid_score: null pointer");
     VAD_REQUIRE(b > 0 && t > 0 && chunk > 0, "vid_score: clips=%lld T=%d chunk=%d must be positive", b, t, chunk);
     VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
                 "vid_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
     if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;   // message already set
     VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score: no output requested");
-    return vid_run(x, b, t, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap,
+    return vid_run(x, x_format, b, t, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap,
                    recon, (hipStream_t)stream, "vid_score");
 }
 
@@ -303,12 +323,20 @@ extern "C" int vad_vid_score_windows(const float* frames, long long nframes, int
                                      int latent, int hid, int layers, const float* packed, void* ws, size_t ws_bytes,
                                      int chunk, float* seq_scores, float* frame_scores, float* errmap, float* recon,
                                      void* stream) {
+    return vad_vid_score_windows_x(frames, VAD_X_F32_NCHW, nframes, t, stride, h, w, latent, hid, layers, packed, ws, ws_bytes,
+                                   chunk, seq_scores, frame_scores, errmap, recon, stream);
+}
+
+extern "C" int vad_vid_score_windows_x(const void* frames, int x_format, long long nframes, int t, int stride, int h, int w,
+                                       int latent, int hid, int layers, const float* packed, void* ws, size_t ws_bytes,
+                                       int chunk, float* seq_scores, float* frame_scores, float* errmap, float* recon,
+                                       void* stream) {
     VAD_REQUIRE(frames && packed && ws, "vid_score_windows: null pointer");
     VAD_REQUIRE(t > 0 && stride > 0 && stride <= t && chunk > 0, "vid_score_windows: need 0 < stride <= T (got T=%d stride=%d) and chunk > 0", t, stride);
     VAD_REQUIRE(nframes >= t, "vid_score_windows: %lld frames are fewer than one window of %d", nframes, t);
     VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0, "vid_score_windows: H=%d W=%d must be positive multiples of 16", h, w);
     if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;
     VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score_windows: no output requested");
-    return vid_run(frames, vad_vid_num_windows(nframes, t, stride), t, stride, h, w, latent, hid, layers, packed, ws,
+    return vid_run(frames, x_format, vad_vid_num_windows(nframes, t, stride), t, stride, h, w, latent, hid, layers, packed, ws,
                    ws_bytes, chunk, seq_scores, frame_scores, errmap, recon, (hipStream_t)stream, "vid_score_windows");
 }

@@ -45,6 +45,28 @@ __device__ __forceinline__ float vad_act(float v, int act) {
 __device__ __forceinline__ float vad_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 __device__ __forceinline__ float vad_tanh(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
 
+// Input formats of the ORIGINAL frames handed to the model-level entry points.
+//   VAD_X_F32_NCHW : float32 [N,3,H,W], already normalised to [-1,1] (what the reference's datasets produce)
+//   VAD_X_U8_NHWC  : uint8 [N,H,W,3] as decoded; the kernels apply ToTensor + Normalize(0.5,0.5) themselves,
+//                    (u8/255 - 0.5)/0.5 in fp32 step by step (reference utils/dataset.py:65-70), bit-identical
+__device__ __forceinline__ float vad_norm_u8(unsigned v) {
+    float f = (float)v;
+    f = f / 255.0f;
+    f = f - 0.5f;
+    return f / 0.5f;
+}
+
+// format-aware internals behind the float-only layer entry points of include/vad_hip.h
+int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias, float* out, int n, int h, int wd,
+                       int cout, int act, int pool, void* stream);
+int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1, const float* b1,
+                             float* out, int n, int h, int wd, void* stream);
+int vad_conv3x3_to3_score_fmt(const float* in, const float* w_packed, const float* bias3, const void* x, int fmt,
+                              float* partials, float* recon, float* errmap, int n, int h2, int w2, int cin, void* stream);
+int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float* bias3, const void* x, int fmt,
+                               float* partials, float* recon, float* errmap, int n, int h, int w, int cin, int t,
+                               int clip_stride, void* stream);
+
 // per-layer profiling hooks (vad_api.hip)
 struct VadProfScope {
     int slot;

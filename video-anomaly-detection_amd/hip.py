@@ -21,6 +21,7 @@ HEADERS = ["vad_common.h", "vad_layout.h"]
 
 VAD_OK = 0
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+X_F32_NCHW, X_U8_NHWC = 0, 1
 PROF_SLOTS = 32
 
 _lock = threading.Lock()
@@ -91,6 +92,9 @@ SIGNATURES = {
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_debug_set_conv_variant": (_i, [_i]),
     "vad_debug_set_tail_group": (_i, [_i]),
+    "vad_img_score_x": (_i, [_vp, _i, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_vid_score_x": (_i, [_vp, _i, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_vid_score_windows_x": (_i, [_vp, _i, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_num_windows": (_ll, [_ll, _i, _i]),
     "vad_vid_windows_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "vad_vid_score_windows": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -167,14 +167,19 @@ class VideoAutoencoder(nn.Module):
         return self._hip.packed
 
     def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False):
-        if x.dim() != 5 or x.shape[2] != 3:
-            raise hip.VadError(f"expected input [B,T,3,H,W], got {tuple(x.shape)}")
+        u8 = x.dtype == torch.uint8       # raw decoded frames [B,T,H,W,3]: normalised inside the kernels (row f-3)
+        if x.dim() != 5 or (x.shape[4] if u8 else x.shape[2]) != 3:
+            raise hip.VadError(f"expected float input [B,T,3,H,W] or uint8 input [B,T,H,W,3], got {x.dtype} {tuple(x.shape)}")
         if not x.is_cuda:
             raise hip.VadError(
                 "VideoAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
                 "'cuda' (there is no CPU fallback)")
-        b, t, _, h, w = x.shape
-        x = x.contiguous().float()
+        if u8:
+            b, t, h, w, _ = x.shape
+            x = x.contiguous()
+        else:
+            b, t, _, h, w = x.shape
+            x = x.contiguous().float()
         l = hip.lib()
         dev = x.device
         packed = self._packed(dev)
@@ -194,7 +199,8 @@ class VideoAutoencoder(nn.Module):
         if recon:
             out["recon"] = torch.empty(b, t, 3, h, w, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(l.vad_vid_score(x.data_ptr(), b, t, h, w, *dims, packed.data_ptr(), ws.data_ptr(), ws.numel(),
+            hip.check(l.vad_vid_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, b, t, h, w, *dims,
+                                        packed.data_ptr(), ws.data_ptr(), ws.numel(),
                                       chunk, hip.ptr(out.get("seq")), hip.ptr(out.get("frame")),
                                       hip.ptr(out.get("errmap")), hip.ptr(out.get("recon")), hip.current_stream()),
                       "vad_vid_score")
@@ -243,17 +249,21 @@ class VideoAutoencoder(nn.Module):
         but each frame goes through the encoder once instead of once per window that contains it."""
         if not self._use_hip():
             raise hip.VadError("score_windows is an inference entry point: call under eval() and torch.no_grad()")
-        if frames.dim() != 4 or frames.shape[1] != 3:
-            raise hip.VadError(f"expected frames [F,3,H,W], got {tuple(frames.shape)}")
+        u8 = frames.dtype == torch.uint8
+        if frames.dim() != 4 or (frames.shape[3] if u8 else frames.shape[1]) != 3:
+            raise hip.VadError(f"expected float frames [F,3,H,W] or uint8 frames [F,H,W,3], got {tuple(frames.shape)}")
         if not frames.is_cuda:
             raise hip.VadError("score_windows runs only on the MI355X HIP path (there is no CPU fallback)")
-        f, _, h, w = frames.shape
+        if u8:
+            f, h, w, _ = frames.shape
+        else:
+            f, _, h, w = frames.shape
         t = int(sequence_length)
         l = hip.lib()
         nw = l.vad_vid_num_windows(f, t, int(stride))
         if nw <= 0 or stride > t:
             raise hip.VadError(f"need F >= T and 0 < stride <= T (F={f}, T={t}, stride={stride})")
-        frames = frames.contiguous().float()
+        frames = frames.contiguous() if u8 else frames.contiguous().float()
         dev = frames.device
         packed = self._packed(dev)
         chunk = max(1, min(int(self.window_chunk), nw))
@@ -269,7 +279,8 @@ class VideoAutoencoder(nn.Module):
         if recon:
             out["recon"] = torch.empty(nw, t, 3, h, w, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(l.vad_vid_score_windows(frames.data_ptr(), f, t, int(stride), h, w, *dims, packed.data_ptr(),
+            hip.check(l.vad_vid_score_windows_x(frames.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, f, t,
+                                                int(stride), h, w, *dims, packed.data_ptr(),
                                               ws.data_ptr(), ws.numel(), chunk, out["seq"].data_ptr(),
                                               out["frame"].data_ptr(), hip.ptr(out.get("errmap")),
                                               hip.ptr(out.get("recon")), hip.current_stream()), "vad_vid_score_windows")
