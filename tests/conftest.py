@@ -18,8 +18,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def vad():
-    """The product package (its directory name is not a Python identifier)."""
-    return importlib.import_module("video-anomaly-detection_amd")
+    """The product package (its directory name is not a Python identifier).  Builds the native library first if a
+    fresh checkout has none (hipcc cross-compiles without a GPU; a no-op when the .so is up to date)."""
+    pkg = importlib.import_module("video-anomaly-detection_amd")
+    if not pkg.hip.LIB_PATH.exists():
+        pkg.hip.build()
+    return pkg
 
 
 @pytest.fixture(scope="session")

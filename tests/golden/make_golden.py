@@ -166,6 +166,62 @@ def init_fixture(name):
           img_w_std=np.array([float(a.state_dict()[k].std()) for k in a.state_dict() if k.endswith("0.weight") and a.state_dict()[k].dim() == 4]))
 
 
+
+
+
+def trained_fixture(name, latent=64, epochs=12):
+    """Precision gate of SURVEY.md section 8(d): a TRAINED, low-residual model.  Recipe: the reference's own synthetic
+    dataset generator (utils/download_data.py:85-184, loaded by file path; numpy + PIL only), its model class, Adam(lr
+    1e-3, wd 1e-5) + MSELoss as in train.py:149-159, batch 10, `epochs` epochs on the 50 training images.  Stored:
+    the trained state dict (latent_dim 64 keeps it at ~2.7 MB), the 30 test images as uint8 and the reference's
+    scores / AUROC on them."""
+    import tempfile
+    from PIL import Image
+    from sklearn.metrics import roc_auc_score
+    dl = _load("_ref_download_data", REF / "utils" / "download_data.py")
+    with tempfile.TemporaryDirectory() as tmp:
+        root = dl.create_synthetic_test_data(tmp, "synthetic")
+
+        def load_dir(d):
+            files = sorted(Path(d).glob("*.png"))
+            return np.stack([np.asarray(Image.open(f).convert("RGB").resize((256, 256))) for f in files])
+        train_u8 = load_dir(root / "train" / "good")
+        good_u8 = load_dir(root / "test" / "good")
+        bad_u8 = load_dir(root / "test" / "defect")
+
+    def to_t(u8):   # ToTensor + Normalize(0.5, 0.5) (reference utils/dataset.py:65-70)
+        return torch.from_numpy(synth.u8_to_unit(u8.transpose(0, 3, 1, 2)))
+    torch.manual_seed(0)
+    model = ref_ae.ConvAutoencoder(in_channels=3, latent_dim=latent)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    crit = torch.nn.MSELoss()
+    xtr = to_t(train_u8)
+    model.train()
+    for ep in range(epochs):
+        perm = torch.randperm(len(xtr))
+        tot = 0.0
+        for i in range(0, len(xtr), 10):
+            xb = xtr[perm[i:i + 10]]
+            opt.zero_grad()
+            loss = crit(model(xb), xb)
+            loss.backward()
+            opt.step()
+            tot += float(loss) * len(xb)
+        print(f"  epoch {ep + 1}: loss {tot / len(xtr):.6f}")
+    model.eval()
+    test_u8 = np.concatenate([good_u8, bad_u8])
+    labels = np.array([0] * len(good_u8) + [1] * len(bad_u8))
+    with torch.no_grad():
+        xt = to_t(test_u8)
+        scores = torch.cat([model.get_reconstruction_error(xt[i:i + 16]) for i in range(0, len(xt), 16)]).numpy()
+        emap0 = model.get_reconstruction_error(xt[:1], per_pixel=True).numpy()
+    st = {("w." + k): v.numpy() for k, v in model.state_dict().items()}
+    print(f"  scores good {scores[labels == 0].mean():.5f} defect {scores[labels == 1].mean():.5f} "
+          f"auroc {roc_auc_score(labels, scores):.4f}")
+    _save(name, latent_dim=np.array(latent), test_u8=test_u8, labels=labels, scores=scores.astype(np.float32),
+          auroc=np.array(roc_auc_score(labels, scores)), errmap0_sub=emap0[:, :, ::8, ::8], **st)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     image_fixture("img_l32_32.npz", latent=32, wseed=11, xseed=101, n=3, hw=32, intermediates=True)
@@ -178,3 +234,4 @@ if __name__ == "__main__":
     auroc_fixture("auroc_cfg0.npz")
     losses_fixture("losses.npz")
     init_fixture("init.npz")
+    trained_fixture("img_trained_l64.npz")

@@ -185,6 +185,24 @@ def test_video_dense_windows_equal_per_window_clips(vad, t, stride, chunk):
         m.score_windows(frames[:3], sequence_length=4)
 
 
+def test_trained_model_precision_gate(vad, golden):
+    """SURVEY.md section 8(d) precision gate on the GPU: trained reference weights (strict state-dict load), the
+    reference's synthetic test images fed as raw uint8 frames, scores within 1e-5 of the reference's own and the same
+    AUROC / ranking."""
+    g = golden("img_trained_l64.npz")
+    m = vad.ConvAutoencoder(in_channels=3, latent_dim=int(g["latent_dim"]))
+    m.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=True)
+    m = m.cuda().eval()
+    xu = torch.from_numpy(g["test_u8"]).cuda()                                   # [30,256,256,3] uint8
+    with torch.no_grad():
+        out = m.score_all(xu)
+    s = out["scores"].cpu().numpy()
+    assert rel_err(s, g["scores"]) < SCORE_RTOL
+    assert vad.scoring.roc_auc(g["labels"], s) == pytest.approx(float(g["auroc"]), abs=1e-12)
+    assert np.array_equal(np.argsort(s), np.argsort(g["scores"]))
+    assert max_abs(out["errmap"].cpu().numpy()[:1, :, ::8, ::8], g["errmap0_sub"]) < ACT_ATOL
+
+
 def test_uint8_ingest_is_bit_identical(vad):
     """Row f-3: raw uint8 NHWC frames, normalised inside the kernels (reference transform utils/dataset.py:65-70),
     give bit-identical scores / maps / reconstructions to feeding the normalised fp32 NCHW tensor."""

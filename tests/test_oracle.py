@@ -120,3 +120,16 @@ def test_auroc_config0(vad, golden):
             scores.extend(torch_oracle.img_scores(st, x)["scores"].numpy())
     assert rel_err(scores, g["scores"]) < SCORE_RTOL
     assert abs(vad.scoring.roc_auc(labels, scores) - float(g["auroc"])) < 1e-12
+
+
+def test_trained_model_gate_oracle(vad, golden):
+    """SURVEY.md section 8(d) precision gate: a TRAINED model of the reference (low-residual regime, trained BN
+    statistics) on its own synthetic test images; the oracle reproduces the reference's scores and AUROC."""
+    g = golden("img_trained_l64.npz")
+    st = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    x = torch.from_numpy(vad.synth.u8_to_unit(g["test_u8"].transpose(0, 3, 1, 2)))
+    with torch.no_grad():
+        s = torch.cat([torch_oracle.img_scores(st, x[i:i + 16])["scores"] for i in range(0, len(x), 16)]).numpy()
+    assert rel_err(s, g["scores"]) < SCORE_RTOL
+    assert abs(vad.scoring.roc_auc(g["labels"], s) - float(g["auroc"])) < 1e-12
+    assert s[g["labels"] == 1].mean() > s[g["labels"] == 0].mean()
