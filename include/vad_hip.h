@@ -155,6 +155,16 @@ int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, 
                   const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips,
                   float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
 
+/* Arithmetic of the 3x3 convolutions (process-wide; set it BEFORE packing weights — the packed layout follows it —
+ * and do not change it while another thread is inside the library):
+ *   0  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain (default; the parity path);
+ *   1  split fp16: every fp32 operand v is used as hi = fp16(v), lo = fp16((v-hi)*2^11) and a*b is evaluated as
+ *      ah*bh + (ah*bl + al*bh)*2^-11 with three v_mfma_f32_32x32x16_f16 and fp32 accumulation.  fp16 products are
+ *      exact in fp32, so each product carries 22 significant bits (fp32 has 24); activations and outputs in HBM stay
+ *      fp32.  Needs |activation| < 65504.  Opt-in; gated by the same golden-vector and trained-model tests. */
+int vad_set_precision(int mode);
+int vad_get_precision(void);
+
 /* Developer switch for A/B timing in one process: 0 = one tile per work-group, 1 = persistent work-groups with
  * register prefetch of the next stage (default).  Results are bit-identical. */
 int vad_debug_set_conv_variant(int variant);

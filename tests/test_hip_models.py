@@ -203,6 +203,45 @@ def test_trained_model_precision_gate(vad, golden):
     assert max_abs(out["errmap"].cpu().numpy()[:1, :, ::8, ::8], g["errmap0_sub"]) < ACT_ATOL
 
 
+def test_split_precision_mode_holds_parity(vad, golden):
+    """Opt-in split-fp16 arithmetic (3 x fp16 MFMA, fp32 accumulate; vad_set_precision): every score gate of the exact
+    path — reference golden vectors on random weights, the trained-model gate, the ConvLSTM video model — within 1e-5
+    relative, i.e. 10x inside north_star's 1e-4 bar."""
+    try:
+        g = golden("img_l256_64.npz")
+        m, _ = _img_model(vad, 256, int(g["wseed"]))
+        m.precision = "split"
+        x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), 3, 64, 64)).cuda()
+        with torch.no_grad():
+            out = m.score_all(x)
+        assert rel_err(out["scores"].cpu().numpy(), g["scores"]) < SCORE_RTOL
+        assert max_abs(out["recon"].cpu().numpy(), g["recon"]) < ACT_ATOL
+        t = golden("img_trained_l64.npz")
+        mt = vad.ConvAutoencoder(in_channels=3, latent_dim=64)
+        mt.load_state_dict({k[2:]: torch.from_numpy(t[k]) for k in t.files if k.startswith("w.")}, strict=True)
+        mt = mt.cuda().eval()
+        mt.precision = "split"
+        with torch.no_grad():
+            s = mt.get_reconstruction_error(torch.from_numpy(t["test_u8"]).cuda()).cpu().numpy()
+        assert rel_err(s, t["scores"]) < SCORE_RTOL
+        assert np.array_equal(np.argsort(s), np.argsort(t["scores"]))
+        v = golden("vid_default_64.npz")
+        mv, _ = _vid_model(vad, 128, 128, 2, int(v["wseed"]))
+        mv.precision = "split"
+        xv = torch.from_numpy(vad.synth.clips(int(v["xseed"]), 0, int(v["b"]), int(v["t"]), 3, 64, 64)).cuda()
+        with torch.no_grad():
+            ov = mv.score_all(xv)
+        assert rel_err(ov["frame"].cpu().numpy(), v["frame"]) < SCORE_RTOL
+        assert max_abs(ov["recon"].cpu().numpy(), v["recon"]) < ACT_ATOL
+        # and the exact path is still what a default model uses afterwards
+        m2, _ = _img_model(vad, 256, int(g["wseed"]))
+        with torch.no_grad():
+            s2 = m2.get_reconstruction_error(x)
+        assert vad.hip.lib().vad_get_precision() == 0 and rel_err(s2.cpu().numpy(), g["scores"]) < SCORE_RTOL
+    finally:
+        vad.hip.lib().vad_set_precision(0)
+
+
 def test_uint8_ingest_is_bit_identical(vad):
     """Row f-3: raw uint8 NHWC frames, normalised inside the kernels (reference transform utils/dataset.py:65-70),
     give bit-identical scores / maps / reconstructions to feeding the normalised fp32 NCHW tensor."""

@@ -1,0 +1,24 @@
+import importlib, sys, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+vad = importlib.import_module("video-anomaly-detection_amd")
+from oracle import torch_oracle
+def synth_load(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    st = {k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, seed).items()}
+    module.load_state_dict(st, strict=True); return st
+m = vad.ConvAutoencoder(); st = synth_load(m, 7); m = m.cuda().eval()
+x = vad.scoring.synth_frames_device(0xC0FFEE + 1, 0, 32)
+with torch.no_grad():
+    a = m.score_all(x)
+    m.precision = "split"
+    b = m.score_all(x)
+    m.precision = "fp32"
+ref = torch_oracle.img_scores(st, x[:8].cpu())
+# float64 truth for the first 2 frames
+st64 = {k: v.double() if v.is_floating_point() else v for k, v in st.items()}
+t64 = torch_oracle.img_scores(st64, x[:2].cpu().double())["scores"].numpy()
+sa, sb = a["scores"].cpu().numpy().astype(np.float64), b["scores"].cpu().numpy().astype(np.float64)
+print("bit-identical scores:", np.array_equal(sa, sb), " max rel |split-exact|:", np.max(np.abs(sa - sb) / sa))
+print("recon max abs diff split vs exact:", float((a["recon"] - b["recon"]).abs().max()))
+print("vs cpu fp32 oracle (8 frames): exact", np.max(np.abs(sa[:8] - ref["scores"].numpy()) / ref["scores"].numpy()), "split", np.max(np.abs(sb[:8] - ref["scores"].numpy()) / ref["scores"].numpy()))
+print("vs fp64 truth (2 frames): exact", np.max(np.abs(sa[:2] - t64) / t64), "split", np.max(np.abs(sb[:2] - t64) / t64), "cpu fp32", np.max(np.abs(ref["scores"].numpy()[:2] - t64) / t64))

@@ -100,6 +100,17 @@ class _HipScorer:
             out.append(np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy()))
         return out
 
+    @staticmethod
+    def set_precision(name: str) -> int:
+        """Select the library's arithmetic mode for the calls that follow (process-wide switch, see vad_hip.h)."""
+        modes = {"fp32": 0, "split": 1}
+        if name not in modes:
+            raise hip.VadError(f"precision must be one of {sorted(modes)}, got {name!r}")
+        l = hip.lib()
+        if l.vad_get_precision() != modes[name]:
+            hip.check(l.vad_set_precision(modes[name]), "vad_set_precision")
+        return modes[name]
+
     def workspace(self, nbytes: int, device) -> torch.Tensor:
         if self.ws is None or self.ws.numel() < nbytes or self.ws.device != device:
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -112,6 +123,9 @@ class ConvAutoencoder(nn.Module):
     #: frames per launch group (workspace = 2 x chunk x 8.4 MB at 256x256); large enough that every layer launches
     #: several work-groups per resident slot
     chunk = 128
+    #: "fp32" = exact fp32 MFMA (default, the parity path); "split" = 3 x fp16 MFMA with fp32 accumulate (opt-in,
+    #: 22-bit products; see include/vad_hip.h vad_set_precision)
+    precision = "fp32"
 
     def __init__(self, in_channels: int = 3, latent_dim: int = 256):
         super().__init__()
@@ -127,9 +141,10 @@ class ConvAutoencoder(nn.Module):
         return not self.training and not torch.is_grad_enabled()
 
     def _packed(self, device) -> torch.Tensor:
-        key = _HipScorer.state_key(self)
+        l = hip.lib()
+        mode = _HipScorer.set_precision(self.precision)
+        key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
-            l = hip.lib()
             n = l.vad_img_packed_floats(self.in_channels, self.latent_dim)
             if n == 0:
                 raise hip.VadError(

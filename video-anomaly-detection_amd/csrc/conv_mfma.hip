@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
 
 unsigned long long* g_vad_dbg = nullptr;
 extern "C" int vad_debug_set_stamp_buffer(void* p) { g_vad_dbg = (unsigned long long*)p; return VAD_OK; }
+extern int g_vad_precision;   // pack.cpp: the weights were packed for this mode
 int g_vad_conv_variant = 1;   // 0: one tile per work-group, 1: persistent + register prefetch (default)
 int g_vad_conv_stagger = 0;
 int g_vad_conv64 = 0;
@@ -293,6 +294,14 @@ static unsigned persistent_grid_for(const Conv3P& p, unsigned cap) {
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT>
 static void launch_conv3_act(const Conv3P& p, hipStream_t s) {
+    if (g_vad_precision == 1) {   // split-fp16 operands (persistent kernel only)
+        static unsigned grid_cap1 = 0;
+        if (!grid_cap1) grid_cap1 = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>, ~0u);
+        Conv3P q = p;
+        q.dbg = g_vad_dbg;
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>), dim3(persistent_grid_for(p, grid_cap1)), dim3(256), 0, s, q);
+        return;
+    }
     if (g_vad_conv_variant == 0) {
         hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(p.nblocks), dim3(256), 0, s, p);
     } else {
@@ -342,6 +351,14 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
     p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
     p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.hid = 0;
     hipStream_t s = (hipStream_t)stream;
+    if (g_vad_precision == 1) {
+        // split-fp16 operands double the accumulators (main + cross terms): keep one N-tile per wave
+        if (cout % 64 == 0)
+            return pool ? launch_conv3<32, 2, 1, 2, 2, MODE_POOL>(p, n, act, s)
+                        : launch_conv3<32, 2, 1, 2, 2, MODE_PLAIN>(p, n, act, s);
+        return pool ? launch_conv3<32, 2, 1, 4, 1, MODE_POOL>(p, n, act, s)
+                    : launch_conv3<32, 2, 1, 4, 1, MODE_PLAIN>(p, n, act, s);
+    }
     if (cout % 128 == 0) {
         return pool ? launch_conv3<32, 2, 2, 2, 2, MODE_POOL>(p, n, act, s)
                     : launch_conv3<32, 2, 2, 2, 2, MODE_PLAIN>(p, n, act, s);
@@ -367,7 +384,7 @@ extern "C" int vad_conv3x3_c3_fused(const float* x, const float* w0, const float
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1,
                              const float* b1, float* out, int n, int h, int wd, void* stream) {
     VAD_REQUIRE(x && w0 && b0 && w1 && b1 && out, "conv3x3_c3_fused: null pointer");
-    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || (fmt == VAD_X_U8_NHWC && g_vad_conv_variant != 0),
+    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || (fmt == VAD_X_U8_NHWC && (g_vad_conv_variant != 0 || g_vad_precision == 1)),
                 "conv3x3_c3_fused: input format %d unsupported (uint8 input needs the persistent kernel)", fmt);
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && h % 2 == 0 && wd % 2 == 0, "conv3x3_c3_fused: bad shape %dx%d", h, wd);
     Conv3P p{};
@@ -381,7 +398,13 @@ int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const floa
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3_fused: grid too large");
     p.nblocks = (unsigned)nb;
     p.n = n;
-    if (g_vad_conv_variant == 0) {
+    if (g_vad_precision == 1) {
+        static unsigned grid_cap1 = 0;
+        if (!grid_cap1) grid_cap1 = persistent_grid(conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1, 1>, ~0u);
+        p.dbg = g_vad_dbg;
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1, 1>), dim3(persistent_grid_for(p, grid_cap1)), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    } else if (g_vad_conv_variant == 0) {
         hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>), dim3((unsigned)nb), dim3(256), 0,
                            (hipStream_t)stream, p);
     } else {
@@ -411,6 +434,7 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
     p.c_prev = c_prev; p.c_out = c_out;
     p.h = h; p.w_ = wd; p.cin = cin_x + hid; p.cout = 4 * hid; p.hid = hid;
     // the persistent kernel shares one set of staging offsets between x and h: needs cin_x == hid
+    VAD_REQUIRE(!(g_vad_precision == 1 && cin_x != hid), "convlstm_step: split precision needs cin_x == hid (got %d, %d)", cin_x, hid);
     const int saved = g_vad_conv_variant;
     if (cin_x != hid) g_vad_conv_variant = 0;
     const int rc = launch_conv3<32, 1, 4, 2, 2, MODE_LSTM>(p, n, VAD_ACT_NONE, (hipStream_t)stream);

@@ -62,8 +62,36 @@ constexpr unsigned VAD_OOB = 0x80000000u;   // byte offset no frame reaches (hos
 #define STAMP(k)
 #endif
 
-template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0>
-__global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 value -> (hi, lo) fp16 pair with hi + lo * 2^-11 == v to 22 significant bits: hi = fp16(v),
+// lo = fp16((v - hi) * 2^11).  fp16 x fp16 products are exact in fp32, so
+//   a*b = ah*bh + (ah*bl + al*bh) * 2^-11 + O(2^-22 |a*b|)
+// with fp32 accumulation: three fp16 MFMAs (16x the fp32 pipe rate each) replace one fp32 MFMA.  |v| must stay
+// below 65504 (fp16 range); activations of these networks are O(1..100).
+__device__ __forceinline__ void vad_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * 2048.0f);
+}
+
+// store one activation (channel ch of the pixel whose tile float offset is pixoff): fp32, or its (hi, lo) fp16 pair
+template <int PREC>
+__device__ __forceinline__ void tile_put_t(float* tile, int pixoff_plus_ch, int ch, float v) {
+    if constexpr (PREC) {
+        _Float16 hi, lo;
+        vad_split(v, hi, lo);
+        _Float16* blk = (_Float16*)&tile[pixoff_plus_ch - ch + (ch >> 3) * 8];   // 8-channel block = 32 bytes = 8 floats
+        blk[ch & 7] = hi;
+        blk[8 + (ch & 7)] = lo;
+    } else {
+        tile[pixoff_plus_ch] = v;
+    }
+}
+
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0>
+__global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
     static_assert(WM * WN == 4, "4 waves per work-group");
     static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
     static_assert(!FUSE_C3 || CK == 32, "fused first layer produces exactly one 32-channel chunk");
@@ -74,7 +102,11 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
     constexpr int XH = LH + 2, XW = 20, XS = 20;
     constexpr int NPIX = LH * LW, NT0 = (NPIX + 31) / 32;
     constexpr int TOT = FUSE_C3 ? 3 * XH * XW : NPIX * (CK / 4), NPF = (TOT + 255) / 256;
-    constexpr int NS = 9 * (CK / 8);
+    // PREC 0: exact fp32 MFMA (32x32x2, 8 channels per step).  PREC 1: split-fp16 MFMA (32x32x16, 16 channels per
+    // step, 3 MFMAs): the LDS tile then holds, per pixel and 8-channel block, [8 x hi fp16 | 8 x lo fp16] (the same
+    // 32 bytes), converted from the fp32 activations while staging; HBM formats are unchanged.
+    constexpr int KS = PREC ? 16 : 8;
+    constexpr int NS = 9 * (CK / KS);
     static_assert(NS % 2 == 0, "double-buffer parity must be the same in every chunk");
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
     __shared__ float xin[FUSE_C3 ? 3 * XH * XS : 1];
@@ -95,12 +127,12 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
     int abase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-        abase[mt] = ((2 * (wm * MT + mt) + prow) * LW + pcol) * PS + 4 * lh;
+        abase[mt] = ((2 * (wm * MT + mt) + prow) * LW + pcol) * PS + (PREC ? 8 : 4) * lh;
 
     const int nch_a = p.cin_a / CK;
     const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
-    const unsigned wstep = (unsigned)p.cout * 32u;                 // bytes per (tap, k8) slab
-    const unsigned wtap = (unsigned)(p.cin / 8) * wstep;           // bytes per tap
+    const unsigned wstep = (unsigned)p.cout * (PREC ? 64u : 32u);  // bytes per (tap, k-step) slab
+    const unsigned wtap = (unsigned)(p.cin / KS) * wstep;          // bytes per tap
     const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 9u * wtap);
 
     // staging slots: slot i of this thread is float4 (or float) number tid + 256 i of the staged tile.
@@ -171,7 +203,8 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
     ISSUE(n, 0);
 
     // per-lane weight rows / bias of this cout block
-    f32x4 a[2][MT], b[2][NT];
+    f32x4 a[2][MT], b[2][NT];          // PREC 0 fragments
+    f16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];   // PREC 1 fragments
     unsigned wl[NT];
     float bv[NT];
     int cofs[NT];                                                  // output channel (element offset) of N-tile nt
@@ -179,20 +212,30 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (MODE == MODE_LSTM) ? nt * p.hid + (cb * WN + wn) * 32 + li : ((cb * WN + wn) * NT + nt) * 32 + li;
         cofs[nt] = co;
-        wl[nt] = (unsigned)co * 32u + 16u * lh;
+        wl[nt] = PREC ? (unsigned)co * 64u + 32u * lh : (unsigned)co * 32u + 16u * lh;
         bv[nt] = p.bias[co];
     }
 #define LOAD_B(buf, chunk, step)                                                                  \
     {                                                                                             \
-        const unsigned woff_ = (unsigned)((step) / (CK / 8)) * wtap +                             \
-                               (unsigned)((chunk) * (CK / 8) + (step) % (CK / 8)) * wstep;        \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = vad_bload4(rw, wl[nt], woff_); \
+        const unsigned woff_ = (unsigned)((step) / (CK / KS)) * wtap +                            \
+                               (unsigned)((chunk) * (CK / KS) + (step) % (CK / KS)) * wstep;      \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                       \
+            if constexpr (PREC) {                                                                 \
+                bh[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw, wl[nt], woff_));           \
+                bl[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw, wl[nt] + 16u, woff_));     \
+            } else b[buf][nt] = vad_bload4(rw, wl[nt], woff_);                                    \
+        }                                                                                         \
     }
 #define LOAD_A(buf, step)                                                                         \
     {                                                                                             \
-        const int toff_ = ((((step) / (CK / 8)) / 3) * LW + (((step) / (CK / 8)) % 3)) * PS +     \
-                          ((step) % (CK / 8)) * 8;                                                \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) a[buf][mt] = *(const f32x4*)&tile[abase[mt] + toff_]; \
+        const int toff_ = ((((step) / (CK / KS)) / 3) * LW + (((step) / (CK / KS)) % 3)) * PS +   \
+                          ((step) % (CK / KS)) * (PREC ? 16 : 8);                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
+            if constexpr (PREC) {                                                                 \
+                ah[buf][mt] = __builtin_bit_cast(f16x8, *(const f32x4*)&tile[abase[mt] + toff_]); \
+                al[buf][mt] = __builtin_bit_cast(f16x8, *(const f32x4*)&tile[abase[mt] + toff_ + 4]); \
+            } else a[buf][mt] = *(const f32x4*)&tile[abase[mt] + toff_];                          \
+        }                                                                                         \
     }
     LOAD_B(0, 0, 0);
 
@@ -229,6 +272,15 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
 
     while (true) {
         f32x16 acc[MT][NT];
+        f32x16 corr[PREC ? MT : 1][PREC ? NT : 1];   // PREC 1: sum of the cross terms, scaled by 2^11
+        if constexpr (PREC) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) corr[mt][nt][r] = 0.f;
+        }
         if constexpr (!FUSE_C3) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -296,7 +348,7 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
                         if (interior && t < NT0 - 1) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
-                                tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = vad_act(c0[u][r], VAD_ACT_LEAKY);
+                                tile_put_t<PREC>(tile, qb + ((r & 3) + 8 * (r >> 2)) * PS, li, vad_act(c0[u][r], VAD_ACT_LEAKY));
                         } else {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
@@ -304,7 +356,7 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
                                 const int ly2 = q2 / LW, lx2 = q2 - ly2 * LW;
                                 const bool inside = (unsigned)(y0 - 1 + ly2) < (unsigned)H && (unsigned)(x0 - 1 + lx2) < (unsigned)W;
                                 const float v = vad_act(c0[u][r], VAD_ACT_LEAKY);
-                                if (q2 < NPIX) tile[qb + ((r & 3) + 8 * (r >> 2)) * PS] = inside ? v : 0.f;
+                                if (q2 < NPIX) tile_put_t<PREC>(tile, qb + ((r & 3) + 8 * (r >> 2)) * PS, li, inside ? v : 0.f);
                             }
                         }
                     }
@@ -321,7 +373,19 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
             } else {
 #pragma unroll
                 for (int i = 0; i < NPF; ++i)
-                    if ((tid >> 3) + 32 * i < NPIX) *(f32x4*)&tile[slds0 + i * 32 * PS] = pf_get_v(pf[i]);
+                    if ((tid >> 3) + 32 * i < NPIX) {
+                        if constexpr (PREC) {   // channels 4*c4..4*c4+3 = half (c4&1) of 8-channel block c4>>1
+                            const f32x4 v = pf_get_v(pf[i]);
+                            f16x4 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { _Float16 h_, l_; vad_split(v[e], h_, l_); hi[e] = h_; lo[e] = l_; }
+                            float* blk = &tile[(tid >> 3) * PS + i * 32 * PS + (c4 >> 1) * 8 + (c4 & 1) * 2];
+                            *(f16x4*)blk = hi;
+                            *(f16x4*)(blk + 4) = lo;
+                        } else {
+                            *(f32x4*)&tile[slds0 + i * 32 * PS] = pf_get_v(pf[i]);
+                        }
+                    }
                 STAMP(2);
                 __syncthreads();
                 STAMP(3);
@@ -340,15 +404,34 @@ __global__ __launch_bounds__(256, FUSE_C3 ? 3 : 2) void conv3x3_mfma_pkernel(Con
                     LOAD_B(nxt, ch + 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                if constexpr (PREC) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = MFMA32(a[cur][mt][j], b[cur][nt][j], acc[mt][nt]);
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[mt][nt] = MFMA16(ah[cur][mt], bh[cur][nt], acc[mt][nt]);
+                            corr[mt][nt] = MFMA16(ah[cur][mt], bl[cur][nt], corr[mt][nt]);
+                            corr[mt][nt] = MFMA16(al[cur][mt], bh[cur][nt], corr[mt][nt]);
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = MFMA32(a[cur][mt][j], b[cur][nt][j], acc[mt][nt]);
+                }
             }
             STAMP(5);
+        }
+        if constexpr (PREC) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(corr[mt][nt][r], 0x1p-11f, acc[mt][nt][r]);
         }
 
         // next frame's first B fragments go out BEFORE this frame's stores (in-order vmcnt)

@@ -41,7 +41,32 @@ static void bn_scale_shift(const float* bias, const float* const* bn, int cout,
     }
 }
 
+int g_vad_precision = 0;   // 0: exact fp32 MFMA; 1: split-fp16 (3 x fp16 MFMA, fp32 accumulate) for the 3x3 convolutions
+extern "C" int vad_set_precision(int mode) {
+    REQ(mode == 0 || mode == 1, "set_precision: mode must be 0 (fp32) or 1 (split fp16)");
+    g_vad_precision = mode;
+    return VAD_OK;
+}
+extern "C" int vad_get_precision(void) { return g_vad_precision; }
+
 extern "C" size_t vad_pack_conv3x3_floats(int cout, int cin) { return (size_t)9 * ((cin + 7) / 8) * cout * 8; }
+
+// Split-fp16 operand form of the same weights (same byte count): [tap][cin/16][cout][half h][8 x hi | 8 x lo] fp16,
+// element j of half h = input channel 16*c16 + 8*h + j; hi = fp16(w), lo = fp16((w - hi) * 2^11).
+static void pack_conv3x3_split(const float* w, const std::vector<double>& s, int cout, int cin, float* out) {
+    _Float16* o = (_Float16*)out;
+    const int c16n = cin / 16;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int tap = 0; tap < 9; ++tap) {
+                const float v = (float)((double)w[((size_t)co * cin + ci) * 9 + tap] * s[co]);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                const size_t base = ((((size_t)tap * c16n + ci / 16) * cout + co) * 2 + ((ci >> 3) & 1)) * 16;
+                o[base + (ci & 7)] = hi;
+                o[base + 8 + (ci & 7)] = lo;
+            }
+}
 
 extern "C" int vad_pack_conv3x3(const float* w, const float* bias, const float* const* bn,
                                 int cout, int cin, float* out, float* bias_out) {
@@ -50,6 +75,10 @@ extern "C" int vad_pack_conv3x3(const float* w, const float* bias, const float* 
     bn_scale_shift(bias, bn, cout, s, bias_out);
     const int c8n = (cin + 7) / 8;
     memset(out, 0, vad_pack_conv3x3_floats(cout, cin) * sizeof(float));
+    if (g_vad_precision == 1 && cin % 16 == 0) {
+        pack_conv3x3_split(w, s, cout, cin, out);
+        return VAD_OK;
+    }
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int tap = 0; tap < 9; ++tap)

@@ -90,6 +90,8 @@ SIGNATURES = {
     "vad_vid_pack": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "vad_vid_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_set_precision": (_i, [_i]),
+    "vad_get_precision": (_i, []),
     "vad_debug_set_conv_variant": (_i, [_i]),
     "vad_debug_set_tail_group": (_i, [_i]),
     "vad_img_score_x": (_i, [_vp, _i, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -125,6 +125,8 @@ class VideoAutoencoder(nn.Module):
 
     #: clips per launch group
     chunk = 64
+    #: "fp32" (default) or "split": see ConvAutoencoder.precision
+    precision = "fp32"
 
     def __init__(self, in_channels: int = 3, latent_dim: int = 128, lstm_hidden_dim: int = 128,
                  lstm_num_layers: int = 2):
@@ -148,9 +150,10 @@ class VideoAutoencoder(nn.Module):
         return not self.training and not torch.is_grad_enabled()
 
     def _packed(self, device) -> torch.Tensor:
-        key = _HipScorer.state_key(self)
+        l = hip.lib()
+        mode = _HipScorer.set_precision(self.precision)
+        key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
-            l = hip.lib()
             n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
             if n == 0 or self.in_channels != 3:
                 raise hip.VadError(
