@@ -103,11 +103,14 @@ if __name__ == "__main__":
     ap.add_argument("--cout", type=int, default=32)
     ap.add_argument("--pool", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--precision", type=int, default=0, help="0 exact fp32, 1 split fp16")
     ap.add_argument("--stamps", type=int, default=0, help="diagnostic build only (VAD_LIB=...stamps.so)")
     ap.add_argument("--variant", type=int, default=-1, help="conv kernel variant (0 one tile per WG, 1 persistent)")
     a = ap.parse_args()
     if a.variant >= 0:
         hip.lib().vad_debug_set_conv_variant(a.variant)
+    if a.precision:
+        hip.lib().vad_set_precision(a.precision)
     dbg = None
     if a.stamps:
         import ctypes

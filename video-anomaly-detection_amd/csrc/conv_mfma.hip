@@ -299,6 +299,7 @@ static void launch_conv3_act(const Conv3P& p, hipStream_t s) {
         if (!grid_cap1) grid_cap1 = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>, ~0u);
         Conv3P q = p;
         q.dbg = g_vad_dbg;
+        q.stagger = g_vad_conv_stagger;   // debug (variant bit 1): zero-sized weight descriptor = price the weight traffic
         hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>), dim3(persistent_grid_for(p, grid_cap1)), dim3(256), 0, s, q);
         return;
     }
@@ -353,6 +354,9 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
     hipStream_t s = (hipStream_t)stream;
     if (g_vad_precision == 1) {
         // split-fp16 operands double the accumulators (main + cross terms): keep one N-tile per wave
+        if (cout % 128 == 0 && !g_vad_conv64)   // one B fragment per 4 M-tiles: halves the weight traffic through L1
+            return pool ? launch_conv3<32, 4, 1, 1, 4, MODE_POOL>(p, n, act, s)
+                        : launch_conv3<32, 4, 1, 1, 4, MODE_PLAIN>(p, n, act, s);
         if (cout % 64 == 0)
             return pool ? launch_conv3<32, 2, 1, 2, 2, MODE_POOL>(p, n, act, s)
                         : launch_conv3<32, 2, 1, 2, 2, MODE_PLAIN>(p, n, act, s);

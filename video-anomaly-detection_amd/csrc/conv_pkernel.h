@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     // 32 bytes), converted from the fp32 activations while staging; HBM formats are unchanged.
     constexpr int KS = PREC ? 16 : 8;
     constexpr int NS = 9 * (CK / KS);
-    static_assert(NS % 2 == 0, "double-buffer parity must be the same in every chunk");
+    // B (weight) fragments come from L2 and are requested PB steps ahead into a ring of NB register sets; the fp16
+    // steps are 5x shorter than the fp32 ones, so they need the deeper prefetch to cover an L2 round trip.
+    constexpr int PB = (PREC && NT <= 2) ? 2 : 1, NB = PB + 1;
+    static_assert(NS % 2 == 0 && NS % NB == 0, "fragment ring parity must be the same in every chunk");
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
     __shared__ float xin[FUSE_C3 ? 3 * XH * XS : 1];
 
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
     const unsigned wstep = (unsigned)p.cout * (PREC ? 64u : 32u);  // bytes per (tap, k-step) slab
     const unsigned wtap = (unsigned)(p.cin / KS) * wstep;          // bytes per tap
-    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 9u * wtap);
+    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, (p.stagger & 1) ? 0u : 9u * wtap);   // stagger bit 0 (debug): price the weight traffic
 
     // staging slots: slot i of this thread is float4 (or float) number tid + 256 i of the staged tile.
     // svo[i] = byte offset of the slot inside one frame of the source (channel chunk 0), or VAD_OOB when the
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     ISSUE(n, 0);
 
     // per-lane weight rows / bias of this cout block
-    f32x4 a[2][MT], b[2][NT];          // PREC 0 fragments
-    f16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];   // PREC 1 fragments
+    f32x4 a[2][MT], b[NB][NT];          // PREC 0 fragments
+    f16x8 ah[PREC ? 1 : 2][MT], al[PREC ? 1 : 2][MT], bh[NB][NT], bl[NB][NT];   // PREC 1 fragments (A single-buffered, refilled in halves)
     unsigned wl[NT];
     float bv[NT];
     int cofs[NT];                                                  // output channel (element offset) of N-tile nt
@@ -226,6 +229,15 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
             } else b[buf][nt] = vad_bload4(rw, wl[nt], woff_);                                    \
         }                                                                                         \
     }
+#define LOAD_A_HALF(step, m0, m1)   /* PREC 1: refill M-tiles [m0, m1) of the single A buffer for `step` */ \
+    {                                                                                             \
+        const int toff_ = ((((step) / (CK / KS)) / 3) * LW + (((step) / (CK / KS)) % 3)) * PS +   \
+                          ((step) % (CK / KS)) * 16;                                              \
+        _Pragma("unroll") for (int mt = (m0); mt < (m1); ++mt) {                                  \
+            ah[0][mt] = __builtin_bit_cast(f16x8, *(const f32x4*)&tile[abase[mt] + toff_]);       \
+            al[0][mt] = __builtin_bit_cast(f16x8, *(const f32x4*)&tile[abase[mt] + toff_ + 4]);   \
+        }                                                                                         \
+    }
 #define LOAD_A(buf, step)                                                                         \
     {                                                                                             \
         const int toff_ = ((((step) / (CK / KS)) / 3) * LW + (((step) / (CK / KS)) % 3)) * PS +   \
@@ -237,7 +249,8 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
             } else a[buf][mt] = *(const f32x4*)&tile[abase[mt] + toff_];                          \
         }                                                                                         \
     }
-    LOAD_B(0, 0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < PB; ++s0) LOAD_B(s0, 0, s0);
 
     float b0w[FUSE_C3 ? 14 : 1];
     float bias0 = 0.f;
@@ -392,35 +405,55 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 if (ch + 1 < nch) { ISSUE(n, ch + 1); }
                 else if (has_next) { ISSUE(nn, 0); }
             }
-            LOAD_A(0, 0);
+            if constexpr (PREC) { LOAD_A_HALF(0, 0, MT); } else { LOAD_A(0, 0); }
             STAMP(4);
+            if constexpr (PREC) {
+                // fp16 steps: B ring from L2 (PB ahead); A single-buffered in registers and refilled for step s+1 in two
+                // halves, each right after the MFMAs that consumed it, so an LDS round trip hides under the other half.
+                constexpr int MH = (MT + 1) / 2;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s + 1 < NS) {
-                    LOAD_A(nxt, s + 1);
-                    LOAD_B(nxt, ch, s + 1);
-                } else if (ch + 1 < nch) {
-                    LOAD_B(nxt, ch + 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PREC) {
+                for (int s = 0; s < NS; ++s) {
+                    const int bcur = s % NB, bnxt = (s + PB) % NB;
+                    if (s + PB < NS) { LOAD_B(bnxt, ch, s + PB); }
+                    else if (ch + 1 < nch) { LOAD_B(bnxt, ch + 1, s + PB - NS); }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MH; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            acc[mt][nt] = MFMA16(ah[cur][mt], bh[cur][nt], acc[mt][nt]);
-                            corr[mt][nt] = MFMA16(ah[cur][mt], bl[cur][nt], corr[mt][nt]);
-                            corr[mt][nt] = MFMA16(al[cur][mt], bh[cur][nt], corr[mt][nt]);
+                            acc[mt][nt] = MFMA16(ah[0][mt], bh[bcur][nt], acc[mt][nt]);
+                            corr[mt][nt] = MFMA16(ah[0][mt], bl[bcur][nt], corr[mt][nt]);
+                            corr[mt][nt] = MFMA16(al[0][mt], bh[bcur][nt], corr[mt][nt]);
                         }
-                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < NS) LOAD_A_HALF(s + 1, 0, MH);
+#pragma unroll
+                    for (int mt = MH; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[mt][nt] = MFMA16(ah[0][mt], bh[bcur][nt], acc[mt][nt]);
+                            corr[mt][nt] = MFMA16(ah[0][mt], bl[bcur][nt], corr[mt][nt]);
+                            corr[mt][nt] = MFMA16(al[0][mt], bh[bcur][nt], corr[mt][nt]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < NS) LOAD_A_HALF(s + 1, MH, MT);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int cur = s & 1, nxt = cur ^ 1;
+                    const int bcur = s % NB, bnxt = (s + PB) % NB;
+                    if (s + 1 < NS) LOAD_A(nxt, s + 1);
+                    if (s + PB < NS) { LOAD_B(bnxt, ch, s + PB); }
+                    else if (ch + 1 < nch) { LOAD_B(bnxt, ch + 1, s + PB - NS); }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = MFMA32(a[cur][mt][j], b[cur][nt][j], acc[mt][nt]);
+                                acc[mt][nt] = MFMA32(a[cur][mt][j], b[bcur][nt][j], acc[mt][nt]);
                 }
             }
             STAMP(5);
@@ -435,7 +468,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
         }
 
         // next frame's first B fragments go out BEFORE this frame's stores (in-order vmcnt)
-        if (has_next) LOAD_B(0, 0, 0);
+        if (has_next) {
+#pragma unroll
+            for (int s0 = 0; s0 < PB; ++s0) LOAD_B(s0, 0, s0);
+        }
 
         // ------------------------------------------------------------ epilogue of this frame's tile
         // Stores go through a buffer descriptor of this frame's output: offset = lane part (VGPR) + wave-uniform
@@ -503,6 +539,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
         n = nn;
     }
 #undef LOAD_A
+#undef LOAD_A_HALF
 #undef LOAD_B
 #undef ISSUE
 #ifdef VAD_STAMPS
