@@ -252,12 +252,22 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #pragma unroll
     for (int s0 = 0; s0 < PB; ++s0) LOAD_B(s0, 0, s0);
 
-    float b0w[FUSE_C3 ? 14 : 1];
+    float b0w[(FUSE_C3 && !PREC) ? 14 : 1];
+    f16x8 b0h[(FUSE_C3 && PREC) ? 2 : 1], b0l[(FUSE_C3 && PREC) ? 2 : 1];
     float bias0 = 0.f;
     bool interior = false;
     if constexpr (FUSE_C3) {
+        if constexpr (PREC) {
+            const f32x4* ws = (const f32x4*)(p.w0 + 28 * 32);          // split-fp16 copy of the first-layer weights
 #pragma unroll
-        for (int s0 = 0; s0 < 14; ++s0) b0w[s0] = p.w0[(s0 * 2 + lh) * 32 + li];
+            for (int ks = 0; ks < 2; ++ks) {
+                b0h[ks] = __builtin_bit_cast(f16x8, ws[((ks * 32 + li) * 2 + lh) * 2]);
+                b0l[ks] = __builtin_bit_cast(f16x8, ws[((ks * 32 + li) * 2 + lh) * 2 + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int s0 = 0; s0 < 14; ++s0) b0w[s0] = p.w0[(s0 * 2 + lh) * 32 + li];
+        }
         bias0 = p.b0[li];
         interior = y0 > 0 && x0 > 0 && y0 + TH < H && x0 + 16 < W;
     }
@@ -266,8 +276,13 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bv[nt]));
     if constexpr (FUSE_C3) {
+        if constexpr (PREC) {
 #pragma unroll
-        for (int s0 = 0; s0 < 14; ++s0) asm volatile("" ::"v"(b0w[s0]));
+            for (int ks = 0; ks < 2; ++ks) { asm volatile("" ::"v"(b0h[ks])); asm volatile("" ::"v"(b0l[ks])); }
+        } else {
+#pragma unroll
+            for (int s0 = 0; s0 < 14; ++s0) asm volatile("" ::"v"(b0w[s0]));
+        }
         asm volatile("" ::"v"(bias0));
     }
 
@@ -327,6 +342,49 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 // Each wave owns M-tiles wave, wave+4, wave+8 of the halo tile and runs their 14-step chains
                 // INTERLEAVED (independent accumulators) at raised priority: a single dependent chain on a pipe
                 // shared with another work-group's main loop advances one MFMA per two pipe slots.
+                if constexpr (PREC) {
+                    // split-fp16 first stage: K = 27 padded to 32 = two 16-deep steps, 3 MFMAs each (192 pipe cycles per
+                    // 32 pixels instead of 896); the 16 gathered taps of a lane are split into hi / lo on the fly.
+                    for (int t = wave; t < NT0; t += 4) {
+                        const int q = t * 32 + li, qc = q < NPIX ? q : NPIX - 1;
+                        const int abase0 = (qc / LW) * XS + (qc % LW);
+                        f16x8 gh[2], gl[2];
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int k0 = 16 * ks + j, k1 = 16 * ks + 8 + j;     // lane half 0 / 1
+                                const int o0 = (k0 < 27) ? ((k0 / 9) * XH + (k0 % 9) / 3) * XS + (k0 % 3) : 0;
+                                const int o1 = (k1 < 27) ? ((k1 / 9) * XH + (k1 % 9) / 3) * XS + (k1 % 3) : 0;
+                                const bool live = lh ? (k1 < 27) : (k0 < 27);
+                                const float v = live ? xin[abase0 + (lh ? o1 : o0)] : 0.f;
+                                _Float16 h_, l_;
+                                vad_split(v, h_, l_);
+                                gh[ks][j] = h_;
+                                gl[ks][j] = l_;
+                            }
+                        f32x16 c0, cc;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { c0[r] = bias0; cc[r] = 0.f; }
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            c0 = MFMA16(gh[ks], b0h[ks], c0);
+                            cc = MFMA16(gh[ks], b0l[ks], cc);
+                            cc = MFMA16(gl[ks], b0h[ks], cc);
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                        const int qb = (t * 32 + 4 * lh) * PS + li;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int q2 = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const int ly2 = q2 / LW, lx2 = q2 - ly2 * LW;
+                            const bool inside = interior || ((unsigned)(y0 - 1 + ly2) < (unsigned)H && (unsigned)(x0 - 1 + lx2) < (unsigned)W);
+                            const float v = vad_act(fmaf(cc[r], 0x1p-11f, c0[r]), VAD_ACT_LEAKY);
+                            if (q2 < NPIX) tile_put_t<PREC>(tile, qb + ((r & 3) + 8 * (r >> 2)) * PS, li, inside ? v : 0.f);
+                        }
+                    }
+                } else {
                 constexpr int TPW = (NT0 + 3) / 4;
                 f32x16 c0[TPW];
                 float av[TPW][14];
@@ -373,6 +431,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                             }
                         }
                     }
+                }
                 }
                 STAMP(8);
                 __syncthreads();

@@ -87,7 +87,9 @@ extern "C" int vad_pack_conv3x3(const float* w, const float* bias, const float* 
     return VAD_OK;
 }
 
-extern "C" size_t vad_pack_conv3x3_c3_floats(int cout) { return (size_t)28 * cout; }
+// [28][cout] fp32 (K = 27 padded to 28) followed by the split-fp16 form for the fused first stage in split mode:
+// [2 k-steps][cout][half h][8 x hi | 8 x lo] fp16 (K padded to 32), 32*cout halves*2 = 32*cout floats.
+extern "C" size_t vad_pack_conv3x3_c3_floats(int cout) { return (size_t)(28 + 32) * cout; }
 
 extern "C" int vad_pack_conv3x3_c3(const float* w, const float* bias, const float* const* bn,
                                    int cout, float* out, float* bias_out) {
@@ -97,6 +99,15 @@ extern "C" int vad_pack_conv3x3_c3(const float* w, const float* bias, const floa
     for (int k = 0; k < 28; ++k)
         for (int co = 0; co < cout; ++co)
             out[(size_t)k * cout + co] = k < 27 ? (float)((double)w[(size_t)co * 27 + k] * s[co]) : 0.f;
+    _Float16* o = (_Float16*)(out + (size_t)28 * cout);
+    for (int k = 0; k < 32; ++k)
+        for (int co = 0; co < cout; ++co) {
+            const float v = k < 27 ? (float)((double)w[(size_t)co * 27 + k] * s[co]) : 0.f;
+            const _Float16 hi = (_Float16)v, lo = (_Float16)((v - (float)hi) * 2048.0f);
+            const size_t base = ((((size_t)(k / 16)) * cout + co) * 2 + ((k >> 3) & 1)) * 16;
+            o[base + (k & 7)] = hi;
+            o[base + 8 + (k & 7)] = lo;
+        }
     return VAD_OK;
 }
 
