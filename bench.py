@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--clip-len", type=int, default=10)
     ap.add_argument("--no-layer-events", action="store_true", help="do not bracket layers with hipEvents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="skip the secondary split-precision measurement")
     ap.add_argument("--tail-group", type=int, default=0, help="frames per dec4.0 -> tail sub-group (0 = auto)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
@@ -271,6 +272,30 @@ def main():
     if layers is not None:
         out["layers"] = layers
 
+    # Secondary measurement, same workload and step count: the opt-in split-fp16 arithmetic (3 x fp16 MFMA, fp32
+    # accumulate).  `value` above is always the exact-fp32 path.
+    if args.precision == "fp32" and not args.no_split:
+        exact_scores = scores.clone()
+        model.precision = "split"
+        for _ in range(max(1, args.warmup)):
+            scores = step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            scores = step()
+        fence()
+        el2 = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        diff = float(((scores - exact_scores).abs() / exact_scores.abs()).max())
+        out["split_precision"] = {"value": round(total_frames / el2, 1), "unit": "frames/s",
+                                  "ms_per_step": round(el2 / args.steps * 1e3, 3),
+                                  "max_rel_score_diff_vs_exact_fp32": diff,
+                                  "arithmetic": "a*b = ah*bh + (ah*bl + al*bh)*2^-11, fp16 hi/lo operands, fp32 accumulate"}
+        model.precision = "fp32"
+        scores = exact_scores
     if args.workload == "dense":
         out["unique_frames_per_sec"] = round(((per_gpu - 1) * args.stride + t) * world * args.steps / elapsed, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "dense":
