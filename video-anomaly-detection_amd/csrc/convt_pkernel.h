@@ -1,0 +1,174 @@
+// ConvTranspose2d(k2, s2) + bias + act as a wave-persistent MFMA GEMM without LDS (included by
+// conv_mfma.hip after conv_pkernel.h).
+//
+//   out[n, 2y+a, 2x+b, co] = bias[co] + sum_ci in[n,y,x,ci] * W[ci,co,a,b]        (reference
+//   models/autoencoder.py:104-131, models/video_autoencoder.py:244-256; BatchNorm folded on the host)
+//
+// GEMM: M = input pixels, K = Cin, N = (quadrant q = 2a+b, co).  Every output element has exactly ONE
+// contributing input pixel, so there is no halo and no reuse between waves worth an LDS tile: each
+// wave walks work items on its own — an item is MT M-tiles (2 rows x 16 columns each, stacked
+// vertically) x NT N-tiles (32 columns each) — with A fragments read straight from the NHWC input
+// (a lane's 4 or 8 consecutive channels of its pixel) and B fragments from the L2-resident packed
+// weights, both one step ahead in registers.  No barriers, no LDS, occupancy set by registers only.
+// These layers are store-bound (dec4.0 writes 8.4 MB per 256x256 frame): the epilogue uses buffer
+// stores with wave-uniform (SGPR) offsets per element; out-of-image elements are dropped by the
+// descriptor's range check.  PREC 1 = split-fp16 arithmetic (see conv_pkernel.h).
+#pragma once
+
+struct ConvTP2 {
+    const float* in; long long in_fs;
+    const float* w; const float* bias;
+    float* out; long long out_fs;
+    int n, h, w_, cin, cout;
+    int tiles_x, tiles_y;     // M-tile groups per frame: tiles_x = ceil(W/16), tiles_y = ceil(H/(2*MT))
+    int ngroups;              // column groups of NT*32 columns: 4*cout / (NT*32)
+    unsigned nitems;          // n * tiles_y * tiles_x * ngroups
+};
+
+template <int MT, int NT, int ACT, int PREC>
+__global__ __launch_bounds__(256, 2) void convt2x2_pkernel(ConvTP2 p) {
+    constexpr int KS = PREC ? 16 : 8;
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const unsigned gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int H = p.h, W = p.w_, ctiles = p.cout / 32;
+    const int nk = p.cin / KS;
+    const unsigned wstep = (unsigned)p.cout * (PREC ? 64u : 32u);      // bytes per (q, k-step) slab
+    const unsigned wq = (unsigned)nk * wstep;                          // bytes per quadrant
+    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 4u * wq);
+    const unsigned in_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u;
+    const int oh = 2 * H, ow = 2 * W;
+    const unsigned out_bytes = (unsigned)(oh * ow) * (unsigned)p.cout * 4u;
+    const int prow = li >> 4, pcol = li & 15;                         // A-operand pixel of this lane inside an M-tile
+
+    for (unsigned item = __builtin_amdgcn_readfirstlane(gw); item < p.nitems; item += nw) {
+        unsigned r0 = item;
+        const int ng = r0 % p.ngroups; r0 /= p.ngroups;
+        const int x0 = (r0 % p.tiles_x) * 16; r0 /= p.tiles_x;
+        const int y0 = (r0 % p.tiles_y) * (2 * MT);
+        const int n = r0 / p.tiles_y;
+        const __amdgpu_buffer_rsrc_t ra = vad_rsrc(p.in + (size_t)n * p.in_fs, in_bytes);
+        const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
+
+        // per-lane offsets: A row of each M-tile (VAD_OOB outside the image -> zeros), B row / bias of each N-tile
+        unsigned ao[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = y0 + 2 * mt + prow, x = x0 + pcol;
+            ao[mt] = (y < H && x < W) ? (unsigned)(__mul24(__mul24(y, W) + x, p.cin) + (PREC ? 8 : 4) * lh) * 4u : VAD_OOB;
+        }
+        unsigned bo[NT];
+        int qd[NT], co[NT];
+        f32x16 acc[MT][NT], corr[PREC ? MT : 1][PREC ? NT : 1];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int g = ng * NT + nt;
+            qd[nt] = g / ctiles;
+            co[nt] = (g % ctiles) * 32 + li;
+            bo[nt] = (unsigned)qd[nt] * wq + (unsigned)co[nt] * (PREC ? 64u : 32u) + (PREC ? 32u : 16u) * lh;
+            const float bv = p.bias[co[nt]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[mt][nt][r] = bv;
+                    if constexpr (PREC) corr[mt][nt][r] = 0.f;
+                }
+        }
+
+        if constexpr (PREC) {
+            f32x4 a0[2][MT], a1[2][MT];        // fp32 channels 8h..8h+3 / 8h+4..8h+7 of the k-step, double-buffered
+            f16x8 bh[2][NT], bl[2][NT];
+#define CT_LOAD(buf, ks)                                                                          \
+    {                                                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
+            a0[buf][mt] = vad_bload4(ra, ao[mt], (unsigned)(ks) * 64u);                           \
+            a1[buf][mt] = vad_bload4(ra, ao[mt], (unsigned)(ks) * 64u + 16u);                     \
+        }                                                                                         \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                       \
+            bh[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw, bo[nt], (unsigned)(ks) * wstep)); \
+            bl[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw, bo[nt] + 16u, (unsigned)(ks) * wstep)); \
+        }                                                                                         \
+    }
+            CT_LOAD(0, 0);
+            for (int ks = 0; ks < nk; ks += 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (ks + u < nk) {
+                        if (ks + u + 1 < nk) { if (u == 0) { CT_LOAD(1, ks + 1); } else { CT_LOAD(0, ks + 2); } }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            f16x8 ah, al;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                _Float16 h_, l_;
+                                vad_split(a0[u][mt][e], h_, l_); ah[e] = h_; al[e] = l_;
+                                vad_split(a1[u][mt][e], h_, l_); ah[4 + e] = h_; al[4 + e] = l_;
+                            }
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                acc[mt][nt] = MFMA16(ah, bh[u][nt], acc[mt][nt]);
+                                corr[mt][nt] = MFMA16(ah, bl[u][nt], corr[mt][nt]);
+                                corr[mt][nt] = MFMA16(al, bh[u][nt], corr[mt][nt]);
+                            }
+                        }
+                    }
+                }
+            }
+#undef CT_LOAD
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(corr[mt][nt][r], 0x1p-11f, acc[mt][nt][r]);
+        } else {
+            f32x4 a[2][MT], b[2][NT];
+#define CT_LOAD(buf, ks)                                                                          \
+    {                                                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) a[buf][mt] = vad_bload4(ra, ao[mt], (unsigned)(ks) * 32u); \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = vad_bload4(rw, bo[nt], (unsigned)(ks) * wstep); \
+    }
+            CT_LOAD(0, 0);
+            for (int ks = 0; ks < nk; ks += 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (ks + u < nk) {
+                        if (ks + u + 1 < nk) { if (u == 0) { CT_LOAD(1, ks + 1); } else { CT_LOAD(0, ks + 2); } }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[mt][nt] = MFMA32(a[u][mt][j], b[u][nt][j], acc[mt][nt]);
+                    }
+                }
+            }
+#undef CT_LOAD
+        }
+
+        // epilogue: D row = (r&3) + 8*(r>>2) + 4*lh -> pixel (prow = row>>4, pcol = row&15) of the M-tile
+        const bool full = (y0 + 2 * MT <= H) && (x0 + 16 <= W);
+        const unsigned erow = (unsigned)__mul24(ow, p.cout) * 4u, ecol = (unsigned)p.cout * 4u;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int qa = qd[nt] >> 1, qb = qd[nt] & 1;
+            // lane part: column 4*lh of the tile, this lane's channel; uniform part added per element below
+            constexpr int sc = 2;
+            const unsigned vlane = (unsigned)(__mul24(sc * 4 * lh, p.cout) + co[nt]) * 4u;
+            const unsigned ubase = ((unsigned)__mul24(sc * y0 + qa, ow) + (unsigned)(sc * x0 + qb)) * ecol;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dy = 2 * mt + (r >> 3), dx = (r & 3) + 8 * ((r >> 2) & 1);      // + 4*lh in the lane part
+                    const bool ok = full || ((y0 + dy) < H && (x0 + dx + 4 * lh) < W);
+                    const unsigned so = ubase + (unsigned)(sc * dy) * erow + (unsigned)(sc * dx) * ecol;
+                    vad_bstore1(vad_act(acc[mt][nt][r], ACT), ro, ok ? vlane : VAD_OOB, so);
+                }
+            }
+        }
+    }
+}
