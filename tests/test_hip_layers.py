@@ -78,8 +78,19 @@ def test_conv3x3_no_bn_and_frame_strides():
 
 @pytest.mark.parametrize("cin,cout,h,w,act", [(256, 128, 4, 4, 2), (128, 64, 8, 6, 2), (64, 32, 16, 16, 2),
                                               (32, 32, 9, 13, 2), (32, 64, 3, 5, 0), (128, 128, 2, 2, 1)])
-def test_convt2x2(cin, cout, h, w, act):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_convt2x2(vad, cin, cout, h, w, act, precision):
+    """precision 1 = split-fp16 operands (weights packed AND kernels launched under vad_set_precision(1))."""
     import hip_helpers as H
+    l = vad.hip.lib()
+    assert l.vad_set_precision(precision) == 0
+    try:
+        _check_convt2x2(H, cin, cout, h, w, act)
+    finally:
+        l.vad_set_precision(0)
+
+
+def _check_convt2x2(H, cin, cout, h, w, act):
     rng = _rng(cin + cout * 7 + h)
     x = rng.standard_normal((3, cin, h, w)).astype(np.float32)
     wt = (rng.standard_normal((cin, cout, 2, 2)) * np.sqrt(1.0 / cin)).astype(np.float32)

@@ -714,29 +714,37 @@ extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, co
     p.w = w; p.bias = bias; p.out = out;
     p.out_fs = out_fs ? out_fs : (long long)4 * h * wd * cout;
     p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.npix = (long long)n * h * wd;
-    if (g_vad_conv_variant == 0) return launch_convt<1>(p, act, (hipStream_t)stream);
+    if (g_vad_conv_variant == 0 && g_vad_precision == 0) return launch_convt<1>(p, act, (hipStream_t)stream);
     // wave-persistent LDS-free kernel (convt_pkernel.h): 32-bit offsets inside one frame
     VAD_REQUIRE(4ll * h * wd * cout * 4 < (1ll << 31) && (long long)h * wd * cin * 4 < (1ll << 31) && 4ll * cin * cout * 4 < (1ll << 31),
                 "convt2x2: frame %dx%d (cin %d, cout %d) too large for 32-bit offsets", h, wd, cin, cout);
     ConvTP2 q{};
     q.in = p.in; q.in_fs = p.in_fs; q.w = w; q.bias = bias; q.out = out; q.out_fs = p.out_fs;
     q.n = n; q.h = h; q.w_ = wd; q.cin = cin; q.cout = cout;
-    constexpr int MT = 2, NT = 4;
-    q.tiles_x = (wd + 15) / 16; q.tiles_y = (h + 2 * MT - 1) / (2 * MT);
-    q.ngroups = 4 * cout / (32 * NT);
+    const int prec = g_vad_precision == 1;           // split-fp16 operands: two accumulator sets, so half the columns per wave
+    // wave tile 2 x 4 (exact) measured best of {2x4, 1x4, 2x2, 1x2}: dec4.0 2.18 / 2.47 / 2.28 / 2.78 us per frame
+    const int mt = 2, nt = prec ? 2 : 4;
+    q.tiles_x = (wd + 15) / 16; q.tiles_y = (h + 2 * mt - 1) / (2 * mt);
+    q.ngroups = 4 * cout / (32 * nt);
     const long long items = (long long)n * q.tiles_x * q.tiles_y * q.ngroups;
     VAD_REQUIRE(items > 0 && items < (1ll << 31), "convt2x2: %lld work items out of range", items);
     q.nitems = (unsigned)items;
     const unsigned want = (unsigned)((items + 3) / 4);
-#define CT_LAUNCH(A)                                                                                         \
+#define CT_LAUNCH_(A, MT_, NT_, P)                                                                           \
     {                                                                                                        \
         static unsigned cap = 0;                                                                             \
-        if (!cap) cap = persistent_grid(convt2x2_pkernel<MT, NT, A, 0>, ~0u);                                \
-        hipLaunchKernelGGL((convt2x2_pkernel<MT, NT, A, 0>), dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, q); \
+        if (!cap) cap = persistent_grid(convt2x2_pkernel<MT_, NT_, A, P>, ~0u);                              \
+        hipLaunchKernelGGL((convt2x2_pkernel<MT_, NT_, A, P>), dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, q); \
+    }
+#define CT_LAUNCH(A)                                                                                         \
+    {                                                                                                        \
+        if (prec) CT_LAUNCH_(A, 2, 2, 1)                                                                     \
+        else CT_LAUNCH_(A, 2, 4, 0)                                                                          \
     }
     if (act == VAD_ACT_RELU) CT_LAUNCH(VAD_ACT_RELU)
     else if (act == VAD_ACT_LEAKY) CT_LAUNCH(VAD_ACT_LEAKY)
     else CT_LAUNCH(VAD_ACT_NONE)
+#undef CT_LAUNCH_
 #undef CT_LAUNCH
     VAD_LAUNCH_CHECK();
     return VAD_OK;

@@ -26,7 +26,7 @@ struct ConvTP2 {
 };
 
 template <int MT, int NT, int ACT, int PREC>
-__global__ __launch_bounds__(256, 2) void convt2x2_pkernel(ConvTP2 p) {
+__global__ __launch_bounds__(256, (MT * NT * (PREC ? 2 : 1) <= 4) ? 4 : 2) void convt2x2_pkernel(ConvTP2 p) {
     constexpr int KS = PREC ? 16 : 8;
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const unsigned gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;

@@ -41,7 +41,7 @@ static void bn_scale_shift(const float* bias, const float* const* bn, int cout,
     }
 }
 
-int g_vad_precision = 0;   // 0: exact fp32 MFMA; 1: split-fp16 (3 x fp16 MFMA, fp32 accumulate) for the 3x3 convolutions
+int g_vad_precision = 0;   // 0: exact fp32 MFMA; 1: split-fp16 (3 x fp16 MFMA, fp32 accumulate) for the 3x3 and transposed convolutions
 extern "C" int vad_set_precision(int mode) {
     REQ(mode == 0 || mode == 1, "set_precision: mode must be 0 (fp32) or 1 (split fp16)");
     g_vad_precision = mode;
@@ -118,6 +118,19 @@ extern "C" int vad_pack_convt2x2(const float* w, const float* bias, const float*
     REQ(w && out && bias_out && cout > 0 && cin > 0 && cin % 8 == 0, "pack_convt2x2: bad arguments");
     std::vector<double> s;
     bn_scale_shift(bias, bn, cout, s, bias_out);
+    if (g_vad_precision == 1 && cin % 16 == 0) {   // split-fp16 operands: [q][cin/16][cout][half h][8 x hi | 8 x lo]
+        _Float16* o = (_Float16*)out;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co)
+                for (int q = 0; q < 4; ++q) {
+                    const float v = (float)((double)w[((size_t)ci * cout + co) * 4 + q] * s[co]);
+                    const _Float16 hi = (_Float16)v, lo = (_Float16)((v - (float)hi) * 2048.0f);
+                    const size_t base = ((((size_t)q * (cin / 16) + ci / 16) * cout + co) * 2 + ((ci >> 3) & 1)) * 16;
+                    o[base + (ci & 7)] = hi;
+                    o[base + 8 + (ci & 7)] = lo;
+                }
+        return VAD_OK;
+    }
     for (int ci = 0; ci < cin; ++ci)
         for (int co = 0; co < cout; ++co)
             for (int q = 0; q < 4; ++q)
