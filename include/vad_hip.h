@@ -122,6 +122,16 @@ int vad_score_finalize(const float* partials, int nparts, int n, int h2, int w2,
 int vad_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, void* stream);
 int vad_nchw_to_nhwc(const float* in, float* out, int n, int h, int w, int c, void* stream);
 
+/* ------------------------------------------------------------------ criteria
+ * Replaces SSIMLoss.forward (utils/losses.py:51-93) and CombinedLoss.forward (utils/losses.py:114-121) for tensors
+ * that need no gradient: pred/target are `planes` = B*C contiguous H x W fp32 planes (NCHW), zero padding
+ * window_size/2, Gaussian sigma 1.5, C1 = 1e-4, C2 = 9e-4.  ONE pass over both inputs; no map is materialised.
+ * workspace: vad_ssim_workspace_floats(planes,h,w) floats (0 = unsupported shape).
+ * out3 (device): { 1 - mean(SSIM), mean((pred-target)^2), (1-alpha)*out3[1] + alpha*out3[0] }. */
+size_t vad_ssim_workspace_floats(long long planes, int h, int w);
+int vad_ssim_mse(const float* pred, const float* target, long long planes, int h, int w, int window_size,
+                 float alpha, float* workspace, float* out3, void* stream);
+
 /* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1]. */
 int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_frame, long long n,
                      int c, int h, int w, int anomalies, void* stream);

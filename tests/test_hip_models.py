@@ -293,3 +293,52 @@ def test_full_size_properties(vad):
         vo = v.score_all(xc)
     assert rel_err(vo["frame"].mean(dim=1).cpu().numpy(), vo["seq"].cpu().numpy()) < 2e-6
     assert rel_err(vo["errmap"].mean(dim=(2, 3, 4)).cpu().numpy(), vo["frame"].cpu().numpy()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ criteria (row f-4)
+
+def test_ssim_combined_losses_match_reference_golden(vad, golden):
+    """SSIMLoss / CombinedLoss through vad_ssim_mse against the REFERENCE's outputs (tests/golden/losses.npz,
+    utils/losses.py run by make_golden.py)."""
+    g = golden("losses.npz")
+    x = torch.from_numpy(vad.synth.frames(77, 0, 2, 3, 32, 32)).cuda()
+    y = torch.from_numpy(vad.synth.frames(78, 0, 2, 3, 32, 32)).cuda() * 0.25 + x * 0.75
+    n0 = vad.hip.calls.get("ssim", 0)
+    with torch.no_grad():
+        assert abs(float(vad.SSIMLoss()(y, x)) - float(g["ssim"])) < 2e-6
+        assert abs(float(vad.CombinedLoss(alpha=0.5)(y, x)) - float(g["combined"])) < 2e-6
+        assert abs(float(vad.CombinedLoss(alpha=0.3, window_size=7)(y, x)) - float(g["combined_03"])) < 2e-6
+    assert vad.hip.calls["ssim"] == n0 + 3
+
+
+
+@pytest.mark.parametrize("shape,window", [((1, 3, 256, 256), 11), ((3, 1, 37, 53), 11), ((2, 3, 7, 5), 11),
+                                          ((2, 2, 64, 33), 3), ((1, 3, 40, 40), 15), ((2, 3, 33, 64), 1)])
+def test_ssim_kernel_vs_torch_composition(vad, shape, window):
+    """Ragged sizes (tiles cut by the image edge, images smaller than the window) against the stock torch composition
+    of the same criterion evaluated on the CPU in fp64-free fp32, and the differentiable path is left untouched."""
+    rng = np.random.default_rng(shape[2] * 131 + window)
+    t = torch.from_numpy(rng.uniform(-1, 1, shape).astype(np.float32))
+    p = (t + torch.from_numpy(rng.normal(0, 0.2, shape).astype(np.float32))).clamp(-1, 1)
+    crit = vad.CombinedLoss(alpha=0.4, window_size=window)
+    crit.ssim.channels = shape[1]
+    crit.ssim.window = vad.losses._gaussian_window(window, shape[1])
+    ref = float(crit(p, t))                                     # CPU tensors -> torch composition
+    ref_ssim = float(crit.ssim(p, t))
+    with torch.no_grad():
+        got = float(crit(p.cuda(), t.cuda()))
+        got_ssim = float(crit.ssim(p.cuda(), t.cuda()))
+    assert abs(got - ref) < 1e-5 * max(1.0, abs(ref)) and abs(got_ssim - ref_ssim) < 1e-5
+    # gradient wanted -> autograd path on the GPU, same value
+    pg = p.cuda().requires_grad_(True)
+    n0 = vad.hip.calls.get("ssim", 0)
+    loss = crit(pg, t.cuda())
+    loss.backward()
+    assert vad.hip.calls.get("ssim", 0) == n0 and pg.grad is not None and abs(float(loss.detach()) - ref) < 1e-5
+
+
+
+def test_ssim_rejects_unsupported_window(vad):
+    x = torch.zeros(1, 3, 32, 32, device="cuda")
+    with torch.no_grad(), pytest.raises(vad.hip.VadError, match="window_size"):
+        vad.SSIMLoss(window_size=17)(x, x)

@@ -8,5 +8,6 @@ from . import hip, synth                                              # noqa: F4
 from .autoencoder import Autoencoder, ConvAutoencoder, Decoder, Encoder   # noqa: F401
 from .video_autoencoder import (ConvLSTM, ConvLSTMCell, VideoAutoencoder,    # noqa: F401
                                 VideoDecoder, VideoEncoder)
+from . import losses                                                   # noqa: F401
 from .losses import CombinedLoss, SSIMLoss                           # noqa: F401
 from . import scoring                                                 # noqa: F401

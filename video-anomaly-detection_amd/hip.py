@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
-SOURCES = ["conv_mfma.hip", "tail.hip", "vad_api.hip", "pack.cpp"]
+SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "vad_api.hip", "pack.cpp"]
 HEADERS = ["vad_common.h", "vad_layout.h"]
 
 VAD_OK = 0
@@ -80,6 +80,8 @@ SIGNATURES = {
     "vad_score_finalize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "vad_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_ssim_workspace_floats": (_sz, [_ll, _i, _i]),
+    "vad_ssim_mse": (_i, [_vp, _vp, _ll, _i, _i, _i, C.c_float, _vp, _vp, _vp]),
     "vad_synth_frames": (_i, [_vp, C.c_ulonglong, _ll, _ll, _i, _i, _i, _i, _vp]),
     "vad_img_packed_floats": (_sz, [_i, _i]),
     "vad_img_pack": (_i, [_vp, _i, _i, _i, _vp]),

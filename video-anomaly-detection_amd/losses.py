@@ -1,14 +1,19 @@
-"""Training criteria kept for API compatibility (reference utils/losses.py:14-121).
+"""`SSIMLoss` / `CombinedLoss` (reference utils/losses.py:14-121).
 
-`SSIMLoss` / `CombinedLoss` are used only by the reference's train.py (:149-158), never by an
-evaluate script, so they are not part of the HIP scoring path.
-They are stated here with plain torch ops so `from utils import CombinedLoss, SSIMLoss` keeps working.
+Two paths, chosen by what the caller needs:
+* evaluation (GPU tensors that need no gradient: `torch.no_grad()` or inputs without `requires_grad`) runs the fused
+  HIP pass `vad_ssim_mse` (csrc/ssim.hip): both inputs are read once, the five blurred maps and the SSIM map never
+  reach memory, one launch returns 1-SSIM, MSE and their combination;
+* the differentiable training criterion (reference train.py:149-158 back-propagates through it) stays the stock
+  torch composition, on any device, so autograd works exactly as in the reference.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import hip
 
 _C1, _C2 = 0.01 ** 2, 0.03 ** 2   # reference utils/losses.py:82-83
 _SIGMA = 1.5                      # reference utils/losses.py:37
@@ -21,6 +26,31 @@ def _gaussian_window(size: int, channels: int) -> torch.Tensor:
     return torch.outer(g, g).expand(channels, 1, size, size).contiguous()
 
 
+def _hip_eligible(pred: torch.Tensor, target: torch.Tensor) -> bool:
+    """GPU tensors, fp32 [B,C,H,W], same shape, no gradient wanted: the fused HIP pass applies."""
+    needs_grad = torch.is_grad_enabled() and (pred.requires_grad or target.requires_grad)
+    return (pred.is_cuda and target.is_cuda and not needs_grad and pred.dim() == 4 and pred.shape == target.shape
+            and pred.dtype == torch.float32 and target.dtype == torch.float32)
+
+
+def _hip_criteria(pred: torch.Tensor, target: torch.Tensor, window_size: int, alpha: float) -> torch.Tensor:
+    """-> device tensor [3] = (1 - mean SSIM, MSE, (1-alpha)*MSE + alpha*(1 - mean SSIM)); raises VadError if the
+    library is missing or the window is unsupported (there is no silent fallback on this path)."""
+    l = hip.lib()
+    pred, target = pred.contiguous(), target.contiguous()
+    b, c, h, w = pred.shape
+    n = l.vad_ssim_workspace_floats(b * c, h, w)
+    if n == 0:
+        raise hip.VadError(f"SSIM: unsupported shape {tuple(pred.shape)}")
+    ws = torch.empty(n, dtype=torch.float32, device=pred.device)
+    out = torch.empty(3, dtype=torch.float32, device=pred.device)
+    with torch.cuda.device(pred.device):
+        hip.check(l.vad_ssim_mse(pred.data_ptr(), target.data_ptr(), b * c, h, w, int(window_size), float(alpha),
+                                 ws.data_ptr(), out.data_ptr(), hip.current_stream()), "vad_ssim_mse")
+    hip.calls["ssim"] = hip.calls.get("ssim", 0) + 1
+    return out
+
+
 class SSIMLoss(nn.Module):
     """1 - mean SSIM with an 11x11 sigma-1.5 Gaussian window (reference utils/losses.py:14-93)."""
 
@@ -31,6 +61,8 @@ class SSIMLoss(nn.Module):
         self.window = _gaussian_window(window_size, channels)
 
     def forward(self, pred: torch.Tensor, target: torch.Tensor):
+        if _hip_eligible(pred, target):
+            return _hip_criteria(pred, target, self.window_size, 1.0)[0]
         if self.window.device != pred.device:
             self.window = self.window.to(pred.device)
         groups, pad, win = pred.shape[1], self.window_size // 2, self.window
@@ -56,4 +88,6 @@ class CombinedLoss(nn.Module):
         self.ssim = SSIMLoss(window_size=window_size)
 
     def forward(self, pred: torch.Tensor, target: torch.Tensor):
+        if _hip_eligible(pred, target):
+            return _hip_criteria(pred, target, self.ssim.window_size, float(self.alpha))[2]
         return (1 - self.alpha) * self.mse(pred, target) + self.alpha * self.ssim(pred, target)
