@@ -132,6 +132,74 @@ size_t vad_ssim_workspace_floats(long long planes, int h, int w);
 int vad_ssim_mse(const float* pred, const float* target, long long planes, int h, int w, int window_size,
                  float alpha, float* workspace, float* out3, void* stream);
 
+/* ------------------------------------------------------------------ training-step kernels
+ * The pieces of one optimisation step of train_video.py:44-65 (model.train(); MSELoss; backward; Adam), exact fp32,
+ * NHWC activations.  What the reference gets from autograd is stated here as explicit forward/backward kernels.
+ * All `ws` arguments are device scratch sized by the matching *_ws_floats function. */
+
+/* Per-channel reductions over an NHWC tensor [npix][c] (c multiple of 4, <= 1024). */
+size_t vad_chan_ws_floats(long long npix, int c);
+/* Train-mode nn.BatchNorm2d statistics (torch defaults eps 1e-5, momentum 0.1): stats[0..c) = batch mean,
+ * stats[c..2c) = 1/sqrt(biased var + eps); running_mean/var (nullable) updated with the unbiased variance. */
+int vad_bn_stats(const float* y, long long npix, int c, float eps, float momentum, float* stats,
+                 float* running_mean, float* running_var, float* ws, void* stream);
+/* out[c] = sum over pixels (bias gradients). */
+int vad_chan_sum(const float* g, long long npix, int c, float* out, float* ws, void* stream);
+/* BatchNorm(batch stats) + activation (+ MaxPool2d(2,2)) of a conv output y [n,h,w,c]
+ * (models/video_autoencoder.py:191-215,242-256 in train mode).  Destination element (frame, pixel, ch) is at
+ * out + F*out_fs + pixel*out_ps + ch, with F = frame, or (frame % T)*B + frame / T when remap_t = T > 0 (time-major
+ * ConvLSTM operand buffers).  out_fs / out_ps 0 = dense. */
+int vad_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out,
+                        long long out_fs, int out_ps, int remap_t, int remap_b, int n, int h, int w, int c,
+                        int act, int pool, void* stream);
+/* Backward of the above: dout is addressed like `out`.  dz [n,h,w,c] scratch (gradient after pool routing and act');
+ * dy = gradient of the conv output, dense NHWC or (s2d != 0) the space-to-depth view [n][h/2][w/2][4][c];
+ * dgamma/dbeta [c]; ksums [2c] scratch. */
+int vad_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+                        long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dz, float* dy, int s2d,
+                        float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
+                        int pool, void* stream);
+/* ConvLSTMCell gate math (models/video_autoencoder.py:73-83) on pre-activations z [nb*hw][4*hid] (order i,f,g,o): z is
+ * overwritten with the activated gates (kept for the backward), c_out = f*c_prev + i*g, h = o*tanh(c_out) written to up
+ * to two destinations (frame b, pixel q, channel j) -> h + b*fs + q*ps + j.  c_prev NULL = zeros. */
+int vad_lstm_gates_fwd(float* z, const float* c_prev, float* c_out, float* h1, long long h1_fs, int h1_ps,
+                       float* h2, long long h2_fs, int h2_ps, int nb, int hw, int hid, void* stream);
+/* Backward through the same step: dh = dh1 + dh2 (nullable sources), dc_next nullable -> dz (pre-activation gradients)
+ * and dc_prev (may alias dc_next). */
+int vad_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, const float* dh1, long long dh1_fs,
+                       int dh1_ps, const float* dh2, long long dh2_fs, int dh2_ps, const float* dc_next, float* dz,
+                       float* dc_prev, int nb, int hw, int hid, void* stream);
+/* Weight gradient GEMM, K = pixels: a [n,h,w,cin], g [n,h,w,ncols].
+ *   taps 9, layout 0: Conv2d k3 p1 weight gradient, dw OIHW (ncols, cin, 3, 3)
+ *   taps 1, layout 1: ConvTranspose2d k2 s2 weight gradient from the space-to-depth output gradient
+ *                     (ncols = 4*cout, column q*cout+co), dw IOHW (cin, cout, 2, 2)
+ *   taps 1, layout 3: ConvTranspose2d(32->3) from the 32-column dpre of vad_convt_to3_mse, dw (32, 3, 2, 2) */
+size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int ncols);
+int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
+                   int taps, int layout, void* stream);
+/* First-layer weight gradient: x NCHW [n,3,h,w], g [n,h,w,cout] -> dw OIHW (cout,3,3,3). */
+size_t vad_conv_c3_wgrad_ws_floats(int n, int h, int cout);
+int vad_conv_c3_wgrad(const float* x_nchw, const float* g, float* dw, float* ws, int n, int h, int w, int cout,
+                      void* stream);
+/* ConvTranspose2d(32->3,k2,s2)+Tanh+MSELoss(mean), forward and backward in one pass (models/video_autoencoder.py:259-260,
+ * train_video.py:54-55): in [n,h,w,32], weight IOHW (32,3,2,2) as stored by torch, x NCHW [n,3,2h,2w].
+ * loss[0] = mean((recon-x)^2); recon (NCHW), din [n,h,w,32], dpre32 [n*h*w][32] and dbias3 are optional outputs. */
+size_t vad_convt_to3_mse_ws_floats(int n, int h, int w);
+int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
+                      float* din, float* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w,
+                      void* stream);
+/* torch.optim.Adam step (train_video.py:175: weight_decay is L2 added to the gradient) over a flat buffer;
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int vad_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* Device-side operand packing of the CURRENT parameters (no BatchNorm folding in train mode):
+ * fwd = the forward kernels' order (vad_pack_conv3x3 / vad_pack_convt2x2 / vad_pack_conv3x3_c3 layouts);
+ * dgrad = the data-gradient operand: for conv3x3 a conv3x3 weight with cin/cout swapped and taps rotated (run it
+ * through vad_conv3x3), for convT a 1x1 weight with K = 4*cout (run vad_conv1x1 on the space-to-depth gradient). */
+int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
+int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream);
+int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* stream);
+
 /* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1]. */
 int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_frame, long long n,
                      int c, int h, int w, int anomalies, void* stream);

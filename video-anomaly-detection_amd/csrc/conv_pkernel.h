@@ -26,27 +26,6 @@ __device__ __forceinline__ float pf_get_f(f32x4 v) { return v[0]; }
 __device__ __forceinline__ f32x4 pf_get_v(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 pf_get_v(float v) { return f32x4{v, v, v, v}; }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// Buffer descriptor for [p, p + bytes): loads past the end return 0 and stores past the end are dropped, which
-// is how zero padding and partial tiles are handled without branches (invalid elements get offset 0x80000000).
-// The pointer halves go through readfirstlane so hipcc can prove the descriptor wave-uniform (no waterfall loops).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t vad_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 vad_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ float vad_bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ void vad_bstore1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
-}
-constexpr unsigned VAD_OOB = 0x80000000u;   // byte offset no frame reaches (host checks frames < 2^31 bytes)
-
 #ifdef VAD_STAMPS
 #define STAMP(k)                                                                                      \
     {                                                                                                 \

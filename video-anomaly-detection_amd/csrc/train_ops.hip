@@ -1,0 +1,830 @@
+// Training-step kernels (reference train_video.py:44-65), gfx950, exact fp32.
+//
+// The reference's step is stock autograd over models/video_autoencoder.py in train() mode.  Here the same arithmetic
+// is stated as explicit kernels on NHWC activations:
+//   * train-mode BatchNorm2d (batch statistics over N*H*W, eps 1e-5, momentum 0.1, unbiased running variance):
+//     per-channel sums with wave/LDS reductions and a fixed-order fp64 finalize, then ONE fused
+//     normalise + activation (+ MaxPool2d) pass; backward in two passes (route the pooled gradient, apply act',
+//     accumulate sum(dz), sum(dz*xhat); then dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)))
+//   * conv / convT weight gradients as one MFMA GEMM (M = input channels, N = output channels, K = pixels) with a
+//     deterministic split-K (partials + fixed-order reduce straight into the torch OIHW / IOHW layouts)
+//   * conv data gradients reuse the forward implicit-GEMM kernels on re-packed (rotated / transposed) weights;
+//     convT data gradients are a 1x1 GEMM over the space-to-depth view that the BatchNorm backward writes directly
+//   * ConvLSTM gate non-linearities + state update, forward and backward (BPTT), as pointwise kernels
+//   * ConvTranspose2d(32->3) + Tanh + MSELoss forward AND backward in one pass over the last activation
+//   * Adam with L2 weight decay folded into the gradient (torch.optim.Adam semantics) over ONE flat parameter buffer.
+#include <hip/hip_runtime.h>
+
+#include "vad_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+__device__ __forceinline__ long long view_frame(int n, int t, int b) { return t > 0 ? (long long)(n % t) * b + n / t : n; }
+
+// Reduce two per-thread float4 channel accumulators over the pixel rows of a 256-thread block; thread = (row, c4).
+__device__ __forceinline__ void block_chan_reduce(f32x4 s0, f32x4 s1, int c, float* dst /*[2][c]*/) {
+    __shared__ f32x4 red[2][256];
+    const int tid = threadIdx.x, cg = c >> 2, rows = 256 / cg;
+    red[0][tid] = s0;
+    red[1][tid] = s1;
+    __syncthreads();
+    if (tid < cg) {
+        f32x4 a = red[0][tid], b = red[1][tid];
+        for (int r = 1; r < rows; ++r) { a += red[0][r * cg + tid]; b += red[1][r * cg + tid]; }
+        *(f32x4*)&dst[4 * tid] = a;
+        *(f32x4*)&dst[c + 4 * tid] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ channel sums
+// ws[block][0][c] = sum over the block's pixels of v, ws[block][1][c] = sum of v*v
+__global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long long npix, int c, long long chunk, float* ws) {
+    const int tid = threadIdx.x, cg = c >> 2, rows = 256 / cg, row = tid / cg, c4 = tid - row * cg;
+    const long long p0 = (long long)blockIdx.x * chunk, p1 = (p0 + chunk < npix) ? p0 + chunk : npix;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (row < rows)
+        for (long long p = p0 + row; p < p1; p += rows) {
+            const f32x4 v = *(const f32x4*)&y[p * c + 4 * c4];
+            s0 += v;
+            s1 += v * v;
+        }
+    block_chan_reduce(s0, s1, c, ws + (size_t)blockIdx.x * 2 * c);
+}
+
+// mode 0: BatchNorm statistics -> stats[0][c] = mean, stats[1][c] = 1/sqrt(var_biased + eps); running stats updated
+//         like torch (momentum; unbiased variance) when given
+// mode 1: BatchNorm backward sums -> dgamma = sum(dz*xhat), dbeta = sum(dz), stats = {sum(dz)/M, sum(dz*xhat)/M}
+// mode 2: plain sums -> dbeta[c] = sum (bias gradients)
+__global__ __launch_bounds__(256) void chan_finalize_kernel(const float* ws, int nblocks, int c, double count, int mode,
+                                                            float eps, float momentum, float* stats, float* running_mean,
+                                                            float* running_var, float* dgamma, float* dbeta) {
+    for (int ch = blockIdx.x * 256 + threadIdx.x; ch < c; ch += gridDim.x * 256) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblocks; ++b) {
+            s += (double)ws[(size_t)b * 2 * c + ch];
+            q += (double)ws[(size_t)b * 2 * c + c + ch];
+        }
+        if (mode == 0) {
+            const double mean = s / count;
+            double var = q / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            stats[ch] = (float)mean;
+            stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
+                running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
+            }
+        } else if (mode == 1) {
+            dbeta[ch] = (float)s;
+            dgamma[ch] = (float)q;
+            stats[ch] = (float)(s / count);
+            stats[c + ch] = (float)(q / count);
+        } else {
+            dbeta[ch] = (float)s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm forward
+struct BnFwdP {
+    const float* y; const float* stats; const float* gamma; const float* beta;
+    float* out; long long out_fs; int out_ps, t, b;
+    int n, h, w, c, act, pool;
+    long long total;      // n * oh * ow * c/4
+};
+
+__device__ __forceinline__ f32x4 bn_apply(f32x4 y, f32x4 mean, f32x4 invstd, f32x4 gamma, f32x4 beta, int act) {
+    f32x4 v = ((y - mean) * invstd) * gamma + beta;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = vad_act(v[e], act);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
+    const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % cg);
+        long long pix = idx / cg;
+        const int x = (int)(pix % ow); pix /= ow;
+        const int y = (int)(pix % oh);
+        const int n = (int)(pix / oh);
+        const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
+        const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
+        const float* src = p.y + (size_t)n * p.h * p.w * p.c + 4 * c4;
+        f32x4 v;
+        if (p.pool) {
+            const size_t o = ((size_t)(2 * y) * p.w + 2 * x) * p.c;
+            v = bn_apply(*(const f32x4*)&src[o], mean, invstd, gamma, beta, p.act);
+            const f32x4 v1 = bn_apply(*(const f32x4*)&src[o + p.c], mean, invstd, gamma, beta, p.act);
+            const f32x4 v2 = bn_apply(*(const f32x4*)&src[o + (size_t)p.w * p.c], mean, invstd, gamma, beta, p.act);
+            const f32x4 v3 = bn_apply(*(const f32x4*)&src[o + (size_t)p.w * p.c + p.c], mean, invstd, gamma, beta, p.act);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(v[e], v1[e]), fmaxf(v2[e], v3[e]));
+        } else {
+            v = bn_apply(*(const f32x4*)&src[((size_t)y * p.w + x) * p.c], mean, invstd, gamma, beta, p.act);
+        }
+        *(f32x4*)&p.out[view_frame(n, p.t, p.b) * p.out_fs + ((size_t)y * ow + x) * p.out_ps + 4 * c4] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm backward
+struct BnBwdP {
+    const float* y; const float* stats; const float* gamma; const float* beta;
+    const float* dout; long long dout_fs; int dout_ps, t, b;
+    float* dz;            // dense NHWC at the conv's resolution
+    float* ws;
+    int n, h, w, c, act, pool;
+    long long opix, chunk;   // pooled-resolution pixels (n*oh*ow), per block
+};
+
+__device__ __forceinline__ float act_grad(float v, int act) {
+    if (act == VAD_ACT_LEAKY) return v > 0.f ? 1.f : 0.2f;
+    if (act == VAD_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// pass A: dz = d(out) routed through MaxPool (first maximum in window scan order, like torch) and act'; partial sums
+__global__ __launch_bounds__(256) void bn_bwd_route_kernel(BnBwdP p) {
+    const int tid = threadIdx.x, cg = p.c >> 2, rows = 256 / cg, row = tid / cg, c4 = tid - row * cg;
+    const int oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w;
+    const long long p0 = (long long)blockIdx.x * p.chunk, p1 = (p0 + p.chunk < p.opix) ? p0 + p.chunk : p.opix;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (row < rows) {
+        const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
+        const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
+        for (long long q = p0 + row; q < p1; q += rows) {
+            const int x = (int)(q % ow), y = (int)((q / ow) % oh), n = (int)(q / ((long long)ow * oh));
+            const f32x4 g = *(const f32x4*)&p.dout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4];
+            const size_t fbase = (size_t)n * p.h * p.w * p.c + 4 * c4;
+            if (p.pool) {
+                const size_t o0 = fbase + ((size_t)(2 * y) * p.w + 2 * x) * p.c;
+                const size_t o1 = o0 + p.c, o2 = o0 + (size_t)p.w * p.c, o3 = o2 + p.c;
+                const f32x4 y0 = *(const f32x4*)&p.y[o0], y1 = *(const f32x4*)&p.y[o1], y2 = *(const f32x4*)&p.y[o2], y3 = *(const f32x4*)&p.y[o3];
+                f32x4 d0, d1, d2, d3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh[4] = {(y0[e] - mean[e]) * invstd[e], (y1[e] - mean[e]) * invstd[e],
+                                         (y2[e] - mean[e]) * invstd[e], (y3[e] - mean[e]) * invstd[e]};
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = vad_act(xh[k] * gamma[e] + beta[e], p.act);
+                    int am = 0;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) if (v[k] > v[am]) am = k;
+                    const float gz = g[e] * act_grad(v[am], p.act);
+                    d0[e] = am == 0 ? gz : 0.f; d1[e] = am == 1 ? gz : 0.f; d2[e] = am == 2 ? gz : 0.f; d3[e] = am == 3 ? gz : 0.f;
+                    s0[e] += gz;
+                    s1[e] += gz * xh[am];
+                }
+                *(f32x4*)&p.dz[o0] = d0; *(f32x4*)&p.dz[o1] = d1; *(f32x4*)&p.dz[o2] = d2; *(f32x4*)&p.dz[o3] = d3;
+            } else {
+                const size_t o = fbase + ((size_t)y * p.w + x) * p.c;
+                const f32x4 yv = *(const f32x4*)&p.y[o];
+                f32x4 d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (yv[e] - mean[e]) * invstd[e];
+                    const float v = vad_act(xh * gamma[e] + beta[e], p.act);
+                    d[e] = g[e] * act_grad(v, p.act);
+                    s0[e] += d[e];
+                    s1[e] += d[e] * xh;
+                }
+                *(f32x4*)&p.dz[o] = d;
+            }
+        }
+    }
+    block_chan_reduce(s0, s1, p.c, p.ws + (size_t)blockIdx.x * 2 * p.c);
+}
+
+// pass B: dy = gamma * invstd * (dz - k1 - xhat * k2); s2d != 0 writes the space-to-depth view [n][h/2][w/2][4][c]
+// (the operand layout of the transposed convolution's data / weight gradients)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* y, const float* stats, const float* gamma, const float* k,
+                                                           const float* dz, float* dy, int n, int h, int w, int c, int s2d,
+                                                           long long total) {
+    const int cg = c >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % cg);
+        const long long pix = idx / cg;
+        const f32x4 mean = *(const f32x4*)&stats[4 * c4], invstd = *(const f32x4*)&stats[c + 4 * c4];
+        const f32x4 ga = *(const f32x4*)&gamma[4 * c4], k1 = *(const f32x4*)&k[4 * c4], k2 = *(const f32x4*)&k[c + 4 * c4];
+        const f32x4 yv = *(const f32x4*)&y[pix * c + 4 * c4], d = *(const f32x4*)&dz[pix * c + 4 * c4];
+        const f32x4 r = (ga * invstd) * (d - k1 - ((yv - mean) * invstd) * k2);
+        if (s2d) {
+            const int x = (int)(pix % w), yy = (int)((pix / w) % h);
+            const long long nn = pix / ((long long)w * h);
+            const size_t o = (((size_t)nn * (h / 2) + yy / 2) * (w / 2) + x / 2) * 4 * c + ((yy & 1) * 2 + (x & 1)) * c + 4 * c4;
+            *(f32x4*)&dy[o] = r;
+        } else {
+            *(f32x4*)&dy[pix * c + 4 * c4] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ConvLSTM pointwise
+struct LstmFwdP {
+    float* z;                 // [npix][4*hid]: pre-activations in, activated gates (i, f, g, o) out
+    const float* c_prev;      // [npix][hid] or null (zeros)
+    float* c_out;             // [npix][hid]
+    float* h1; long long h1_fs; int h1_ps;     // destination 1 of h (frame b, pixel, channel) or null
+    float* h2; long long h2_fs; int h2_ps;     // destination 2 or null
+    int hw, hid;
+    long long total;          // nb * hw * hid/4
+};
+
+__global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(LstmFwdP p) {
+    const int hg = p.hid >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
+        const int j4 = (int)(idx % hg);
+        const long long pix = idx / hg;
+        float* zz = p.z + pix * 4 * p.hid + 4 * j4;
+        f32x4 gi = *(f32x4*)&zz[0], gf = *(f32x4*)&zz[p.hid], gg = *(f32x4*)&zz[2 * p.hid], go = *(f32x4*)&zz[3 * p.hid];
+        f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+        if (p.c_prev) cp = *(const f32x4*)&p.c_prev[pix * p.hid + 4 * j4];
+        f32x4 cn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gi[e] = vad_sigmoid(gi[e]); gf[e] = vad_sigmoid(gf[e]); gg[e] = vad_tanh(gg[e]); go[e] = vad_sigmoid(go[e]);
+            cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
+            hn[e] = go[e] * vad_tanh(cn[e]);
+        }
+        *(f32x4*)&zz[0] = gi; *(f32x4*)&zz[p.hid] = gf; *(f32x4*)&zz[2 * p.hid] = gg; *(f32x4*)&zz[3 * p.hid] = go;
+        *(f32x4*)&p.c_out[pix * p.hid + 4 * j4] = cn;
+        const long long b = pix / p.hw, q = pix - b * p.hw;
+        if (p.h1) *(f32x4*)&p.h1[b * p.h1_fs + q * p.h1_ps + 4 * j4] = hn;
+        if (p.h2) *(f32x4*)&p.h2[b * p.h2_fs + q * p.h2_ps + 4 * j4] = hn;
+    }
+}
+
+struct LstmBwdP {
+    const float* gates;       // [npix][4*hid] activated
+    const float* c_prev;      // null = zeros
+    const float* c;           // [npix][hid]
+    const float* dh1; long long dh1_fs; int dh1_ps;   // gradient sources for h (either may be null)
+    const float* dh2; long long dh2_fs; int dh2_ps;
+    const float* dc_next;     // null = zeros
+    float* dz;                // [npix][4*hid]
+    float* dc_prev;           // [npix][hid] (may alias dc_next)
+    int hw, hid;
+    long long total;
+};
+
+__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(LstmBwdP p) {
+    const int hg = p.hid >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
+        const int j4 = (int)(idx % hg);
+        const long long pix = idx / hg, b = pix / p.hw, q = pix - b * p.hw;
+        const float* gz = p.gates + pix * 4 * p.hid + 4 * j4;
+        const f32x4 gi = *(const f32x4*)&gz[0], gf = *(const f32x4*)&gz[p.hid], gg = *(const f32x4*)&gz[2 * p.hid], go = *(const f32x4*)&gz[3 * p.hid];
+        const f32x4 c = *(const f32x4*)&p.c[pix * p.hid + 4 * j4];
+        f32x4 cp = {0.f, 0.f, 0.f, 0.f}, dh = cp, dcn = cp;
+        if (p.c_prev) cp = *(const f32x4*)&p.c_prev[pix * p.hid + 4 * j4];
+        if (p.dh1) dh += *(const f32x4*)&p.dh1[b * p.dh1_fs + q * p.dh1_ps + 4 * j4];
+        if (p.dh2) dh += *(const f32x4*)&p.dh2[b * p.dh2_fs + q * p.dh2_ps + 4 * j4];
+        if (p.dc_next) dcn = *(const f32x4*)&p.dc_next[pix * p.hid + 4 * j4];
+        f32x4 di, df, dg, dgo, dcp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float tc = vad_tanh(c[e]);
+            const float dc = dcn[e] + dh[e] * go[e] * (1.f - tc * tc);
+            dgo[e] = dh[e] * tc * go[e] * (1.f - go[e]);
+            di[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
+            df[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+            dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
+            dcp[e] = dc * gf[e];
+        }
+        float* dzp = p.dz + pix * 4 * p.hid + 4 * j4;
+        *(f32x4*)&dzp[0] = di; *(f32x4*)&dzp[p.hid] = df; *(f32x4*)&dzp[2 * p.hid] = dg; *(f32x4*)&dzp[3 * p.hid] = dgo;
+        *(f32x4*)&p.dc_prev[pix * p.hid + 4 * j4] = dcp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+// dW[tap][ci][col] = sum over (n, y, x) of A[n, y+dy-1, x+dx-1, ci] * G[n, y, x, col]   (TAPS == 9: 3x3, pad 1)
+// dW[ci][col]      = sum over pixels of A[pix][ci] * G[pix][col]                        (TAPS == 1)
+// One wave owns a 32 (ci) x 32*NT (col) tile of every tap and a slice of the image rows (split-K); each
+// v_mfma_f32_32x32x2_f32 consumes two horizontally adjacent pixels: lane (li, lh) feeds A[pixel lh][ci li] and
+// G[pixel lh][col li], both 128-byte coalesced rows of the NHWC tensors.  Partials go to ws[split][tap][ci][col].
+struct WgradP {
+    const float* a; const float* g; float* ws;
+    int n, h, w, cin, ncols;
+    int ci_tiles, col_groups, splits, rows_per_split;
+    unsigned nitems;
+};
+
+template <int TAPS, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= p.nitems) return;
+    const int ct = item % p.ci_tiles; item /= p.ci_tiles;
+    const int cgp = item % p.col_groups;
+    const int split = item / p.col_groups;
+    const int H = p.h, W = p.w, total_rows = p.n * H;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * 4u;
+    f32x16 acc[TAPS][NT];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.f;
+
+    for (int row = r0; row < r1; ++row) {
+        const int n = row / H, y = row - n * H;
+        const __amdgpu_buffer_rsrc_t ra = vad_rsrc(p.a + (size_t)n * H * W * p.cin, a_bytes);
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n * H * W * p.ncols, g_bytes);
+        for (int x = 0; x < W; x += 2) {
+            const int px = x + lh;
+            float bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bv[nt] = vad_bload1(rg, px < W ? (unsigned)(((y * W + px) * p.ncols + (cgp * NT + nt) * 32 + li) * 4) : VAD_OOB, 0);
+            float av[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
+                const int yy = y + dy, xx = px + dx;
+                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && px < W;
+                av[t] = vad_bload1(ra, ok ? (unsigned)(((yy * W + xx) * p.cin + ct * 32 + li) * 4) : VAD_OOB, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = MFMA32(av[t], bv[nt], acc[t][nt]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                p.ws[(((size_t)split * TAPS + t) * p.cin + ci) * p.ncols + (cgp * NT + nt) * 32 + li] = acc[t][nt][r];
+            }
+}
+
+// First layer (input NCHW, 3 channels): M index k = c*9 + tap (27, padded to 32), A gathered from the input planes.
+struct WgradC3P {
+    const float* x; const float* g; float* ws;
+    int n, h, w, cout, splits, rows_per_split;
+    unsigned nitems;
+};
+
+__global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= p.nitems) return;
+    const int ctiles = p.cout / 32;
+    const int cgp = item % ctiles;
+    const int split = item / ctiles;
+    const int H = p.h, W = p.w, total_rows = p.n * H;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const int c = li / 9, tap = li - c * 9, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const unsigned x_bytes = (unsigned)(3 * H * W) * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.cout * 4u;
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    for (int row = r0; row < r1; ++row) {
+        const int n = row / H, y = row - n * H;
+        const __amdgpu_buffer_rsrc_t rx = vad_rsrc(p.x + (size_t)n * 3 * H * W, x_bytes);
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n * H * W * p.cout, g_bytes);
+        const int yy = y + dy;
+        const bool rowok = li < 27 && yy >= 0 && yy < H;
+        for (int x = 0; x < W; x += 4) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int px = x + 2 * u + lh, xx = px + dx;
+                const float bv = vad_bload1(rg, px < W ? (unsigned)(((y * W + px) * p.cout + cgp * 32 + li) * 4) : VAD_OOB, 0);
+                const float av = vad_bload1(rx, (rowok && xx >= 0 && xx < W && px < W) ? (unsigned)(((c * H + yy) * W + xx) * 4) : VAD_OOB, 0);
+                acc[u] = MFMA32(av, bv, acc[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        p.ws[((size_t)split * 32 + k) * p.cout + cgp * 32 + li] = acc[0][r] + acc[1][r];
+    }
+}
+
+// Fixed-order sum of the split-K partials, written in the torch parameter layout.
+//   layout 0: Conv2d OIHW            dst[(col*cin + ci)*9 + tap]                       (taps 9)
+//   layout 1: ConvTranspose2d IOHW   col = q*cout + co -> dst[(ci*cout + co)*4 + q]    (taps 1, ncols = 4*cout)
+//   layout 2: first layer OIHW       rows k = c*9+tap of 32 -> dst[col*27 + k], k < 27 (taps 1, cin = 32 rows)
+//   layout 3: ConvTranspose2d(->3)   col = q*3 + c < 12 -> dst[(ci*3 + c)*4 + q]       (taps 1, ncols = 32)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int splits, int taps, int cin, int ncols, int layout,
+                                                           float* dst) {
+    const long long total = (long long)taps * cin * ncols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + idx];
+        const int col = (int)(idx % ncols), ci = (int)((idx / ncols) % cin), tap = (int)(idx / ((long long)ncols * cin));
+        if (layout == 0) dst[((size_t)col * cin + ci) * 9 + tap] = s;
+        else if (layout == 1) { const int cout = ncols / 4, q = col / cout, co = col - q * cout; dst[((size_t)ci * cout + co) * 4 + q] = s; }
+        else if (layout == 2) { if (ci < 27) dst[(size_t)col * 27 + ci] = s; }
+        else if (col < 12) { const int q = col / 3, c = col - q * 3; dst[((size_t)ci * 3 + c) * 4 + q] = s; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ last layer + loss
+// ConvTranspose2d(32->3, k2 s2) + Tanh + MSELoss, forward and backward in one pass (models/video_autoencoder.py:259-260,
+// train_video.py:54-55): per input pixel the 4x3 outputs, their squared error against x, d(pre-activation) and the
+// gradient with respect to the 32 input channels.  dpre is also written as the 32-column GEMM operand of the weight
+// gradient (columns q*3+c, 12..31 zero).
+struct To3P {
+    const float* in; const float* w; const float* bias; const float* x;
+    float* recon; float* din; float* dpre; float* loss_parts;
+    int n, h, w_;           // input resolution (output is 2h x 2w)
+    float gscale;           // 2 / (n * 3 * 2h * 2w)
+    long long total;
+};
+
+__global__ __launch_bounds__(256) void convt_to3_mse_kernel(To3P p) {
+    __shared__ float ws[32 * 12], bs[3], red[4];
+    for (int i = threadIdx.x; i < 384; i += 256) ws[i] = p.w[i];     // [ci][c][q]
+    if (threadIdx.x < 3) bs[threadIdx.x] = p.bias[threadIdx.x];
+    __syncthreads();
+    float lsum = 0.f;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < p.total) {
+        const int x = (int)(idx % p.w_), y = (int)((idx / p.w_) % p.h);
+        const long long n = idx / ((long long)p.w_ * p.h);
+        float r[32];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 v = *(const f32x4*)&p.in[idx * 32 + 4 * k];
+            r[4 * k] = v[0]; r[4 * k + 1] = v[1]; r[4 * k + 2] = v[2]; r[4 * k + 3] = v[3];
+        }
+        float dp[12];       // index q*3 + c
+        const int H2 = 2 * p.h, W2 = 2 * p.w_;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float pre = bs[c];
+#pragma unroll
+                for (int ci = 0; ci < 32; ++ci) pre = fmaf(r[ci], ws[ci * 12 + c * 4 + q], pre);
+                const float rec = vad_tanh(pre);
+                const size_t xo = (((size_t)n * 3 + c) * H2 + 2 * y + (q >> 1)) * W2 + 2 * x + (q & 1);
+                const float d = rec - p.x[xo];
+                if (p.recon) p.recon[xo] = rec;
+                lsum = fmaf(d, d, lsum);
+                dp[q * 3 + c] = p.gscale * d * (1.f - rec * rec);
+            }
+        if (p.din) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) s = fmaf(dp[q * 3 + c], ws[(4 * k + e) * 12 + c * 4 + q], s);
+                    o[e] = s;
+                }
+                *(f32x4*)&p.din[idx * 32 + 4 * k] = o;
+            }
+        }
+        if (p.dpre) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (k < 3) o = f32x4{dp[4 * k], dp[4 * k + 1], dp[4 * k + 2], dp[4 * k + 3]};
+                *(f32x4*)&p.dpre[idx * 32 + 4 * k] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) p.loss_parts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// loss = sum(parts)/count (fixed order); optionally db[c] = sum_q colsum[q*3+c]
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* parts, int nparts, double count, float* loss,
+                                                            const float* colsum32, float* dbias3) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)parts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / count);
+    if (dbias3 && threadIdx.x < 3)
+        dbias3[threadIdx.x] = (colsum32[threadIdx.x] + colsum32[3 + threadIdx.x]) + (colsum32[6 + threadIdx.x] + colsum32[9 + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+// torch.optim.Adam (train_video.py:175): g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float sqrt_bc2, float gscale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float pv = p[i];
+        const float gv = g[i] * gscale + wd * pv;
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        p[i] = pv - (lr / bc1) * (mv / (sqrtf(vv) / sqrt_bc2 + eps));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ operand packing
+// torch layouts -> the kernels' MFMA operand orders, on the device (the parameters change every step)
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad) {
+    const long long total = (long long)cout * cin * 9;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int tap = (int)(idx % 9), ci = (int)((idx / 9) % cin), co = (int)(idx / (9ll * cin));
+        const float v = w[idx];
+        if (fwd) fwd[(((size_t)tap * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
+        // data gradient = the same convolution with the taps rotated by 180 degrees and the channel roles swapped
+        if (dgrad) dgrad[(((size_t)(8 - tap) * (cout / 8) + co / 8) * cin + ci) * 8 + (co & 7)] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int cin, int cout, float* fwd, float* dgrad) {
+    const long long total = (long long)cin * cout * 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int q = (int)(idx & 3), co = (int)((idx >> 2) % cout), ci = (int)(idx / (4ll * cout));
+        const float v = w[idx];
+        if (fwd) fwd[(((size_t)q * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
+        // data gradient = 1x1 convolution over the space-to-depth gradient: K index q*cout+co, N index ci
+        if (dgrad) { const int kk = q * cout + co; dgrad[(((size_t)(kk / 8)) * cin + ci) * 8 + (kk & 7)] = v; }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_conv3x3_c3_kernel(const float* w, int cout, float* fwd) {
+    const int total = 28 * cout;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int co = idx % cout, k = idx / cout;
+        fwd[idx] = k < 27 ? w[(size_t)co * 27 + k] : 0.f;
+    }
+}
+
+unsigned grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+// ================================================================================================ host entry points
+static long long stats_chunk(long long npix) {
+    long long chunk = 4096;
+    if ((npix + chunk - 1) / chunk > 1024) chunk = (npix + 1023) / 1024;
+    return chunk;
+}
+
+extern "C" size_t vad_chan_ws_floats(long long npix, int c) {
+    if (npix <= 0 || c <= 0) return 0;
+    const long long chunk = stats_chunk(npix);
+    return (size_t)((npix + chunk - 1) / chunk) * 2 * c;
+}
+
+static bool chan_ok(int c) { return c >= 4 && c % 4 == 0 && c <= 1024; }
+
+extern "C" int vad_bn_stats(const float* y, long long npix, int c, float eps, float momentum, float* stats,
+                            float* running_mean, float* running_var, float* ws, void* stream) {
+    VAD_REQUIRE(y && stats && ws && npix > 0 && chan_ok(c), "bn_stats: bad arguments (c=%d)", c);
+    VAD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running_mean/var must come together");
+    const long long chunk = stats_chunk(npix);
+    const int nb = (int)((npix + chunk - 1) / chunk);
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, npix, c, chunk, ws);
+    VAD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
+                       (double)npix, 0, eps, momentum, stats, running_mean, running_var, (float*)nullptr, (float*)nullptr);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_chan_sum(const float* g, long long npix, int c, float* out, float* ws, void* stream) {
+    VAD_REQUIRE(g && out && ws && npix > 0 && chan_ok(c), "chan_sum: bad arguments (c=%d)", c);
+    const long long chunk = stats_chunk(npix);
+    const int nb = (int)((npix + chunk - 1) / chunk);
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, npix, c, chunk, ws);
+    VAD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
+                       (double)npix, 2, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, out);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out,
+                                   long long out_fs, int out_ps, int remap_t, int remap_b, int n, int h, int w, int c,
+                                   int act, int pool, void* stream) {
+    VAD_REQUIRE(y && stats && gamma && beta && out && n > 0 && h > 0 && w > 0 && chan_ok(c), "bn_act_pool_fwd: bad arguments");
+    VAD_REQUIRE(act >= 0 && act <= 2 && (!pool || (h % 2 == 0 && w % 2 == 0)), "bn_act_pool_fwd: bad act/pool");
+    VAD_REQUIRE(remap_t == 0 || (remap_b > 0 && n == remap_t * remap_b), "bn_act_pool_fwd: n must equal T*B with a frame remap");
+    const int oh = pool ? h / 2 : h, ow = pool ? w / 2 : w;
+    BnFwdP p{y, stats, gamma, beta, out, out_fs ? out_fs : (long long)oh * ow * (out_ps ? out_ps : c), out_ps ? out_ps : c,
+             remap_t, remap_b, n, h, w, c, act, pool, (long long)n * oh * ow * (c / 4)};
+    VAD_REQUIRE(p.out_ps % 4 == 0 && p.out_fs % 4 == 0, "bn_act_pool_fwd: strides must be multiples of 4 floats");
+    hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
+                                   long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dz, float* dy, int s2d,
+                                   float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
+                                   int pool, void* stream) {
+    VAD_REQUIRE(y && stats && gamma && beta && dout && dz && dy && dgamma && dbeta && ksums && ws, "bn_act_pool_bwd: null pointer");
+    VAD_REQUIRE(n > 0 && h > 0 && w > 0 && chan_ok(c) && act >= 0 && act <= 2, "bn_act_pool_bwd: bad arguments");
+    VAD_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "bn_act_pool_bwd: pooling needs even H, W");
+    VAD_REQUIRE(!s2d || (h % 2 == 0 && w % 2 == 0 && dy != dz), "bn_act_pool_bwd: space-to-depth output needs even H, W and dy != dz");
+    VAD_REQUIRE(remap_t == 0 || (remap_b > 0 && n == remap_t * remap_b), "bn_act_pool_bwd: n must equal T*B with a frame remap");
+    const int oh = pool ? h / 2 : h, ow = pool ? w / 2 : w;
+    BnBwdP p{};
+    p.y = y; p.stats = stats; p.gamma = gamma; p.beta = beta; p.dout = dout;
+    p.dout_ps = dout_ps ? dout_ps : c;
+    p.dout_fs = dout_fs ? dout_fs : (long long)oh * ow * p.dout_ps;
+    p.t = remap_t; p.b = remap_b; p.dz = dz; p.ws = ws; p.n = n; p.h = h; p.w = w; p.c = c; p.act = act; p.pool = pool;
+    p.opix = (long long)n * oh * ow;
+    p.chunk = stats_chunk(p.opix);
+    VAD_REQUIRE(p.dout_ps % 4 == 0 && p.dout_fs % 4 == 0, "bn_act_pool_bwd: strides must be multiples of 4 floats");
+    const int nb = (int)((p.opix + p.chunk - 1) / p.chunk);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_route_kernel, dim3(nb), dim3(256), 0, s, p);
+    VAD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const float*)ws, nb, c,
+                       (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta);
+    VAD_LAUNCH_CHECK();
+    const long long total = (long long)n * h * w * (c / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, y, stats, gamma, (const float*)ksums,
+                       (const float*)dz, dy, n, h, w, c, s2d, total);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_lstm_gates_fwd(float* z, const float* c_prev, float* c_out, float* h1, long long h1_fs, int h1_ps,
+                                  float* h2, long long h2_fs, int h2_ps, int nb, int hw, int hid, void* stream) {
+    VAD_REQUIRE(z && c_out && nb > 0 && hw > 0 && hid > 0 && hid % 4 == 0, "lstm_gates_fwd: bad arguments");
+    LstmFwdP p{z, c_prev, c_out, h1, h1_fs ? h1_fs : (long long)hw * (h1_ps ? h1_ps : hid), h1_ps ? h1_ps : hid,
+               h2, h2_fs ? h2_fs : (long long)hw * (h2_ps ? h2_ps : hid), h2_ps ? h2_ps : hid, hw, hid, (long long)nb * hw * (hid / 4)};
+    hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, const float* dh1, long long dh1_fs,
+                                  int dh1_ps, const float* dh2, long long dh2_fs, int dh2_ps, const float* dc_next, float* dz,
+                                  float* dc_prev, int nb, int hw, int hid, void* stream) {
+    VAD_REQUIRE(gates && c && dz && dc_prev && nb > 0 && hw > 0 && hid > 0 && hid % 4 == 0, "lstm_gates_bwd: bad arguments");
+    LstmBwdP p{gates, c_prev, c, dh1, dh1_fs ? dh1_fs : (long long)hw * (dh1_ps ? dh1_ps : hid), dh1_ps ? dh1_ps : hid,
+               dh2, dh2_fs ? dh2_fs : (long long)hw * (dh2_ps ? dh2_ps : hid), dh2_ps ? dh2_ps : hid, dc_next, dz, dc_prev,
+               hw, hid, (long long)nb * hw * (hid / 4)};
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// split-K factor: enough waves to fill the chip (~4096), never more splits than image rows
+static int wgrad_splits(long long tiles, int total_rows) {
+    long long s = (4096 + tiles - 1) / tiles;
+    if (s > total_rows) s = total_rows;
+    if (s > 2048) s = 2048;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int ncols) {
+    if (n <= 0 || h <= 0 || cin <= 0 || ncols <= 0 || cin % 32 || ncols % 32 || (taps != 9 && taps != 1)) return 0;
+    const int nt = (taps == 1 && ncols % 128 == 0) ? 4 : 1;
+    const long long tiles = (long long)(cin / 32) * (ncols / (32 * nt));
+    return (size_t)wgrad_splits(tiles, n * h) * taps * cin * ncols;
+}
+
+extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
+                              int taps, int layout, void* stream) {
+    VAD_REQUIRE(a && g && dw && ws && n > 0 && h > 0 && w > 0, "conv_wgrad: bad arguments");
+    VAD_REQUIRE(cin % 32 == 0 && ncols % 32 == 0 && cin > 0 && ncols > 0, "conv_wgrad: cin=%d ncols=%d must be multiples of 32", cin, ncols);
+    VAD_REQUIRE((taps == 9 && layout == 0) || (taps == 1 && (layout == 1 || layout == 3)), "conv_wgrad: taps/layout mismatch");
+    VAD_REQUIRE(layout != 1 || ncols % 128 == 0, "conv_wgrad: convT gradient needs ncols = 4*cout");
+    VAD_REQUIRE(layout != 3 || (ncols == 32), "conv_wgrad: to3 gradient needs 32 columns");
+    VAD_REQUIRE((long long)h * w * cin * 4 < (1ll << 31) && (long long)h * w * ncols * 4 < (1ll << 31), "conv_wgrad: frame too large for 32-bit offsets");
+    WgradP p{};
+    p.a = a; p.g = g; p.ws = ws; p.n = n; p.h = h; p.w = w; p.cin = cin; p.ncols = ncols;
+    const int nt = (taps == 1 && ncols % 128 == 0) ? 4 : 1;
+    p.ci_tiles = cin / 32; p.col_groups = ncols / (32 * nt);
+    const long long tiles = (long long)p.ci_tiles * p.col_groups;
+    p.splits = wgrad_splits(tiles, n * h);
+    p.rows_per_split = (n * h + p.splits - 1) / p.splits;
+    p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;     // no empty splits
+    const long long items = tiles * p.splits;
+    VAD_REQUIRE(items < (1ll << 31), "conv_wgrad: too many work items");
+    p.nitems = (unsigned)items;
+    const dim3 grid((unsigned)((items + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (taps == 9) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), grid, dim3(256), 0, s, p);
+    else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
+    VAD_LAUNCH_CHECK();
+    const long long total = (long long)taps * cin * ncols;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" size_t vad_conv_c3_wgrad_ws_floats(int n, int h, int cout) {
+    if (n <= 0 || h <= 0 || cout <= 0 || cout % 32) return 0;
+    return (size_t)wgrad_splits(cout / 32, n * h) * 32 * cout;
+}
+
+extern "C" int vad_conv_c3_wgrad(const float* x_nchw, const float* g, float* dw, float* ws, int n, int h, int w, int cout,
+                                 void* stream) {
+    VAD_REQUIRE(x_nchw && g && dw && ws && n > 0 && h > 0 && w > 0 && cout > 0 && cout % 32 == 0, "conv_c3_wgrad: bad arguments");
+    VAD_REQUIRE((long long)h * w * cout * 4 < (1ll << 31), "conv_c3_wgrad: frame too large for 32-bit offsets");
+    WgradC3P p{};
+    p.x = x_nchw; p.g = g; p.ws = ws; p.n = n; p.h = h; p.w = w; p.cout = cout;
+    p.splits = wgrad_splits(cout / 32, n * h);
+    p.rows_per_split = (n * h + p.splits - 1) / p.splits;
+    p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;
+    const long long items = (long long)(cout / 32) * p.splits;
+    p.nitems = (unsigned)items;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
+    VAD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(32ll * cout)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// ws = [nb loss partials][64: column sums of dpre][partials of that column reduction]
+extern "C" size_t vad_convt_to3_mse_ws_floats(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    const long long total = (long long)n * h * w;
+    return (size_t)((total + 255) / 256) + 64 + vad_chan_ws_floats(total, 32);
+}
+
+extern "C" int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
+                                 float* din, float* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w,
+                                 void* stream) {
+    VAD_REQUIRE(in_nhwc && w_iohw && bias3 && x_nchw && loss && ws && n > 0 && h > 0 && w > 0, "convt_to3_mse: bad arguments");
+    VAD_REQUIRE(!dbias3 || dpre32, "convt_to3_mse: the bias gradient needs the dpre buffer");
+    const long long total = (long long)n * h * w;
+    const long long nb = (total + 255) / 256;
+    VAD_REQUIRE(nb < (1ll << 31), "convt_to3_mse: grid too large");
+    const double count = (double)n * 3.0 * (2.0 * h) * (2.0 * w);
+    To3P p{in_nhwc, w_iohw, bias3, x_nchw, recon, din, dpre32, ws, n, h, w, (float)(2.0 / count), total};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(convt_to3_mse_kernel, dim3((unsigned)nb), dim3(256), 0, s, p);
+    VAD_LAUNCH_CHECK();
+    float* colsum = ws + nb;
+    if (dbias3) {
+        const long long chunk = stats_chunk(total);
+        const int cb = (int)((total + chunk - 1) / chunk);
+        float* cws = ws + nb + 64;
+        hipLaunchKernelGGL(chan_sums_kernel, dim3(cb), dim3(256), 0, s, (const float*)dpre32, total, 32, chunk, cws);
+        VAD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(chan_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)cws, cb, 32, (double)total, 2, 0.f, 0.f,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, colsum);
+        VAD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)nb, count, loss,
+                       (const float*)colsum, dbias3);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    VAD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream) {
+    VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv3x3: bad arguments");
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(9ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream) {
+    VAD_REQUIRE(w_iohw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || (4 * cout) % 8 == 0), "train_pack_convt2x2: bad arguments");
+    hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* stream) {
+    VAD_REQUIRE(w_oihw && fwd && cout > 0, "train_pack_conv3x3_c3: bad arguments");
+    hipLaunchKernelGGL(pack_conv3x3_c3_kernel, dim3(grid_for(28ll * cout)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, fwd);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}

@@ -45,6 +45,27 @@ __device__ __forceinline__ float vad_act(float v, int act) {
 __device__ __forceinline__ float vad_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 __device__ __forceinline__ float vad_tanh(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor for [p, p + bytes): loads past the end return 0 and stores past the end are dropped, which
+// is how zero padding and partial tiles are handled without branches (invalid elements get offset 0x80000000).
+// The pointer halves go through readfirstlane so hipcc can prove the descriptor wave-uniform (no waterfall loops).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vad_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 vad_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float vad_bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void vad_bstore1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+constexpr unsigned VAD_OOB = 0x80000000u;   // byte offset no frame reaches (host checks frames < 2^31 bytes)
+
 // Input formats of the ORIGINAL frames handed to the model-level entry points.
 //   VAD_X_F32_NCHW : float32 [N,3,H,W], already normalised to [-1,1] (what the reference's datasets produce)
 //   VAD_X_U8_NHWC  : uint8 [N,H,W,3] as decoded; the kernels apply ToTensor + Normalize(0.5,0.5) themselves,

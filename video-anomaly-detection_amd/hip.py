@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
-SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "vad_api.hip", "pack.cpp"]
+SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "train_ops.hip", "vad_api.hip", "pack.cpp"]
 HEADERS = ["vad_common.h", "vad_layout.h"]
 
 VAD_OK = 0
@@ -53,6 +53,7 @@ _vp = C.c_void_p
 _ll = C.c_longlong
 _i = C.c_int
 _sz = C.c_size_t
+_f = C.c_float
 
 # name -> (restype, argtypes); every symbol of include/vad_hip.h
 SIGNATURES = {
@@ -82,6 +83,24 @@ SIGNATURES = {
     "vad_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_ssim_workspace_floats": (_sz, [_ll, _i, _i]),
     "vad_ssim_mse": (_i, [_vp, _vp, _ll, _i, _i, _i, C.c_float, _vp, _vp, _vp]),
+    "vad_chan_ws_floats": (_sz, [_ll, _i]),
+    "vad_bn_stats": (_i, [_vp, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "vad_chan_sum": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
+    "vad_bn_act_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_bn_act_pool_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                 _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_lstm_gates_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _vp]),
+    "vad_lstm_gates_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vad_conv_wgrad_ws_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "vad_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_conv_c3_wgrad_ws_floats": (_sz, [_i, _i, _i]),
+    "vad_conv_c3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_convt_to3_mse_ws_floats": (_sz, [_i, _i, _i]),
+    "vad_convt_to3_mse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vad_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "vad_train_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "vad_train_pack_convt2x2": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "vad_train_pack_conv3x3_c3": (_i, [_vp, _i, _vp, _vp]),
     "vad_synth_frames": (_i, [_vp, C.c_ulonglong, _ll, _ll, _i, _i, _i, _i, _vp]),
     "vad_img_packed_floats": (_sz, [_i, _i]),
     "vad_img_pack": (_i, [_vp, _i, _i, _i, _vp]),
