@@ -200,6 +200,25 @@ int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, f
 int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream);
 int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* stream);
 
+/* ------------------------------------------------------------------ whole training step (row f-1)
+ * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim ==
+ * latent_dim, lstm_num_layers): train-mode forward (batch-statistics BatchNorm, running stats updated when `running`
+ * is given), nn.MSELoss, and the full backward.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
+ * floats, torch layouts in named_parameters() order (see csrc/train_step.hip); running: vad_vid_train_nstats floats,
+ * {running_mean, running_var} per BatchNorm in module order.  x [B,T,3,H,W]; loss: device float[1];
+ * recon (nullable) [B,T,3,H,W].  Every gradient is overwritten (no accumulation), so there is no zero_grad.
+ * Follow with vad_adam_step on the same flat buffers (after the gradient all-reduce when data-parallel). */
+size_t vad_vid_train_nparams(int latent, int hid, int layers);
+size_t vad_vid_train_nstats(int latent, int hid, int layers);
+size_t vad_vid_train_workspace_bytes(int b, int t, int h, int w, int latent, int hid, int layers);
+/* Debug: float offsets of the saved forward buffers inside the training workspace (order documented at the definition in
+ * csrc/train_step.hip); returns the number of entries written to out[cap] or a negative VAD_ERR_*. */
+int vad_debug_set_train_stop(int stage);   /* debug: stop vad_vid_train_fwd_bwd after a backward stage (see csrc/train_step.hip) */
+int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent, int hid, int layers, long long* out, int cap);
+int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent, int hid, int layers,
+                          const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
+                          float* loss, float* recon, void* stream);
+
 /* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1]. */
 int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_frame, long long n,
                      int c, int h, int w, int anomalies, void* stream);

@@ -169,6 +169,37 @@ def init_fixture(name):
 
 
 
+def train_fixture(name, latent=32, layers=2, b=2, t=3, hw=32, wseed=61, xseed=161, steps=3, stride=7):
+    """Row f-1: the reference's own training step (train_video.py:44-65,175): VideoAutoencoder.train(), nn.MSELoss,
+    torch.optim.Adam(lr 1e-4, weight_decay 1e-5), `steps` steps on one seeded batch.  Stored: the losses, the norm and
+    a strided sample of every first-step gradient, a strided sample of the state dict after the last step."""
+    m = ref_vae.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    _load_synth(m, wseed)
+    m.train()
+    x = torch.from_numpy(synth.clips(xseed, 0, b, t, 3, hw, hw))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    crit = torch.nn.MSELoss()
+    arrays, losses = {}, []
+    for s in range(steps):
+        loss = crit(m(x), x)
+        opt.zero_grad()
+        loss.backward()
+        if s == 0:
+            keys = [k for k, _ in m.named_parameters()]
+            arrays["param_keys"] = np.array(keys)
+            arrays["grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+            for i, (_, p) in enumerate(m.named_parameters()):
+                arrays[f"grad_{i}"] = p.grad.detach().reshape(-1)[::stride].numpy().copy()
+        opt.step()
+        losses.append(float(loss.detach()))
+    st = m.state_dict()
+    arrays["state_keys"] = np.array(list(st.keys()))
+    for i, (k, v) in enumerate(st.items()):
+        arrays[f"state_{i}"] = (v.detach().reshape(-1)[::stride] if v.dim() else v.detach().reshape(1)).numpy().copy()
+    _save(name, losses=np.array(losses), latent=np.array(latent), layers=np.array(layers), b=np.array(b), t=np.array(t),
+          hw=np.array(hw), wseed=np.array(wseed), xseed=np.array(xseed), steps=np.array(steps), stride=np.array(stride), **arrays)
+
+
 def trained_fixture(name, latent=64, epochs=12):
     """Precision gate of SURVEY.md section 8(d): a TRAINED, low-residual model.  Recipe: the reference's own synthetic
     dataset generator (utils/download_data.py:85-184, loaded by file path; numpy + PIL only), its model class, Adam(lr
@@ -235,3 +266,4 @@ if __name__ == "__main__":
     losses_fixture("losses.npz")
     init_fixture("init.npz")
     trained_fixture("img_trained_l64.npz")
+    train_fixture("train_vid_l32.npz")

@@ -39,17 +39,24 @@ __device__ __forceinline__ void block_chan_reduce(f32x4 s0, f32x4 s1, int c, flo
 }
 
 // ------------------------------------------------------------------------------------------------ channel sums
-// ws[block][0][c] = sum over the block's pixels of v, ws[block][1][c] = sum of v*v
-__global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long long npix, int c, long long chunk, float* ws) {
+// ws[block][0][c] = sum over the block's pixels of (v - pivot[c]), ws[block][1][c] = sum of (v - pivot[c])^2.
+// pivot (nullable = 0) is a per-channel shift applied BEFORE squaring: BatchNorm statistics pass the channel's first
+// sample, so the variance is not formed as E[x^2] - mean^2 of the raw values (that cancels catastrophically in fp32 when
+// |mean| >> std: measured 5e-5 relative error in 1/std, enough to flip ReLU decisions in the layers that follow).
+__global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long long npix, int c, long long chunk, const float* pivot,
+                                                        float* ws) {
     const int tid = threadIdx.x, cg = c >> 2, rows = 256 / cg, row = tid / cg, c4 = tid - row * cg;
     const long long p0 = (long long)blockIdx.x * chunk, p1 = (p0 + chunk < npix) ? p0 + chunk : npix;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    if (row < rows)
+    if (row < rows) {
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (pivot) pv = *(const f32x4*)&pivot[4 * c4];
         for (long long p = p0 + row; p < p1; p += rows) {
-            const f32x4 v = *(const f32x4*)&y[p * c + 4 * c4];
+            const f32x4 v = *(const f32x4*)&y[p * c + 4 * c4] - pv;
             s0 += v;
             s1 += v * v;
         }
+    }
     block_chan_reduce(s0, s1, c, ws + (size_t)blockIdx.x * 2 * c);
 }
 
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long lon
 // mode 2: plain sums -> dbeta[c] = sum (bias gradients)
 __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* ws, int nblocks, int c, double count, int mode,
                                                             float eps, float momentum, float* stats, float* running_mean,
-                                                            float* running_var, float* dgamma, float* dbeta) {
+                                                            float* running_var, float* dgamma, float* dbeta, const float* pivot) {
     for (int ch = blockIdx.x * 256 + threadIdx.x; ch < c; ch += gridDim.x * 256) {
         double s = 0.0, q = 0.0;
         for (int b = 0; b < nblocks; ++b) {
@@ -67,8 +74,9 @@ __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* ws, int
             q += (double)ws[(size_t)b * 2 * c + c + ch];
         }
         if (mode == 0) {
-            const double mean = s / count;
-            double var = q / count - mean * mean;
+            const double sm = s / count;                     // mean of the shifted values
+            const double mean = (pivot ? (double)pivot[ch] : 0.0) + sm;
+            double var = q / count - sm * sm;
             if (var < 0.0) var = 0.0;
             stats[ch] = (float)mean;
             stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
@@ -601,10 +609,11 @@ extern "C" int vad_bn_stats(const float* y, long long npix, int c, float eps, fl
     VAD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running_mean/var must come together");
     const long long chunk = stats_chunk(npix);
     const int nb = (int)((npix + chunk - 1) / chunk);
-    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, npix, c, chunk, ws);
+    // pivot = the first pixel's channel vector (y[0..c)): a sample of each channel
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, npix, c, chunk, y, ws);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
-                       (double)npix, 0, eps, momentum, stats, running_mean, running_var, (float*)nullptr, (float*)nullptr);
+                       (double)npix, 0, eps, momentum, stats, running_mean, running_var, (float*)nullptr, (float*)nullptr, y);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -613,10 +622,10 @@ extern "C" int vad_chan_sum(const float* g, long long npix, int c, float* out, f
     VAD_REQUIRE(g && out && ws && npix > 0 && chan_ok(c), "chan_sum: bad arguments (c=%d)", c);
     const long long chunk = stats_chunk(npix);
     const int nb = (int)((npix + chunk - 1) / chunk);
-    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, npix, c, chunk, ws);
+    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, npix, c, chunk, (const float*)nullptr, ws);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
-                       (double)npix, 2, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, out);
+                       (double)npix, 2, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, out, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -659,7 +668,7 @@ extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const flo
     hipLaunchKernelGGL(bn_bwd_route_kernel, dim3(nb), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const float*)ws, nb, c,
-                       (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta);
+                       (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     const long long total = (long long)n * h * w * (c / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, y, stats, gamma, (const float*)ksums,
@@ -786,10 +795,10 @@ extern "C" int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, cons
         const long long chunk = stats_chunk(total);
         const int cb = (int)((total + chunk - 1) / chunk);
         float* cws = ws + nb + 64;
-        hipLaunchKernelGGL(chan_sums_kernel, dim3(cb), dim3(256), 0, s, (const float*)dpre32, total, 32, chunk, cws);
+        hipLaunchKernelGGL(chan_sums_kernel, dim3(cb), dim3(256), 0, s, (const float*)dpre32, total, 32, chunk, (const float*)nullptr, cws);
         VAD_LAUNCH_CHECK();
         hipLaunchKernelGGL(chan_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)cws, cb, 32, (double)total, 2, 0.f, 0.f,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, colsum);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, colsum, (const float*)nullptr);
         VAD_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)nb, count, loss,

@@ -1,0 +1,328 @@
+// One optimisation step of the ConvLSTM video autoencoder (reference train_video.py:44-65: model.train(); out = model(x);
+// loss = MSELoss(out, x); zero_grad; backward; Adam.step) as an explicit launch sequence over the kernels of
+// train_ops.hip and the forward convolution kernels.  Host orchestration only: no kernels in this file.
+//
+// Parameters live in ONE flat fp32 buffer in torch layouts and torch named_parameters() order, gradients in a buffer of
+// the same shape (the Python module's nn.Parameters are views into them), so the optimiser is one launch and a
+// data-parallel run needs one all-reduce.  Order (models/video_autoencoder.py:191-215, 299-316, 242-261):
+//   encoder.encoder.{0,4,8,12}: conv w (OIHW), conv b, then BatchNorm gamma, beta   channels 3->32->64->128->latent
+//   convlstm.cells.l.conv: w (4*hid, cin_l+hid, 3, 3), b                            cin_0 = latent, cin_l = hid
+//   decoder.decoder.{0,3,6}: convT w (IOHW), b, BatchNorm gamma, beta               latent->128->64->32
+//   decoder.decoder.9: convT w (32,3,2,2), b
+// Running statistics: one flat buffer, {running_mean[c], running_var[c]} per BatchNorm in the order above.
+//
+// Activation memory (fp32, per frame of H x W): every conv output before BatchNorm is kept (the backward recomputes
+// normalisation, activation and pooling from it), plus the pooled activations that feed the next conv and its weight
+// gradient: 30.4 MB per 256x256 frame; the ConvLSTM keeps its operand buffers [t][b][h][w][x|h], activated gates and
+// cell states for all t (BPTT).  Three scratch buffers of the largest activation size carry the gradients.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "vad_common.h"
+
+namespace {
+
+constexpr int ENC_C[5] = {3, 32, 64, 128, 0};    // [4] = latent
+constexpr int DEC_C[4] = {0, 128, 64, 32};       // [0] = latent
+
+struct Plan {
+    int B, T, H, W, L, Hd, NL, N, h16, w16, hw;
+    int encC[5], decC[4];
+    // parameter offsets (floats) into the flat buffer
+    size_t e_w[4], e_b[4], e_g[4], e_be[4];
+    size_t l_w[8], l_b[8];
+    size_t d_w[3], d_b[3], d_g[3], d_be[3];
+    size_t t_w, t_b, nparams;
+    size_t e_rs[4], d_rs[3], nstats;             // running stats offsets (mean at +0, var at +c)
+    // workspace offsets (floats)
+    size_t pk_e[4], pk_e_dg[4], pk_l[8], pk_l_dg[8], pk_d[3], pk_d_dg[3];
+    size_t y[4], a[3], st_e[4], cat[8], z[8], c[8], hseq, u[3], r[3], st_d[3], dpre;
+    size_t g[3], dcat[8], dzl[8], dc, ksums, zeros, chan_ws, wgrad_ws, to3_ws;
+    size_t ws_floats;
+    int lstm_cin(int l) const { return l == 0 ? L : Hd; }
+};
+
+size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16 || L <= 0 || L % 32 || Hd != L || NL < 1 || NL > 8) return false;
+    if ((long long)B * T > (1 << 20)) return false;
+    p.B = B; p.T = T; p.H = H; p.W = W; p.L = L; p.Hd = Hd; p.NL = NL; p.N = B * T;
+    p.h16 = H / 16; p.w16 = W / 16; p.hw = p.h16 * p.w16;
+    for (int i = 0; i < 5; ++i) p.encC[i] = ENC_C[i];
+    p.encC[4] = L;
+    for (int i = 0; i < 4; ++i) p.decC[i] = DEC_C[i];
+    p.decC[0] = L;
+    size_t o = 0, rs = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int ci = p.encC[k], co = p.encC[k + 1];
+        p.e_w[k] = o; o += (size_t)co * ci * 9;
+        p.e_b[k] = o; o += co;
+        p.e_g[k] = o; o += co;
+        p.e_be[k] = o; o += co;
+        p.e_rs[k] = rs; rs += 2 * (size_t)co;
+    }
+    for (int l = 0; l < NL; ++l) {
+        p.l_w[l] = o; o += (size_t)4 * Hd * (p.lstm_cin(l) + Hd) * 9;
+        p.l_b[l] = o; o += (size_t)4 * Hd;
+    }
+    for (int j = 0; j < 3; ++j) {
+        const int ci = p.decC[j], co = p.decC[j + 1];
+        p.d_w[j] = o; o += (size_t)ci * co * 4;
+        p.d_b[j] = o; o += co;
+        p.d_g[j] = o; o += co;
+        p.d_be[j] = o; o += co;
+        p.d_rs[j] = rs; rs += 2 * (size_t)co;
+    }
+    p.t_w = o; o += 32 * 3 * 4;
+    p.t_b = o; o += 3;
+    p.nparams = o;
+    p.nstats = rs;
+
+    // ---- workspace
+    size_t w = 0;
+    auto take = [&](size_t n) { const size_t at = w; w += align64(n); return at; };
+    const size_t N = (size_t)p.N;
+    size_t max_act = 0, max_chan = 0, max_wgrad = 0;
+    auto chan = [&](long long npix, int c) { const size_t v = vad_chan_ws_floats(npix, c); if (v > max_chan) max_chan = v; };
+    for (int k = 0; k < 4; ++k) {
+        const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
+        p.pk_e[k] = take(k == 0 ? vad_pack_conv3x3_c3_floats(co) : vad_pack_conv3x3_floats(co, ci));
+        p.pk_e_dg[k] = k == 0 ? 0 : take(vad_pack_conv3x3_floats(ci, co));
+        const size_t ysz = N * hk * wk * co;
+        p.y[k] = take(ysz);
+        if (ysz > max_act) max_act = ysz;
+        if (k < 3) p.a[k] = take(ysz / 4);
+        p.st_e[k] = take(2 * (size_t)co);
+        chan((long long)N * hk * wk, co);
+        const size_t wg = k == 0 ? vad_conv_c3_wgrad_ws_floats(p.N, hk, co) : vad_conv_wgrad_ws_floats(p.N, hk, 9, ci, co);
+        if (wg > max_wgrad) max_wgrad = wg;
+    }
+    for (int l = 0; l < NL; ++l) {
+        const int cin = p.lstm_cin(l) + Hd;
+        p.pk_l[l] = take(vad_pack_conv3x3_floats(4 * Hd, cin));
+        p.pk_l_dg[l] = take(vad_pack_conv3x3_floats(cin, 4 * Hd));
+        p.cat[l] = take(N * p.hw * cin);
+        p.z[l] = take(N * p.hw * 4 * Hd);
+        p.c[l] = take(N * p.hw * Hd);
+        p.dcat[l] = take(N * p.hw * cin);
+        p.dzl[l] = take(N * p.hw * 4 * Hd);
+        chan((long long)N * p.hw, 4 * Hd);
+        const size_t wg = vad_conv_wgrad_ws_floats(p.N, p.h16, 9, cin, 4 * Hd);
+        if (wg > max_wgrad) max_wgrad = wg;
+    }
+    p.dc = take((size_t)B * p.hw * Hd);
+    p.hseq = take(N * p.hw * Hd);
+    for (int j = 0; j < 3; ++j) {
+        const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
+        p.pk_d[j] = take(vad_pack_convt2x2_floats(ci, co));
+        p.pk_d_dg[j] = take(vad_pack_conv1x1_floats(ci, 4 * co));
+        const size_t usz = N * (size_t)(2 * hj) * (2 * wj) * co;
+        p.u[j] = take(usz);
+        p.r[j] = take(usz);
+        if (usz > max_act) max_act = usz;
+        p.st_d[j] = take(2 * (size_t)co);
+        chan((long long)N * 4 * hj * wj, co);
+        const size_t wg = vad_conv_wgrad_ws_floats(p.N, hj, 1, ci, 4 * co);
+        if (wg > max_wgrad) max_wgrad = wg;
+    }
+    {
+        const size_t wg = vad_conv_wgrad_ws_floats(p.N, H / 2, 1, 32, 32);
+        if (wg > max_wgrad) max_wgrad = wg;
+    }
+    p.dpre = take(N * (size_t)(H / 2) * (W / 2) * 32);
+    for (int i = 0; i < 3; ++i) p.g[i] = take(max_act);
+    p.ksums = take(2 * 1024);
+    p.zeros = take(1024);
+    p.chan_ws = take(max_chan);
+    p.wgrad_ws = take(max_wgrad);
+    p.to3_ws = take(vad_convt_to3_mse_ws_floats(p.N, H / 2, W / 2));
+    p.ws_floats = w;
+    return true;
+}
+
+}  // namespace
+
+// Debug: return from vad_vid_train_fwd_bwd right after the backward of decoder stage `j` (2, 1, 0), 10 + l after ConvLSTM
+// layer l, leaving the gradient scratch (g0 = gradient of that stage's input, g1 = dz, g2 = gradient of its conv output)
+// in the workspace for inspection (tools/diag_stream.py).  -1 = run the whole step (default).
+static int g_vad_train_stop = -1;
+extern "C" int vad_debug_set_train_stop(int stage) { g_vad_train_stop = stage; return VAD_OK; }
+
+#define TRY(expr)                    \
+    do {                             \
+        const int rc_ = (expr);      \
+        if (rc_ != VAD_OK) return rc_; \
+    } while (0)
+
+extern "C" size_t vad_vid_train_nparams(int latent, int hid, int layers) {
+    Plan p;
+    return make_plan(p, 1, 1, 16, 16, latent, hid, layers) ? p.nparams : 0;
+}
+
+extern "C" size_t vad_vid_train_nstats(int latent, int hid, int layers) {
+    Plan p;
+    return make_plan(p, 1, 1, 16, 16, latent, hid, layers) ? p.nstats : 0;
+}
+
+extern "C" size_t vad_vid_train_workspace_bytes(int b, int t, int h, int w, int latent, int hid, int layers) {
+    Plan p;
+    return make_plan(p, b, t, h, w, latent, hid, layers) ? p.ws_floats * sizeof(float) : 0;
+}
+
+// Debug: float offsets of the saved forward buffers inside the workspace, in the order
+//   y[0..3], a[0..2], st_e[0..3], cat[0..NL), z[0..NL), c[0..NL), hseq, u[0..2], r[0..2], st_d[0..2], dpre, g[0..2], ws_floats
+// (tools/diag_saved.py compares them with a float64 forward after a real step).  Returns the number written or < 0.
+extern "C" int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent, int hid, int layers, long long* out, int cap) {
+    Plan p;
+    VAD_REQUIRE(out && make_plan(p, b, t, h, w, latent, hid, layers), "vid_train_debug_layout: unsupported configuration");
+    std::vector<long long> v;
+    for (int k = 0; k < 4; ++k) v.push_back((long long)p.y[k]);
+    for (int k = 0; k < 3; ++k) v.push_back((long long)p.a[k]);
+    for (int k = 0; k < 4; ++k) v.push_back((long long)p.st_e[k]);
+    for (int l = 0; l < layers; ++l) v.push_back((long long)p.cat[l]);
+    for (int l = 0; l < layers; ++l) v.push_back((long long)p.z[l]);
+    for (int l = 0; l < layers; ++l) v.push_back((long long)p.c[l]);
+    v.push_back((long long)p.hseq);
+    for (int j = 0; j < 3; ++j) v.push_back((long long)p.u[j]);
+    for (int j = 0; j < 3; ++j) v.push_back((long long)p.r[j]);
+    for (int j = 0; j < 3; ++j) v.push_back((long long)p.st_d[j]);
+    v.push_back((long long)p.dpre);
+    for (int i = 0; i < 3; ++i) v.push_back((long long)p.g[i]);
+    v.push_back((long long)p.ws_floats);
+    VAD_REQUIRE((int)v.size() <= cap, "vid_train_debug_layout: need room for %d entries", (int)v.size());
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent, int hid, int layers,
+                                     const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
+                                     float* loss, float* recon, void* stream) {
+    VAD_REQUIRE(x && params && grads && workspace && loss, "vid_train_fwd_bwd: null pointer");
+    VAD_REQUIRE(vad_get_precision() == 0, "vid_train_fwd_bwd: training runs in exact fp32 (vad_set_precision(0))");
+    Plan p;
+    VAD_REQUIRE(make_plan(p, b, t, h, w, latent, hid, layers),
+                "vid_train_fwd_bwd: unsupported configuration (B=%d T=%d %dx%d latent=%d hid=%d layers=%d): H, W multiples of 16, "
+                "latent multiple of 32, lstm_hidden_dim == latent_dim, 1..8 layers", b, t, h, w, latent, hid, layers);
+    if (workspace_bytes < p.ws_floats * sizeof(float))
+        return vad_fail(VAD_ERR_WS, "vid_train_fwd_bwd: workspace %zu bytes < %zu needed", workspace_bytes, p.ws_floats * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const float* P = params;
+    float* G = grads;
+    const int N = p.N, B = p.B, T = p.T, H = p.H, W = p.W, L = p.L, Hd = p.Hd, NL = p.NL, hw = p.hw;
+    const float eps = 1e-5f, mom = 0.1f;     // nn.BatchNorm2d defaults (models/video_autoencoder.py:193)
+    float* zeros = ws + p.zeros;
+    VAD_HIP_TRY(hipMemsetAsync(zeros, 0, 1024 * sizeof(float), s));
+
+    // ---- operand packing of the current parameters
+    TRY(vad_train_pack_conv3x3_c3(P + p.e_w[0], 32, ws + p.pk_e[0], s));
+    for (int k = 1; k < 4; ++k)
+        TRY(vad_train_pack_conv3x3(P + p.e_w[k], p.encC[k + 1], p.encC[k], ws + p.pk_e[k], ws + p.pk_e_dg[k], s));
+    for (int l = 0; l < NL; ++l)
+        TRY(vad_train_pack_conv3x3(P + p.l_w[l], 4 * Hd, p.lstm_cin(l) + Hd, ws + p.pk_l[l], ws + p.pk_l_dg[l], s));
+    for (int j = 0; j < 3; ++j)
+        TRY(vad_train_pack_convt2x2(P + p.d_w[j], p.decC[j], p.decC[j + 1], ws + p.pk_d[j], ws + p.pk_d_dg[j], s));
+
+    // ================================================================================== forward
+    // encoder (models/video_autoencoder.py:191-215): conv -> BatchNorm(batch stats) -> LeakyReLU(0.2) -> MaxPool2
+    for (int k = 0; k < 4; ++k) {
+        const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
+        float* y = ws + p.y[k];
+        if (k == 0) TRY(vad_conv3x3_c3(x, ws + p.pk_e[0], P + p.e_b[0], y, N, hk, wk, co, VAD_ACT_NONE, 0, s));
+        else TRY(vad_conv3x3(ws + p.a[k - 1], 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, s));
+        float* rs = running ? running + p.e_rs[k] : nullptr;
+        TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
+        if (k < 3)
+            TRY(vad_bn_act_pool_fwd(y, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.a[k], 0, 0, 0, 0, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+        else   // latent features go straight into layer 0's operand buffers: frame b*T+t -> slot t*B+b, x-part
+            TRY(vad_bn_act_pool_fwd(y, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.cat[0], 0, L + Hd, T, B, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+    }
+    // ConvLSTM (models/video_autoencoder.py:153-163): layer by layer, step by step; h(-1) = c(-1) = 0
+    for (int l = 0; l < NL; ++l) {
+        const int cx = p.lstm_cin(l), cin = cx + Hd;
+        const size_t slab = (size_t)B * hw * cin;
+        // h-part of the t = 0 operand is the zero initial state (the x-part was / will be written by the producer)
+        VAD_HIP_TRY(hipMemset2DAsync(ws + p.cat[l] + cx, (size_t)cin * sizeof(float), 0, (size_t)Hd * sizeof(float), (size_t)B * hw, s));
+        for (int tt = 0; tt < T; ++tt) {
+            float* zt = ws + p.z[l] + (size_t)tt * B * hw * 4 * Hd;
+            float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
+            TRY(vad_conv3x3(ws + p.cat[l] + tt * slab, 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, s));
+            float* h1 = tt + 1 < T ? ws + p.cat[l] + (tt + 1) * slab + cx : nullptr;
+            float* h2; long long h2_fs; int h2_ps;
+            if (l + 1 < NL) { h2 = ws + p.cat[l + 1] + (size_t)tt * B * hw * 2 * Hd; h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
+            else { h2 = ws + p.hseq + (size_t)tt * hw * Hd; h2_ps = Hd; h2_fs = (long long)T * hw * Hd; }
+            TRY(vad_lstm_gates_fwd(zt, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, h1, (long long)hw * cin, cin, h2, h2_fs, h2_ps, B, hw, Hd, s));
+        }
+    }
+    // decoder (models/video_autoencoder.py:242-256): convT -> BatchNorm -> ReLU, three times
+    for (int j = 0; j < 3; ++j) {
+        const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
+        const float* in = j == 0 ? ws + p.hseq : ws + p.r[j - 1];
+        float* u = ws + p.u[j];
+        TRY(vad_convt2x2(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, s));
+        float* rs = running ? running + p.d_rs[j] : nullptr;
+        TRY(vad_bn_stats(u, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
+        TRY(vad_bn_act_pool_fwd(u, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], ws + p.r[j], 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
+    }
+    // last layer + loss, forward and backward (models/video_autoencoder.py:259-260, train_video.py:55)
+    float *g0 = ws + p.g[0], *g1 = ws + p.g[1], *g2 = ws + p.g[2];
+    TRY(vad_convt_to3_mse(ws + p.r[2], P + p.t_w, P + p.t_b, x, recon, g0, ws + p.dpre, loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, s));
+
+    if (g_vad_train_stop == 20) return VAD_OK;      // debug: g0 = gradient of the last decoder activation, dpre intact
+
+    // ================================================================================== backward
+    TRY(vad_conv_wgrad(ws + p.r[2], ws + p.dpre, G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, s));
+    for (int j = 2; j >= 0; --j) {
+        const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
+        const float* in = j == 0 ? ws + p.hseq : ws + p.r[j - 1];
+        // g0 = d r_j (dense, 2hj x 2wj) -> g2 = d u_j in the space-to-depth view [N][hj][wj][4*co]
+        TRY(vad_bn_act_pool_bwd(ws + p.u[j], ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g1, g2, 1, G + p.d_g[j], G + p.d_be[j],
+                                ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
+        TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, s));
+        TRY(vad_chan_sum(g2, (long long)N * hj * wj * 4, co, G + p.d_b[j], ws + p.chan_ws, s));
+        TRY(vad_conv1x1(g2, ws + p.pk_d_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, s));     // g0 = d (input of convT j)
+        if (g_vad_train_stop == j) return VAD_OK;
+    }
+    // g0 = d hseq [b*T+t][hw][Hd].  BPTT, top layer first.
+    for (int l = NL - 1; l >= 0; --l) {
+        const int cx = p.lstm_cin(l), cin = cx + Hd;
+        const size_t slab = (size_t)B * hw * cin;
+        float* dc = ws + p.dc;
+        for (int tt = T - 1; tt >= 0; --tt) {
+            const float* dh1; long long dh1_fs; int dh1_ps;
+            if (l == NL - 1) { dh1 = g0 + (size_t)tt * hw * Hd; dh1_ps = Hd; dh1_fs = (long long)T * hw * Hd; }
+            else { dh1 = ws + p.dcat[l + 1] + (size_t)tt * B * hw * 2 * Hd; dh1_ps = 2 * Hd; dh1_fs = (long long)hw * dh1_ps; }
+            const float* dh2 = tt + 1 < T ? ws + p.dcat[l] + (tt + 1) * slab + cx : nullptr;
+            float* dzt = ws + p.dzl[l] + (size_t)tt * B * hw * 4 * Hd;
+            const float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
+            TRY(vad_lstm_gates_bwd(ws + p.z[l] + (size_t)tt * B * hw * 4 * Hd, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
+                                   dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s));
+            TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, ws + p.dcat[l] + tt * slab, 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, s));
+        }
+        // weight / bias gradients of the cell's convolution over all steps at once (frames = T*B)
+        TRY(vad_conv_wgrad(ws + p.cat[l], ws + p.dzl[l], G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, s));
+        TRY(vad_chan_sum(ws + p.dzl[l], (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s));
+        if (g_vad_train_stop == 10 + l) return VAD_OK;
+    }
+    // encoder, last stage first; the x-part of layer 0's operand gradient is d(latent features)
+    for (int k = 3; k >= 0; --k) {
+        const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
+        if (k == 3)
+            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.dcat[0], 0, L + Hd, T, B, g1, g2, 0,
+                                    G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+        else
+            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, g1, g2, 0,
+                                    G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+        TRY(vad_chan_sum(g2, (long long)N * hk * wk, co, G + p.e_b[k], ws + p.chan_ws, s));
+        if (k == 0) {
+            TRY(vad_conv_c3_wgrad(x, g2, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
+        } else {
+            TRY(vad_conv_wgrad(ws + p.a[k - 1], g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, s));
+            TRY(vad_conv3x3(g2, 0, ws + p.pk_e_dg[k], zeros, g0, 0, N, hk, wk, co, ci, VAD_ACT_NONE, 0, s));
+        }
+    }
+    return VAD_OK;
+}

@@ -1,0 +1,132 @@
+"""Native training step for `VideoAutoencoder`.
+
+Replaces the body of the reference's `train_one_epoch` loop (train_video.py:50-60):
+
+    reconstructions = model(sequences); loss = criterion(reconstructions, sequences)      # nn.MSELoss
+    optimizer.zero_grad(); loss.backward(); optimizer.step()                              # Adam(lr, weight_decay=1e-5)
+
+with `loss = trainer.step(sequences)`: forward in train() semantics (batch-statistics BatchNorm, running stats and
+num_batches_tracked updated), MSE loss, the whole backward and the Adam update run as hand-written HIP kernels through
+`vad_vid_train_fwd_bwd` + `vad_adam_step` (csrc/train_step.hip, csrc/train_ops.hip); there is no autograd graph and no
+CPU fallback.  The model's `nn.Parameter`s and BatchNorm buffers are re-pointed to views of flat device buffers, so
+`state_dict()`, `load_state_dict()`, checkpoints and the eval-mode scoring path keep working on the same storage, the
+optimiser is one launch, and data-parallel training needs exactly one gradient all-reduce per step (RCCL through
+torch.distributed; BatchNorm statistics stay per rank, the reference has no SyncBN).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .video_autoencoder import VideoAutoencoder
+
+
+class VideoTrainer:
+    """Adam-on-MSE training steps for a `VideoAutoencoder` living on a GPU (exact fp32)."""
+
+    def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
+                 eps: float = 1e-8, process_group=None):
+        if not isinstance(model, VideoAutoencoder):
+            raise hip.VadError("VideoTrainer drives a VideoAutoencoder")
+        params = list(model.parameters())
+        if not params or not all(p.is_cuda for p in params):
+            raise hip.VadError("VideoTrainer needs the model on a GPU: model.cuda() first (there is no CPU fallback)")
+        if model.in_channels != 3 or model.lstm_hidden_dim != model.latent_dim:
+            raise hip.VadError("native training supports in_channels == 3 and lstm_hidden_dim == latent_dim "
+                               f"(got {model.in_channels}, {model.lstm_hidden_dim} vs {model.latent_dim})")
+        self.model, self.group = model, process_group
+        self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.device = params[0].device
+        l = hip.lib()
+        cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
+        n = l.vad_vid_train_nparams(*cfg)
+        if n == 0 or n != sum(p.numel() for p in params):
+            raise hip.VadError(f"native training does not support this configuration {cfg} "
+                               f"({sum(p.numel() for p in params)} parameters vs layout {n})")
+        self.cfg = cfg
+        # flat parameter / gradient / moment buffers; the module's parameters become views (named_parameters order ==
+        # the order train_step.hip documents: encoder, convlstm cells, decoder)
+        self.flat = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().reshape(-1).float())
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+        self.bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+        ns = l.vad_vid_train_nstats(*cfg)
+        if ns != sum(2 * m.num_features for m in self.bns):
+            raise hip.VadError("unexpected BatchNorm layout")
+        self.running = torch.empty(ns, dtype=torch.float32, device=self.device)
+        off = 0
+        for m in self.bns:
+            c = m.num_features
+            self.running[off:off + c].copy_(m.running_mean)
+            self.running[off + c:off + 2 * c].copy_(m.running_var)
+            m.running_mean = self.running[off:off + c]
+            m.running_var = self.running[off + c:off + 2 * c]
+            off += 2 * c
+        self.steps = 0
+        self._ws: Optional[torch.Tensor] = None
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _workspace(self, b, t, h, w) -> torch.Tensor:
+        nbytes = hip.lib().vad_vid_train_workspace_bytes(b, t, h, w, *self.cfg)
+        if nbytes == 0:
+            raise hip.VadError(f"unsupported training shape B={b} T={t} {h}x{w}: H and W must be multiples of 16")
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward_backward(self, clips: torch.Tensor, recon: bool = False):
+        """Loss and gradients of one batch (train-mode forward, MSE, full backward) without the optimiser update.
+        Returns (loss 0-dim device tensor, reconstruction or None); gradients are in `p.grad` of every parameter."""
+        if clips.dim() != 5 or clips.shape[2] != 3 or not clips.is_cuda:
+            raise hip.VadError(f"expected GPU clips [B,T,3,H,W], got {tuple(clips.shape)} on {clips.device}")
+        x = clips.contiguous().float()
+        b, t, _, h, w = x.shape
+        ws = self._workspace(b, t, h, w)
+        out = torch.empty_like(x) if recon else None
+        l = hip.lib()
+        with torch.cuda.device(self.device):
+            if l.vad_get_precision() != 0:
+                hip.check(l.vad_set_precision(0), "vad_set_precision")
+            hip.check(l.vad_vid_train_fwd_bwd(x.data_ptr(), b, t, h, w, *self.cfg, self.flat.data_ptr(), self.grad.data_ptr(),
+                                              self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._loss.data_ptr(),
+                                              hip.ptr(out), hip.current_stream()), "vad_vid_train_fwd_bwd")
+        for m in self.bns:
+            m.num_batches_tracked += 1
+        hip.calls["train_step"] = hip.calls.get("train_step", 0) + 1
+        return self._loss[0].clone(), out
+
+    def optimizer_step(self, grad_scale: float = 1.0) -> None:
+        """torch.optim.Adam semantics (L2 weight decay added to the gradient) over the flat buffers."""
+        self.steps += 1
+        with torch.cuda.device(self.device):
+            hip.check(hip.lib().vad_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), self.flat.numel(), self.lr, self.betas[0], self.betas[1],
+                                              self.eps, self.weight_decay, self.steps, float(grad_scale), hip.current_stream()),
+                      "vad_adam_step")
+        self.model._hip.key = None       # the eval-mode packed-weight cache is stale now
+
+    def step(self, clips: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on this rank's batch; with a process group the gradients are summed over ranks with ONE
+        all-reduce of the flat buffer and averaged inside the optimiser kernel (DistributedDataParallel semantics)."""
+        import torch.distributed as dist
+        loss, _ = self.forward_backward(clips)
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(self.group)
+            if world > 1:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+        self.optimizer_step(1.0 / world)
+        return loss
