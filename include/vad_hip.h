@@ -213,6 +213,10 @@ size_t vad_vid_train_nstats(int latent, int hid, int layers);
 size_t vad_vid_train_workspace_bytes(int b, int t, int h, int w, int latent, int hid, int layers);
 /* Debug: float offsets of the saved forward buffers inside the training workspace (order documented at the definition in
  * csrc/train_step.hip); returns the number of entries written to out[cap] or a negative VAD_ERR_*. */
+/* debug: record the branch decisions (pooling argmax, activation sign) of the following vad_bn_act_pool_bwd calls, one byte
+ * per output pixel and channel, consecutively into buf; (NULL, 0) stops.  See csrc/train_ops.hip. */
+int vad_debug_set_train_decisions(void* buf, size_t bytes);
+size_t vad_debug_train_decisions_used(void);
 int vad_debug_set_train_stop(int stage);   /* debug: stop vad_vid_train_fwd_bwd after a backward stage (see csrc/train_step.hip) */
 int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent, int hid, int layers, long long* out, int cap);
 int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent, int hid, int layers,

@@ -27,7 +27,8 @@ def _ws(n):
 
 
 @pytest.mark.parametrize("n,h,w,c,act,pool", [(3, 8, 12, 32, 1, 1), (2, 6, 6, 64, 2, 0), (5, 4, 4, 128, 1, 1),
-                                              (2, 16, 16, 96, 2, 0), (64, 32, 32, 32, 1, 1)])
+                                              (2, 16, 16, 96, 2, 0), (64, 32, 32, 32, 1, 1), (4, 56, 56, 32, 2, 0),
+                                              (4, 14, 14, 128, 2, 0), (4, 6, 10, 64, 1, 1)])
 def test_batchnorm_act_pool_forward_backward(vad, n, h, w, c, act, pool):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(n * 100 + c)
@@ -74,6 +75,26 @@ def test_batchnorm_act_pool_forward_backward(vad, n, h, w, c, act, pool):
                                             n, h, w, c, act, pool, H.stream()))
         ref = dy.view(n, h // 2, 2, w // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h // 2, w // 2, 4, c)
         assert torch.equal(dy2, ref)
+
+
+@pytest.mark.parametrize("mean,std", [(100.0, 0.1), (-30.0, 1.0), (0.0, 1.0), (1000.0, 3.0)])
+def test_batchnorm_statistics_survive_large_mean(vad, mean, std):
+    """Variance of a channel whose mean dwarfs its spread.  E[x^2] - mean^2 on the raw values cancels catastrophically in
+    fp32 (mean/std = 1000 leaves no correct digit); the kernel shifts by a per-channel sample before squaring.  This is the
+    defect that made the training step's BatchNorm outputs 10x less accurate than fp32 autograd's and flipped ReLU
+    decisions downstream (see tests/test_hip_train_step.py)."""
+    import hip_helpers as H
+    l, rng = vad.hip.lib(), _rng(int(abs(mean)) + 5)
+    n, h, w, c = 4, 14, 14, 64
+    y = (mean + std * rng.standard_normal((n, h, w, c))).astype(np.float32)
+    yd = H.dev(y)
+    stats, ws = _ws(2 * c), _ws(l.vad_chan_ws_floats(n * h * w, c))
+    vad.hip.check(l.vad_bn_stats(yd.data_ptr(), n * h * w, c, 1e-5, 0.1, stats.data_ptr(), None, None, ws.data_ptr(), H.stream()))
+    y64 = y.astype(np.float64).reshape(-1, c)
+    got = stats.cpu().numpy().astype(np.float64)
+    assert np.abs(got[:c] - y64.mean(0)).max() < 1e-6 * max(1.0, abs(mean), std)     # fp32 partial sums of ~100 shifted terms
+    want = 1.0 / np.sqrt(y64.var(0) + 1e-5)
+    assert np.abs(got[c:] / want - 1).max() < 2e-6, f"1/std off by {np.abs(got[c:] / want - 1).max():.2e}"
 
 
 def test_batchnorm_forward_time_major_strided_destination(vad):
@@ -152,7 +173,7 @@ def test_lstm_gates_forward_backward(vad, nb, hw, hid, first):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 32, 32), (3, 6, 10, 64, 32), (2, 16, 16, 256, 512), (40, 32, 32, 32, 64),
-                                            (1, 2, 2, 128, 128)])
+                                            (1, 2, 2, 128, 128), (2, 3, 3, 64, 128), (4, 7, 7, 128, 64), (2, 5, 3, 64, 128)])
 def test_conv3x3_weight_and_data_gradients(vad, n, h, w, cin, cout):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin + cout + h)
@@ -182,7 +203,8 @@ def test_conv3x3_weight_and_data_gradients(vad, n, h, w, cin, cout):
     _close(H.to_nchw(out), F.conv2d(torch.from_numpy(a), torch.from_numpy(wt), padding=1).numpy(), 2e-5, "forward with device pack")
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 4, 4, 128, 128), (3, 8, 6, 128, 64), (2, 16, 16, 64, 32), (8, 32, 32, 64, 32)])
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 4, 4, 128, 128), (3, 8, 6, 128, 64), (2, 16, 16, 64, 32), (8, 32, 32, 64, 32),
+                                            (4, 28, 28, 64, 32), (4, 7, 7, 32, 128), (2, 5, 3, 128, 64)])
 def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin * 3 + cout + h)

@@ -146,6 +146,7 @@ struct BnBwdP {
     float* ws;
     int n, h, w, c, act, pool;
     long long opix, chunk;   // pooled-resolution pixels (n*oh*ow), per block
+    unsigned char* dec;   // debug (nullable): [opix][c] bytes, bits 0-1 = pooling argmax (window scan order), bit 2 = value > 0
 };
 
 __device__ __forceinline__ float act_grad(float v, int act) {
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void bn_bwd_route_kernel(BnBwdP p) {
 #pragma unroll
                     for (int k = 1; k < 4; ++k) if (v[k] > v[am]) am = k;
                     const float gz = g[e] * act_grad(v[am], p.act);
+                    if (p.dec) p.dec[q * p.c + 4 * c4 + e] = (unsigned char)(am | (v[am] > 0.f ? 4 : 0));
                     d0[e] = am == 0 ? gz : 0.f; d1[e] = am == 1 ? gz : 0.f; d2[e] = am == 2 ? gz : 0.f; d3[e] = am == 3 ? gz : 0.f;
                     s0[e] += gz;
                     s1[e] += gz * xh[am];
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256) void bn_bwd_route_kernel(BnBwdP p) {
                 for (int e = 0; e < 4; ++e) {
                     const float xh = (yv[e] - mean[e]) * invstd[e];
                     const float v = vad_act(xh * gamma[e] + beta[e], p.act);
+                    if (p.dec) p.dec[q * p.c + 4 * c4 + e] = (unsigned char)(v > 0.f ? 4 : 0);
                     d[e] = g[e] * act_grad(v, p.act);
                     s0[e] += d[e];
                     s1[e] += d[e] * xh;
@@ -645,6 +648,14 @@ extern "C" int vad_bn_act_pool_fwd(const float* y, const float* stats, const flo
     return VAD_OK;
 }
 
+// Debug: the next vad_bn_act_pool_bwd calls record their branch decisions (one byte per output pixel and channel, see
+// BnBwdP::dec) consecutively into this buffer until it is full or reset with (NULL, 0).  Used by the decision-conditioned
+// float64 oracle of tests/test_hip_train_step.py; vad_debug_train_decisions_used() tells how many bytes were written.
+static unsigned char* g_dec_buf = nullptr;
+static size_t g_dec_cap = 0, g_dec_used = 0;
+extern "C" int vad_debug_set_train_decisions(void* buf, size_t bytes) { g_dec_buf = (unsigned char*)buf; g_dec_cap = buf ? bytes : 0; g_dec_used = 0; return VAD_OK; }
+extern "C" size_t vad_debug_train_decisions_used(void) { return g_dec_used; }
+
 extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
                                    long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dz, float* dy, int s2d,
                                    float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
@@ -662,6 +673,13 @@ extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const flo
     p.t = remap_t; p.b = remap_b; p.dz = dz; p.ws = ws; p.n = n; p.h = h; p.w = w; p.c = c; p.act = act; p.pool = pool;
     p.opix = (long long)n * oh * ow;
     p.chunk = stats_chunk(p.opix);
+    p.dec = nullptr;
+    if (g_dec_buf) {
+        const size_t need = (size_t)p.opix * c;
+        VAD_REQUIRE(g_dec_used + need <= g_dec_cap, "bn_act_pool_bwd: decision buffer too small (%zu + %zu > %zu)", g_dec_used, need, g_dec_cap);
+        p.dec = g_dec_buf + g_dec_used;
+        g_dec_used += need;
+    }
     VAD_REQUIRE(p.dout_ps % 4 == 0 && p.dout_fs % 4 == 0, "bn_act_pool_bwd: strides must be multiples of 4 floats");
     const int nb = (int)((p.opix + p.chunk - 1) / p.chunk);
     hipStream_t s = (hipStream_t)stream;

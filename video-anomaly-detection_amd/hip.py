@@ -104,6 +104,8 @@ SIGNATURES = {
     "vad_vid_train_nparams": (_sz, [_i, _i, _i]),
     "vad_vid_train_nstats": (_sz, [_i, _i, _i]),
     "vad_vid_train_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "vad_debug_set_train_decisions": (_i, [_vp, _sz]),
+    "vad_debug_train_decisions_used": (_sz, []),
     "vad_debug_set_train_stop": (_i, [_i]),
     "vad_vid_train_debug_layout": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "vad_vid_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
