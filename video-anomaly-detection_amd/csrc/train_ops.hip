@@ -67,32 +67,44 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long lon
 __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* ws, int nblocks, int c, double count, int mode,
                                                             float eps, float momentum, float* stats, float* running_mean,
                                                             float* running_var, float* dgamma, float* dbeta, const float* pivot) {
-    for (int ch = blockIdx.x * 256 + threadIdx.x; ch < c; ch += gridDim.x * 256) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < nblocks; ++b) {
-            s += (double)ws[(size_t)b * 2 * c + ch];
-            q += (double)ws[(size_t)b * 2 * c + c + ch];
+    // one work-group per channel: thread t adds partial blocks t, t+256, ... in fp64, then a fixed-shape tree over the
+    // 256 threads (the result depends only on the data and the block count, never on scheduling)
+    __shared__ double rs[256], rq[256];
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = tid; b < nblocks; b += 256) {
+        s += (double)ws[(size_t)b * 2 * c + ch];
+        q += (double)ws[(size_t)b * 2 * c + c + ch];
+    }
+    rs[tid] = s;
+    rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    s = rs[0];
+    q = rq[0];
+    if (mode == 0) {
+        const double sm = s / count;                     // mean of the shifted values
+        const double mean = (pivot ? (double)pivot[ch] : 0.0) + sm;
+        double var = q / count - sm * sm;
+        if (var < 0.0) var = 0.0;
+        stats[ch] = (float)mean;
+        stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
+            running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
         }
-        if (mode == 0) {
-            const double sm = s / count;                     // mean of the shifted values
-            const double mean = (pivot ? (double)pivot[ch] : 0.0) + sm;
-            double var = q / count - sm * sm;
-            if (var < 0.0) var = 0.0;
-            stats[ch] = (float)mean;
-            stats[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
-            if (running_mean) {
-                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + momentum * mean);
-                running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + momentum * unb);
-            }
-        } else if (mode == 1) {
-            dbeta[ch] = (float)s;
-            dgamma[ch] = (float)q;
-            stats[ch] = (float)(s / count);
-            stats[c + ch] = (float)(q / count);
-        } else {
-            dbeta[ch] = (float)s;
-        }
+    } else if (mode == 1) {
+        dbeta[ch] = (float)s;
+        dgamma[ch] = (float)q;
+        stats[ch] = (float)(s / count);
+        stats[c + ch] = (float)(q / count);
+    } else {
+        dbeta[ch] = (float)s;
     }
 }
 
@@ -430,16 +442,23 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
 //   layout 3: ConvTranspose2d(->3)   col = q*3 + c < 12 -> dst[(ci*3 + c)*4 + q]       (taps 1, ncols = 32)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int splits, int taps, int cin, int ncols, int layout,
                                                            float* dst) {
+    // 64 consecutive elements x 4 slices of the split range per work-group; slice sums combined in a fixed order
+    __shared__ float part[4][64];
     const long long total = (long long)taps * cin * ncols;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + idx];
-        const int col = (int)(idx % ncols), ci = (int)((idx / ncols) % cin), tap = (int)(idx / ((long long)ncols * cin));
-        if (layout == 0) dst[((size_t)col * cin + ci) * 9 + tap] = s;
-        else if (layout == 1) { const int cout = ncols / 4, q = col / cout, co = col - q * cout; dst[((size_t)ci * cout + co) * 4 + q] = s; }
-        else if (layout == 2) { if (ci < 27) dst[(size_t)col * 27 + ci] = s; }
-        else if (col < 12) { const int q = col / 3, c = col - q * 3; dst[((size_t)ci * 3 + c) * 4 + q] = s; }
-    }
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + e;
+    float s = 0.f;
+    if (idx < total)
+        for (int k = sl; k < splits; k += 4) s += ws[(size_t)k * total + idx];
+    part[sl][e] = s;
+    __syncthreads();
+    if (sl != 0 || idx >= total) return;
+    s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    const int col = (int)(idx % ncols), ci = (int)((idx / ncols) % cin), tap = (int)(idx / ((long long)ncols * cin));
+    if (layout == 0) dst[((size_t)col * cin + ci) * 9 + tap] = s;
+    else if (layout == 1) { const int cout = ncols / 4, q = col / cout, co = col - q * cout; dst[((size_t)ci * cout + co) * 4 + q] = s; }
+    else if (layout == 2) { if (ci < 27) dst[(size_t)col * 27 + ci] = s; }
+    else if (col < 12) { const int q = col / 3, c = col - q * 3; dst[((size_t)ci * 3 + c) * 4 + q] = s; }
 }
 
 // ------------------------------------------------------------------------------------------------ last layer + loss
@@ -592,9 +611,11 @@ unsigned grid_for(long long total) {
 }  // namespace
 
 // ================================================================================================ host entry points
+// pixels per work-group of the channel-reduction passes: short per-thread loops (memory-level parallelism comes from
+// many resident groups), at most 16384 partial rows for the finalize
 static long long stats_chunk(long long npix) {
-    long long chunk = 4096;
-    if ((npix + chunk - 1) / chunk > 1024) chunk = (npix + 1023) / 1024;
+    long long chunk = 512;
+    if ((npix + chunk - 1) / chunk > 16384) chunk = (npix + 16383) / 16384;
     return chunk;
 }
 
@@ -615,7 +636,7 @@ extern "C" int vad_bn_stats(const float* y, long long npix, int c, float eps, fl
     // pivot = the first pixel's channel vector (y[0..c)): a sample of each channel
     hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, npix, c, chunk, y, ws);
     VAD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
                        (double)npix, 0, eps, momentum, stats, running_mean, running_var, (float*)nullptr, (float*)nullptr, y);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
@@ -627,7 +648,7 @@ extern "C" int vad_chan_sum(const float* g, long long npix, int c, float* out, f
     const int nb = (int)((npix + chunk - 1) / chunk);
     hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, npix, c, chunk, (const float*)nullptr, ws);
     VAD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
                        (double)npix, 2, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, out, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
@@ -685,7 +706,7 @@ extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const flo
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_route_kernel, dim3(nb), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chan_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const float*)ws, nb, c,
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, s, (const float*)ws, nb, c,
                        (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     const long long total = (long long)n * h * w * (c / 4);
@@ -759,7 +780,7 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
     const long long total = (long long)taps * cin * ncols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -783,7 +804,7 @@ extern "C" int vad_conv_c3_wgrad(const float* x_nchw, const float* g, float* dw,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(32ll * cout)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((32ll * cout + 63) / 64)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -815,7 +836,7 @@ extern "C" int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, cons
         float* cws = ws + nb + 64;
         hipLaunchKernelGGL(chan_sums_kernel, dim3(cb), dim3(256), 0, s, (const float*)dpre32, total, 32, chunk, (const float*)nullptr, cws);
         VAD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(chan_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)cws, cb, 32, (double)total, 2, 0.f, 0.f,
+        hipLaunchKernelGGL(chan_finalize_kernel, dim3(32), dim3(256), 0, s, (const float*)cws, cb, 32, (double)total, 2, 0.f, 0.f,
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, colsum, (const float*)nullptr);
         VAD_LAUNCH_CHECK();
     }
