@@ -365,6 +365,11 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
                     : launch_conv3<32, 2, 1, 4, 1, MODE_PLAIN>(p, n, act, s);
     }
     if (cout % 128 == 0) {
+        // Small grids (the per-step ConvLSTM gate convolutions of the training path: 16x16 maps, a few dozen frames): the
+        // 8-row tile yields 8 work-groups per 16x16x512 frame, too few to fill 256 CUs twice; a 4-row tile doubles them
+        // (same K order, identical results).  Measured at 32 clips: 24 -> see DESIGN.md section 9.
+        const long long nb8 = (long long)n * ((wd + 15) / 16) * ((h + 7) / 8) * (cout / 128);
+        if (!pool && nb8 < 768) return launch_conv3<32, 1, 2, 2, 2, MODE_PLAIN>(p, n, act, s);
         return pool ? launch_conv3<32, 2, 2, 2, 2, MODE_POOL>(p, n, act, s)
                     : launch_conv3<32, 2, 2, 2, 2, MODE_PLAIN>(p, n, act, s);
     } else if (cout % 64 == 0) {

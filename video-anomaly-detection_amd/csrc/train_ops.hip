@@ -356,30 +356,51 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.f;
 
-    for (int row = r0; row < r1; ++row) {
-        const int n = row / H, y = row - n * H;
-        const __amdgpu_buffer_rsrc_t ra = vad_rsrc(p.a + (size_t)n * H * W * p.cin, a_bytes);
-        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n * H * W * p.ncols, g_bytes);
-        for (int x = 0; x < W; x += 2) {
-            const int px = x + lh;
-            float bv[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                bv[nt] = vad_bload1(rg, px < W ? (unsigned)(((y * W + px) * p.ncols + (cgp * NT + nt) * 32 + li) * 4) : VAD_OOB, 0);
-            float av[TAPS];
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
-                const int yy = y + dy, xx = px + dx;
-                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && px < W;
-                av[t] = vad_bload1(ra, ok ? (unsigned)(((yy * W + xx) * p.cin + ct * 32 + li) * 4) : VAD_OOB, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = MFMA32(av[t], bv[nt], acc[t][nt]);
-        }
+    // software pipeline over (row, pixel pair): the operands of the next pair are in flight while the current pair's
+    // TAPS*NT MFMAs run.  Branch-free body: (lrow, lx) is the next pair to LOAD; past the end of the slice every offset is
+    // out of range, the loads return 0 and the surplus MFMAs add nothing (early exits inside the unrolled body made the
+    // compiler spill the 144 accumulator registers).
+    float av[2][TAPS], bv[2][NT];
+    int lrow = r0, lx = 0, ly = 0;
+    __amdgpu_buffer_rsrc_t ra = vad_rsrc(p.a, 0), rg = vad_rsrc(p.g, 0);
+#define WG_LOAD(buf)                                                                                                   \
+    {                                                                                                                  \
+        const bool valid = lrow < r1;                                                                                  \
+        if (valid && lx == 0) {                                                                                        \
+            const int n_ = lrow / H;                                                                                   \
+            ly = lrow - n_ * H;                                                                                        \
+            ra = vad_rsrc(p.a + (size_t)n_ * H * W * p.cin, a_bytes);                                                  \
+            rg = vad_rsrc(p.g + (size_t)n_ * H * W * p.ncols, g_bytes);                                                \
+        }                                                                                                              \
+        const int px = lx + lh;                                                                                        \
+        const bool pok = valid && px < W;                                                                              \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                              \
+            bv[buf][nt] = vad_bload1(rg, pok ? (unsigned)(((ly * W + px) * p.ncols + (cgp * NT + nt) * 32 + li) * 4) : VAD_OOB, 0); \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                                             \
+            const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;                                  \
+            const int yy = ly + dy, xx = px + dx;                                                                      \
+            const bool ok = pok && yy >= 0 && yy < H && xx >= 0 && xx < W;                                             \
+            av[buf][t] = vad_bload1(ra, ok ? (unsigned)(((yy * W + xx) * p.cin + ct * 32 + li) * 4) : VAD_OOB, 0);     \
+        }                                                                                                              \
+        lx += 2;                                                                                                       \
+        if (lx >= W) { lx = 0; ++lrow; }                                                                               \
     }
+#define WG_MFMA(buf)                                                                         \
+    {                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                     \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[t][nt] = MFMA32(av[buf][t], bv[buf][nt], acc[t][nt]); \
+    }
+    const int npairs = (r1 - r0) * ((W + 1) / 2);
+    WG_LOAD(0);
+    for (int i = 0; i < npairs; i += 2) {
+        WG_LOAD(1);
+        WG_MFMA(0);
+        WG_LOAD(0);
+        WG_MFMA(1);
+    }
+#undef WG_MFMA
+#undef WG_LOAD
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -409,29 +430,37 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
     const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
     const int c = li / 9, tap = li - c * 9, dy = tap / 3 - 1, dx = tap % 3 - 1;
     const unsigned x_bytes = (unsigned)(3 * H * W) * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.cout * 4u;
-    f32x16 acc[2];
+    // four independent accumulator chains (one 32x32x2 MFMA each per 8 pixels) so the matrix pipe never waits on its own
+    // result; the 8 operand loads of a group are issued before its MFMAs
+    constexpr int U = 4;
+    f32x16 acc[U];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
     for (int row = r0; row < r1; ++row) {
         const int n = row / H, y = row - n * H;
         const __amdgpu_buffer_rsrc_t rx = vad_rsrc(p.x + (size_t)n * 3 * H * W, x_bytes);
         const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n * H * W * p.cout, g_bytes);
         const int yy = y + dy;
         const bool rowok = li < 27 && yy >= 0 && yy < H;
-        for (int x = 0; x < W; x += 4) {
+        for (int x = 0; x < W; x += 2 * U) {
+            float av[U], bv[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int px = x + 2 * u + lh, xx = px + dx;
-                const float bv = vad_bload1(rg, px < W ? (unsigned)(((y * W + px) * p.cout + cgp * 32 + li) * 4) : VAD_OOB, 0);
-                const float av = vad_bload1(rx, (rowok && xx >= 0 && xx < W && px < W) ? (unsigned)(((c * H + yy) * W + xx) * 4) : VAD_OOB, 0);
-                acc[u] = MFMA32(av, bv, acc[u]);
+                bv[u] = vad_bload1(rg, px < W ? (unsigned)(((y * W + px) * p.cout + cgp * 32 + li) * 4) : VAD_OOB, 0);
+                av[u] = vad_bload1(rx, (rowok && xx >= 0 && xx < W && px < W) ? (unsigned)(((c * H + yy) * W + xx) * 4) : VAD_OOB, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = MFMA32(av[u], bv[u], acc[u]);
         }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        p.ws[((size_t)split * 32 + k) * p.cout + cgp * 32 + li] = acc[0][r] + acc[1][r];
+        p.ws[((size_t)split * 32 + k) * p.cout + cgp * 32 + li] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
     }
 }
 
