@@ -1,0 +1,75 @@
+"""Data-parallel semantics of the native training step on a GPU (row f-1, SURVEY.md section 8e "Training"): two ranks
+share the one device of the test box over gloo (RCCL needs one device per rank; the collective is the same single
+all-reduce of the flat gradient buffer), each steps on its half of the batch.  Both must end with identical parameters,
+equal bit for bit to ONE process that averages the two halves' gradients and takes one Adam step.  BatchNorm statistics
+stay per rank (the reference has no SyncBN)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(latent=64, layers=2, b=4, t=3, hw=32, wseed=51, xseed=151, lr=1e-4, wd=1e-5)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(vad):
+    from conftest import load_synthetic
+    m = vad.VideoAutoencoder(in_channels=3, latent_dim=CFG["latent"], lstm_hidden_dim=CFG["latent"], lstm_num_layers=CFG["layers"])
+    load_synthetic(vad, m, CFG["wseed"])
+    return m.cuda()
+
+
+def _clips(vad):
+    return torch.from_numpy(vad.synth.clips(CFG["xseed"], 0, CFG["b"], CFG["t"], 3, CFG["hw"], CFG["hw"]))
+
+
+def _rank(rank, world, port, out_dir):
+    import importlib
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import torch.distributed as dist
+    vad = importlib.import_module("video-anomaly-detection_amd")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = vad.VideoTrainer(_build(vad), lr=CFG["lr"], weight_decay=CFG["wd"])
+    per = CFG["b"] // world
+    x = _clips(vad)[rank * per:(rank + 1) * per].cuda()
+    losses = [float(tr.step(x)) for _ in range(2)]
+    np.save(os.path.join(out_dir, f"p{rank}.npy"), tr.flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"l{rank}.npy"), np.array(losses))
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), tr.running.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_with_averaged_gradients(vad, tmp_path):
+    world = 2
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    assert np.array_equal(p0, p1), "ranks diverged"
+    # one process: per-half gradients from two replicas, averaged, one optimiser step; twice
+    x = _clips(vad).cuda()
+    per = CFG["b"] // world
+    reps = [vad.VideoTrainer(_build(vad), lr=CFG["lr"], weight_decay=CFG["wd"]) for _ in range(world)]
+    for _ in range(2):
+        losses = [float(tr.forward_backward(x[r * per:(r + 1) * per])[0]) for r, tr in enumerate(reps)]
+        total = reps[0].grad + reps[1].grad
+        for tr in reps:
+            tr.grad.copy_(total)
+            tr.optimizer_step(1.0 / world)
+    assert np.array_equal(reps[0].flat.cpu().numpy(), p0), f"max diff {np.abs(reps[0].flat.cpu().numpy() - p0).max():.3e}"
+    for r in range(world):
+        assert abs(np.load(tmp_path / f"l{r}.npy")[-1] - losses[r]) < 1e-7 * losses[r]
+        assert np.array_equal(np.load(tmp_path / f"s{r}.npy"), reps[r].running.cpu().numpy())      # per-rank BatchNorm statistics
+    assert not np.array_equal(np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy"))

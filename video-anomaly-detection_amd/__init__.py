@@ -10,5 +10,6 @@ from .video_autoencoder import (ConvLSTM, ConvLSTMCell, VideoAutoencoder,    # n
                                 VideoDecoder, VideoEncoder)
 from . import losses                                                   # noqa: F401
 from .losses import CombinedLoss, SSIMLoss                           # noqa: F401
+from . import training                                                 # noqa: F401
 from .training import VideoTrainer                                    # noqa: F401
 from . import scoring                                                 # noqa: F401

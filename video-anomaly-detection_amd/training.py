@@ -24,6 +24,25 @@ from . import hip
 from .video_autoencoder import VideoAutoencoder
 
 
+def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
+    """Sum `flat` over the ranks of `group`, in place; returns the world size (1 when no process group is initialised).
+    Backend "nccl" is RCCL on ROCm: one collective over the flat gradient buffer on the device.  With gloo (the CPU tests,
+    single-GPU rehearsals with several ranks sharing one device) a GPU tensor goes through a host copy."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return world
+
+
 class VideoTrainer:
     """Adam-on-MSE training steps for a `VideoAutoencoder` living on a GPU (exact fp32)."""
 
@@ -121,12 +140,7 @@ class VideoTrainer:
     def step(self, clips: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's batch; with a process group the gradients are summed over ranks with ONE
         all-reduce of the flat buffer and averaged inside the optimiser kernel (DistributedDataParallel semantics)."""
-        import torch.distributed as dist
         loss, _ = self.forward_backward(clips)
-        world = 1
-        if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(self.group)
-            if world > 1:
-                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+        world = allreduce_sum_(self.grad, self.group)
         self.optimizer_step(1.0 / world)
         return loss
