@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-layer-events", action="store_true", help="do not bracket layers with hipEvents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the secondary split-precision measurement")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (row f-1)")
     ap.add_argument("--tail-group", type=int, default=0, help="frames per dec4.0 -> tail sub-group (0 = auto)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
@@ -296,6 +297,10 @@ def main():
                                   "arithmetic": "a*b = ah*bh + (ah*bl + al*bh)*2^-11, fp16 hi/lo operands, fp32 accumulate"}
         model.precision = "fp32"
         scores = exact_scores
+    # Secondary measurement (row f-1): the native training step of the ConvLSTM video autoencoder (train_video.py:44-65),
+    # exact fp32, 32 clips x 10 frames at the bench resolution.  Never part of `value` / `roofline`.
+    if rank == 0 and world == 1 and not args.no_train and args.workload == "image" and args.precision == "fp32":
+        out["training_step"] = training_step(vad, dev, hw)
     if args.workload == "dense":
         out["unique_frames_per_sec"] = round(((per_gpu - 1) * args.stride + t) * world * args.steps / elapsed, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "dense":
@@ -304,6 +309,33 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
+    """frames/s through VideoTrainer.step (forward in train mode + MSE + backward + Adam as HIP kernels) on synthetic clips,
+    default VideoAutoencoder(latent 128, hidden 128, 2 layers); FLOPs counted as 3 x the forward's."""
+    import numpy as np
+    import torch
+    m = vad.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, 5).items()}, strict=True)
+    tr = vad.VideoTrainer(m.to(dev))
+    x = vad.scoring.synth_frames_device(0xC0FFEE + 4, 0, clips * t, hw, hw, 3, dev).view(clips, t, 3, hw, hw)
+    first = None
+    for _ in range(warmup):
+        first = float(tr.step(x))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(x)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    out = {"value": round(clips * t / dt, 1), "unit": "frames/s trained", "ms_per_step": round(dt * 1e3, 3), "clips": clips, "t": t,
+           "dtype": "f32", "loss_first_last": [first, float(loss)], "workspace_GiB": round(tr._ws.numel() / 2**30, 2),
+           "algorithmic_tflops": round(3 * 3011510272.0 * (hw / 256.0) ** 2 * clips * t / dt / 1e12, 2)}
+    del tr, m, x
+    torch.cuda.empty_cache()
+    return out
 
 
 def host_cores() -> int:
