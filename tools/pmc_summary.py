@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "conv" not in k and "score" not in k:
+            if "conv" not in k and "score" not in k and "wgrad" not in k:
                 continue
             acc[k[:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in acc.items():

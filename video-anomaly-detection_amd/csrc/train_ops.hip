@@ -358,30 +358,61 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
 
     // software pipeline over (row, pixel pair): the operands of the next pair are in flight while the current pair's
     // TAPS*NT MFMAs run.  Branch-free body: (lrow, lx) is the next pair to LOAD; past the end of the slice every offset is
-    // out of range, the loads return 0 and the surplus MFMAs add nothing (early exits inside the unrolled body made the
-    // compiler spill the 144 accumulator registers).
+    // out of range, the loads return 0 and the surplus MFMAs add nothing.
+    // Address work is split by rate (PMC: the first version issued 1.4 scalar + 1.0 vector instructions per MFMA and kept
+    // the matrix pipe 48 % busy): per ROW three descriptors (zero-sized for rows outside the image) and TAPS scalar tap
+    // bases; per PAIR two scalar increments, three lane masks (left / centre / right column validity) and one scalar add
+    // per load.  Lane parts of the offsets are loop invariants.
+    // Every scalar offset is >= 0 and every lane that passes the range check addresses a pixel inside the frame whether or
+    // not the hardware includes the scalar offset in that check: the left-column tap (dx = -1) takes its scalar base at
+    // pixel max(x-2, 0) with the lane part one pixel further (at x == 0 only the upper lane half exists: pixel 0).
+    constexpr int NR = TAPS == 9 ? 3 : 1;
     float av[2][TAPS], bv[2][NT];
-    int lrow = r0, lx = 0, ly = 0;
-    __amdgpu_buffer_rsrc_t ra = vad_rsrc(p.a, 0), rg = vad_rsrc(p.g, 0);
+    int lrow = r0, lx = 0;
+    const __amdgpu_buffer_rsrc_t rzero = vad_rsrc(p.a, 0);
+    __amdgpu_buffer_rsrc_t rrow[NR], rg = vad_rsrc(p.g, 0);
+    unsigned rbase[NR], sx = 0, sxm = 0, sgx = 0;     // scalar: row bases of the load row, x offsets (sxm: max(x-2,0))
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { rrow[i] = rzero; rbase[i] = 0; }
+    const unsigned pix_a = (unsigned)(p.cin * 4);
+    const unsigned lane_a = (unsigned)((lh * p.cin + ct * 32 + li) * 4), lane_b = (unsigned)((lh * p.ncols + cgp * NT * 32 + li) * 4);
+    const unsigned lane_a_p1 = lane_a + pix_a;                              // one pixel to the right of the lane's own
+    const unsigned lane_a_x0 = lh ? lane_a - pix_a : VAD_OOB;                // dx = -1 at x == 0: lane half 1 reads pixel 0
+    const unsigned step_a = 2 * pix_a, step_b = (unsigned)(2 * p.ncols * 4);
 #define WG_LOAD(buf)                                                                                                   \
     {                                                                                                                  \
         const bool valid = lrow < r1;                                                                                  \
         if (valid && lx == 0) {                                                                                        \
-            const int n_ = lrow / H;                                                                                   \
-            ly = lrow - n_ * H;                                                                                        \
-            ra = vad_rsrc(p.a + (size_t)n_ * H * W * p.cin, a_bytes);                                                  \
+            const int n_ = lrow / H, ly = lrow - n_ * H;                                                               \
+            const float* fa = p.a + (size_t)n_ * H * W * p.cin;                                                        \
             rg = vad_rsrc(p.g + (size_t)n_ * H * W * p.ncols, g_bytes);                                                \
+            _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                           \
+                const int yy = ly + (NR == 3 ? i - 1 : 0);                                                             \
+                const bool rok = yy >= 0 && yy < H;                                                                    \
+                rrow[i] = rok ? vad_rsrc(fa, a_bytes) : rzero;                                                         \
+                rbase[i] = rok ? (unsigned)(yy * W) * pix_a : 0u;                                                      \
+            }                                                                                                          \
+            sx = 0;                                                                                                    \
+            sxm = 0;                                                                                                   \
+            sgx = (unsigned)(ly * W * p.ncols * 4);                                                                    \
         }                                                                                                              \
         const int px = lx + lh;                                                                                        \
         const bool pok = valid && px < W;                                                                              \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                              \
-            bv[buf][nt] = vad_bload1(rg, pok ? (unsigned)(((ly * W + px) * p.ncols + (cgp * NT + nt) * 32 + li) * 4) : VAD_OOB, 0); \
-        _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                                             \
-            const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;                                  \
-            const int yy = ly + dy, xx = px + dx;                                                                      \
-            const bool ok = pok && yy >= 0 && yy < H && xx >= 0 && xx < W;                                             \
-            av[buf][t] = vad_bload1(ra, ok ? (unsigned)(((yy * W + xx) * p.cin + ct * 32 + li) * 4) : VAD_OOB, 0);     \
+        const unsigned vb = pok ? lane_b : VAD_OOB;                                                                    \
+        unsigned va[NR];                                                                                               \
+        if (NR == 3) {                                                                                                 \
+            va[0] = pok ? (lx >= 2 ? lane_a_p1 : lane_a_x0) : VAD_OOB;                                                 \
+            va[1] = pok ? lane_a : VAD_OOB;                                                                            \
+            va[2] = (pok && px + 1 < W) ? lane_a_p1 : VAD_OOB;                                                         \
+        } else {                                                                                                       \
+            va[0] = pok ? lane_a : VAD_OOB;                                                                            \
         }                                                                                                              \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bv[buf][nt] = vad_bload1(rg, vb, sgx + (unsigned)(nt * 128)); \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                                               \
+            av[buf][t] = vad_bload1(rrow[t / NR], va[t % NR], rbase[t / NR] + ((NR == 3 && t % NR == 0) ? sxm : sx));   \
+        sxm = lx >= 2 ? sxm + step_a : (lx == 0 ? 0u : sxm);                                                           \
+        sx += step_a;                                                                                                  \
+        sgx += step_b;                                                                                                 \
         lx += 2;                                                                                                       \
         if (lx >= W) { lx = 0; ++lrow; }                                                                               \
     }
