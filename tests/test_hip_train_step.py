@@ -279,9 +279,11 @@ def _conditioned_float64(vad, latent, layers, wseed, x, decisions):
 
 
 @pytest.mark.parametrize("latent,layers,b,t,hw,wseed", [(32, 3, 1, 4, 48, 43), (32, 3, 1, 4, 80, 43), (32, 3, 1, 4, 112, 43),
-                                                        (32, 3, 1, 4, 64, 43), (64, 2, 2, 3, 32, 41), (64, 1, 2, 2, 96, 44)])
+                                                        (32, 3, 1, 4, 64, 43), (64, 2, 2, 3, 32, 41), (64, 1, 2, 2, 96, 44),
+                                                        (32, 2, 2, 2, (48, 80), 45), (64, 2, 1, 3, (64, 32), 46)])
 def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, layers, b, t, hw, wseed):
-    x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, hw, hw))
+    h, w = hw if isinstance(hw, tuple) else (hw, hw)          # non-square cases: H and W are carried separately everywhere
+    x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, h, w))
     m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
     load_synthetic(vad, m, wseed)
     m = m.cuda()
@@ -307,3 +309,30 @@ def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, la
         assert err < 1e-4, f"grad {k}: {err:.3e} of max |g| {scale:.3e} from the decision-conditioned float64 gradient " \
                            f"(decisions differing from float64: {[(s, n_) for s, n_, _, _ in report if n_]})"
     print(f"[{latent},{layers},{b}x{t},{hw}] worst gradient deviation {worst:.2e}; differing decisions {[(s, n_, f'{mg:.1e}') for s, n_, mg, _ in report if n_]}")
+
+
+def test_loss_curve_follows_cpu_autograd_over_many_steps(vad):
+    """SURVEY.md section 8 row f-1 gate: the loss trajectory of the native step against the fp32 CPU restatement
+    (train_video.py:44-65 semantics) over 25 Adam steps on one batch.  Individual parameters may wander by a few lr (see
+    the notes above); the trajectory must not: every loss within 5e-4 relative, and the loss must actually fall."""
+    latent, layers, b, t, hw, wseed, steps = 64, 2, 2, 3, 32, 47, 25
+    x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, hw, hw))
+    lr = 1e-3                                    # larger than the reference's default so that 25 steps move the loss
+    ref = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    load_synthetic(vad, ref, wseed)
+    ref.train()
+    opt, crit, want = torch.optim.Adam(ref.parameters(), lr=lr, weight_decay=WD), nn.MSELoss(), []
+    for _ in range(steps):
+        loss = crit(ref(x), x)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want.append(float(loss.detach()))
+    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    load_synthetic(vad, m, wseed)
+    tr = vad.VideoTrainer(m.cuda(), lr=lr, weight_decay=WD)
+    xd = x.cuda()
+    got = [float(tr.step(xd)) for _ in range(steps)]
+    rel = [abs(a - r) / r for a, r in zip(got, want)]
+    assert max(rel) < 5e-4, f"loss curves diverge: max rel {max(rel):.2e} at step {int(np.argmax(rel))}: {got[-3:]} vs {want[-3:]}"
+    assert got[-1] < 0.8 * got[0], (got[0], got[-1])
