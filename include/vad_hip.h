@@ -152,11 +152,11 @@ int vad_chan_sum(const float* g, long long npix, int c, float* out, float* ws, v
 int vad_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out,
                         long long out_fs, int out_ps, int remap_t, int remap_b, int n, int h, int w, int c,
                         int act, int pool, void* stream);
-/* Backward of the above: dout is addressed like `out`.  dz [n,h,w,c] scratch (gradient after pool routing and act');
- * dy = gradient of the conv output, dense NHWC or (s2d != 0) the space-to-depth view [n][h/2][w/2][4][c];
- * dgamma/dbeta [c]; ksums [2c] scratch. */
+/* Backward of the above: dout is addressed like `out`.  dy = gradient of the conv output, dense NHWC or (s2d != 0,
+ * un-pooled layers) the space-to-depth view [n][h/2][w/2][4][c]; must not alias dout.  dgamma/dbeta [c]; ksums [2c]
+ * scratch.  Two passes over y: per-channel sums of the routed gradient, then dy; the routed gradient is never stored. */
 int vad_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
-                        long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dz, float* dy, int s2d,
+                        long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dy, int s2d,
                         float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
                         int pool, void* stream);
 /* ConvLSTMCell gate math (models/video_autoencoder.py:73-83) on pre-activations z [nb*hw][4*hid] (order i,f,g,o): z is

@@ -59,11 +59,11 @@ def test_batchnorm_act_pool_forward_backward(vad, n, h, w, c, act, pool):
     _close(rmd.cpu().numpy(), rmt.numpy(), 1e-5, "running_mean")
     _close(rvd.cpu().numpy(), rvt.numpy(), 1e-5, "running_var")
 
-    dz, dy = torch.empty(n, h, w, c, device="cuda"), torch.empty(n, h, w, c, device="cuda")
+    dy = torch.full((n, h, w, c), float("nan"), device="cuda")
     dg, db, ks = _ws(c), _ws(c), _ws(2 * c)
     doutd = H.nhwc(dout)
     vad.hip.check(l.vad_bn_act_pool_bwd(yd.data_ptr(), stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), doutd.data_ptr(), 0, 0, 0, 0,
-                                        dz.data_ptr(), dy.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), ks.data_ptr(), ws.data_ptr(),
+                                        dy.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), ks.data_ptr(), ws.data_ptr(),
                                         n, h, w, c, act, pool, H.stream()))
     _close(H.to_nchw(dy), yt.grad.numpy(), 1e-4, "dy")
     _close(dg.cpu().numpy(), gt.grad.numpy(), 1e-4, "dgamma")
@@ -71,7 +71,7 @@ def test_batchnorm_act_pool_forward_backward(vad, n, h, w, c, act, pool):
     if not pool and h % 2 == 0 and w % 2 == 0:      # space-to-depth form of the same gradient
         dy2 = torch.full((n, h // 2, w // 2, 4, c), float("nan"), device="cuda")
         vad.hip.check(l.vad_bn_act_pool_bwd(yd.data_ptr(), stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), doutd.data_ptr(), 0, 0, 0, 0,
-                                            dz.data_ptr(), dy2.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), ks.data_ptr(), ws.data_ptr(),
+                                            dy2.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), ks.data_ptr(), ws.data_ptr(),
                                             n, h, w, c, act, pool, H.stream()))
         ref = dy.view(n, h // 2, 2, w // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h // 2, w // 2, 4, c)
         assert torch.equal(dy2, ref)
@@ -122,10 +122,10 @@ def test_batchnorm_forward_time_major_strided_destination(vad):
     ddense = dcat[..., :c].permute(1, 0, 2, 3, 4).reshape(n, h // 2, w // 2, c).contiguous()
     outs = []
     for src, ps_, tt, bb in ((dcat, ps, t, bsz), (ddense, 0, 0, 0)):
-        dz, dy = torch.empty(n, h, w, c, device="cuda"), torch.empty(n, h, w, c, device="cuda")
+        dy = torch.full((n, h, w, c), float("nan"), device="cuda")
         dg, db, ks = _ws(c), _ws(c), _ws(2 * c)
         vad.hip.check(l.vad_bn_act_pool_bwd(yd.data_ptr(), stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), src.data_ptr(), 0, ps_, tt, bb,
-                                            dz.data_ptr(), dy.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), ks.data_ptr(), ws.data_ptr(),
+                                            dy.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), ks.data_ptr(), ws.data_ptr(),
                                             n, h, w, c, 1, 1, H.stream()))
         outs.append((dy, dg, db))
     assert all(torch.equal(a, b) for a, b in zip(*outs))

@@ -116,10 +116,15 @@ struct BnFwdP {
     long long total;      // n * oh * ow * c/4
 };
 
+// xhat and the BatchNorm output with every operation rounded on its own (no fma contraction): forward, backward pass A and
+// backward pass B must take bit-identical branch decisions whatever code the compiler generates around them.
+__device__ __forceinline__ float bn_xhat(float y, float mean, float invstd) { return __fmul_rn(__fsub_rn(y, mean), invstd); }
+__device__ __forceinline__ float bn_value(float xhat, float gamma, float beta) { return __fadd_rn(__fmul_rn(xhat, gamma), beta); }
+
 __device__ __forceinline__ f32x4 bn_apply(f32x4 y, f32x4 mean, f32x4 invstd, f32x4 gamma, f32x4 beta, int act) {
-    f32x4 v = ((y - mean) * invstd) * gamma + beta;
+    f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = vad_act(v[e], act);
+    for (int e = 0; e < 4; ++e) v[e] = vad_act(bn_value(bn_xhat(y[e], mean[e], invstd[e]), gamma[e], beta[e]), act);
     return v;
 }
 
@@ -154,8 +159,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
 struct BnBwdP {
     const float* y; const float* stats; const float* gamma; const float* beta;
     const float* dout; long long dout_fs; int dout_ps, t, b;
-    float* dz;            // dense NHWC at the conv's resolution
-    float* ws;
+    float* ws;            // pass A: partial sums
+    const float* k;       // pass B: {sum(dz)/M, sum(dz*xhat)/M}
+    float* dy;            // pass B: gradient of the conv output, dense NHWC or space-to-depth
+    int s2d;
     int n, h, w, c, act, pool;
     long long opix, chunk;   // pooled-resolution pixels (n*oh*ow), per block
     unsigned char* dec;   // debug (nullable): [opix][c] bytes, bits 0-1 = pooling argmax (window scan order), bit 2 = value > 0
@@ -167,10 +174,29 @@ __device__ __forceinline__ float act_grad(float v, int act) {
     return 1.f;
 }
 
-// pass A: dz = d(out) routed through MaxPool (first maximum in window scan order, like torch) and act'; partial sums
-__global__ __launch_bounds__(256) void bn_bwd_route_kernel(BnBwdP p) {
+// The routed gradient of one (pooled) output element: which window element receives it (first maximum in window scan
+// order, like torch), its xhat, and dz = d(out) * act'(value).  Shared by both passes.
+struct Routed { int am; float xh, gz, v; };
+__device__ __forceinline__ Routed bn_route(const float y4[4], int nwin, float mean, float invstd, float gamma, float beta, float g, int act) {
+    Routed r;
+    float xh[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nwin) { xh[k] = bn_xhat(y4[k], mean, invstd); v[k] = vad_act(bn_value(xh[k], gamma, beta), act); }
+    r.am = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < nwin && v[k] > v[r.am]) r.am = k;
+    r.xh = xh[r.am];
+    r.v = v[r.am];
+    r.gz = g * act_grad(r.v, act);
+    return r;
+}
+
+// pass A: per-channel partial sums of dz and dz*xhat (dz itself is never stored; pass B re-derives it)
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
     const int tid = threadIdx.x, cg = p.c >> 2, rows = 256 / cg, row = tid / cg, c4 = tid - row * cg;
-    const int oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w;
+    const int oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w, nwin = p.pool ? 4 : 1;
     const long long p0 = (long long)blockIdx.x * p.chunk, p1 = (p0 + p.chunk < p.opix) ? p0 + p.chunk : p.opix;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (row < rows) {
@@ -179,69 +205,61 @@ __global__ __launch_bounds__(256) void bn_bwd_route_kernel(BnBwdP p) {
         for (long long q = p0 + row; q < p1; q += rows) {
             const int x = (int)(q % ow), y = (int)((q / ow) % oh), n = (int)(q / ((long long)ow * oh));
             const f32x4 g = *(const f32x4*)&p.dout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4];
-            const size_t fbase = (size_t)n * p.h * p.w * p.c + 4 * c4;
-            if (p.pool) {
-                const size_t o0 = fbase + ((size_t)(2 * y) * p.w + 2 * x) * p.c;
-                const size_t o1 = o0 + p.c, o2 = o0 + (size_t)p.w * p.c, o3 = o2 + p.c;
-                const f32x4 y0 = *(const f32x4*)&p.y[o0], y1 = *(const f32x4*)&p.y[o1], y2 = *(const f32x4*)&p.y[o2], y3 = *(const f32x4*)&p.y[o3];
-                f32x4 d0, d1, d2, d3;
+            const size_t o0 = (size_t)n * p.h * p.w * p.c + 4 * c4 + (p.pool ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
+            f32x4 yv[4];
+            yv[0] = *(const f32x4*)&p.y[o0];
+            if (p.pool) { yv[1] = *(const f32x4*)&p.y[o0 + p.c]; yv[2] = *(const f32x4*)&p.y[o0 + (size_t)p.w * p.c]; yv[3] = *(const f32x4*)&p.y[o0 + (size_t)p.w * p.c + p.c]; }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh[4] = {(y0[e] - mean[e]) * invstd[e], (y1[e] - mean[e]) * invstd[e],
-                                         (y2[e] - mean[e]) * invstd[e], (y3[e] - mean[e]) * invstd[e]};
-                    float v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = vad_act(xh[k] * gamma[e] + beta[e], p.act);
-                    int am = 0;
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) if (v[k] > v[am]) am = k;
-                    const float gz = g[e] * act_grad(v[am], p.act);
-                    if (p.dec) p.dec[q * p.c + 4 * c4 + e] = (unsigned char)(am | (v[am] > 0.f ? 4 : 0));
-                    d0[e] = am == 0 ? gz : 0.f; d1[e] = am == 1 ? gz : 0.f; d2[e] = am == 2 ? gz : 0.f; d3[e] = am == 3 ? gz : 0.f;
-                    s0[e] += gz;
-                    s1[e] += gz * xh[am];
-                }
-                *(f32x4*)&p.dz[o0] = d0; *(f32x4*)&p.dz[o1] = d1; *(f32x4*)&p.dz[o2] = d2; *(f32x4*)&p.dz[o3] = d3;
-            } else {
-                const size_t o = fbase + ((size_t)y * p.w + x) * p.c;
-                const f32x4 yv = *(const f32x4*)&p.y[o];
-                f32x4 d;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh = (yv[e] - mean[e]) * invstd[e];
-                    const float v = vad_act(xh * gamma[e] + beta[e], p.act);
-                    if (p.dec) p.dec[q * p.c + 4 * c4 + e] = (unsigned char)(v > 0.f ? 4 : 0);
-                    d[e] = g[e] * act_grad(v, p.act);
-                    s0[e] += d[e];
-                    s1[e] += d[e] * xh;
-                }
-                *(f32x4*)&p.dz[o] = d;
+            for (int e = 0; e < 4; ++e) {
+                const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
+                const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[e], p.act);
+                if (p.dec) p.dec[q * p.c + 4 * c4 + e] = (unsigned char)(r.am | (r.v > 0.f ? 4 : 0));
+                s0[e] += r.gz;
+                s1[e] += r.gz * r.xh;
             }
         }
     }
     block_chan_reduce(s0, s1, p.c, p.ws + (size_t)blockIdx.x * 2 * p.c);
 }
 
-// pass B: dy = gamma * invstd * (dz - k1 - xhat * k2); s2d != 0 writes the space-to-depth view [n][h/2][w/2][4][c]
-// (the operand layout of the transposed convolution's data / weight gradients)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* y, const float* stats, const float* gamma, const float* k,
-                                                           const float* dz, float* dy, int n, int h, int w, int c, int s2d,
-                                                           long long total) {
-    const int cg = c >> 2;
+// pass B: dy = gamma * invstd * (dz - k1 - xhat * k2) for every element of the window (dz = 0 off the routed element);
+// s2d writes the space-to-depth view [n][h/2][w/2][4][c] (the operand layout of the transposed convolution's gradients)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
+    const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w, nwin = p.pool ? 4 : 1;
+    const long long total = p.opix * cg;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c4 = (int)(idx % cg);
-        const long long pix = idx / cg;
-        const f32x4 mean = *(const f32x4*)&stats[4 * c4], invstd = *(const f32x4*)&stats[c + 4 * c4];
-        const f32x4 ga = *(const f32x4*)&gamma[4 * c4], k1 = *(const f32x4*)&k[4 * c4], k2 = *(const f32x4*)&k[c + 4 * c4];
-        const f32x4 yv = *(const f32x4*)&y[pix * c + 4 * c4], d = *(const f32x4*)&dz[pix * c + 4 * c4];
-        const f32x4 r = (ga * invstd) * (d - k1 - ((yv - mean) * invstd) * k2);
-        if (s2d) {
-            const int x = (int)(pix % w), yy = (int)((pix / w) % h);
-            const long long nn = pix / ((long long)w * h);
-            const size_t o = (((size_t)nn * (h / 2) + yy / 2) * (w / 2) + x / 2) * 4 * c + ((yy & 1) * 2 + (x & 1)) * c + 4 * c4;
-            *(f32x4*)&dy[o] = r;
+        const long long q = idx / cg;
+        const int x = (int)(q % ow), y = (int)((q / ow) % oh), n = (int)(q / ((long long)ow * oh));
+        const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
+        const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
+        const f32x4 k1 = *(const f32x4*)&p.k[4 * c4], k2 = *(const f32x4*)&p.k[p.c + 4 * c4];
+        const f32x4 g = *(const f32x4*)&p.dout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4];
+        const size_t fb = (size_t)n * p.h * p.w * p.c + 4 * c4;
+        const size_t o0 = fb + (p.pool ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
+        const size_t off[4] = {o0, o0 + p.c, o0 + (size_t)p.w * p.c, o0 + (size_t)p.w * p.c + p.c};
+        f32x4 yv[4], out[4];
+        yv[0] = *(const f32x4*)&p.y[off[0]];
+        if (p.pool) { yv[1] = *(const f32x4*)&p.y[off[1]]; yv[2] = *(const f32x4*)&p.y[off[2]]; yv[3] = *(const f32x4*)&p.y[off[3]]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
+            const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[e], p.act);
+            const float sc = gamma[e] * invstd[e];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nwin) {
+                    const float xh = bn_xhat(y4[k], mean[e], invstd[e]);
+                    out[k][e] = sc * ((k == r.am ? r.gz : 0.f) - k1[e] - xh * k2[e]);
+                }
+        }
+        if (p.s2d) {          // no-pool layers only (checked on the host): pixel (y, x) of an h x w map
+            const size_t o = (((size_t)n * (p.h / 2) + y / 2) * (p.w / 2) + x / 2) * 4 * p.c + ((y & 1) * 2 + (x & 1)) * p.c + 4 * c4;
+            *(f32x4*)&p.dy[o] = out[0];
         } else {
-            *(f32x4*)&dy[pix * c + 4 * c4] = r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nwin) *(f32x4*)&p.dy[off[k]] = out[k];
         }
     }
 }
@@ -738,20 +756,22 @@ extern "C" int vad_debug_set_train_decisions(void* buf, size_t bytes) { g_dec_bu
 extern "C" size_t vad_debug_train_decisions_used(void) { return g_dec_used; }
 
 extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* dout,
-                                   long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dz, float* dy, int s2d,
+                                   long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dy, int s2d,
                                    float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
                                    int pool, void* stream) {
-    VAD_REQUIRE(y && stats && gamma && beta && dout && dz && dy && dgamma && dbeta && ksums && ws, "bn_act_pool_bwd: null pointer");
+    VAD_REQUIRE(y && stats && gamma && beta && dout && dy && dgamma && dbeta && ksums && ws, "bn_act_pool_bwd: null pointer");
     VAD_REQUIRE(n > 0 && h > 0 && w > 0 && chan_ok(c) && act >= 0 && act <= 2, "bn_act_pool_bwd: bad arguments");
     VAD_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "bn_act_pool_bwd: pooling needs even H, W");
-    VAD_REQUIRE(!s2d || (h % 2 == 0 && w % 2 == 0 && dy != dz), "bn_act_pool_bwd: space-to-depth output needs even H, W and dy != dz");
+    VAD_REQUIRE(!s2d || (!pool && h % 2 == 0 && w % 2 == 0), "bn_act_pool_bwd: space-to-depth output is for un-pooled layers with even H, W");
+    VAD_REQUIRE(dy != dout, "bn_act_pool_bwd: dy must not alias dout (pass B reads dout while writing dy)");
     VAD_REQUIRE(remap_t == 0 || (remap_b > 0 && n == remap_t * remap_b), "bn_act_pool_bwd: n must equal T*B with a frame remap");
     const int oh = pool ? h / 2 : h, ow = pool ? w / 2 : w;
     BnBwdP p{};
     p.y = y; p.stats = stats; p.gamma = gamma; p.beta = beta; p.dout = dout;
     p.dout_ps = dout_ps ? dout_ps : c;
     p.dout_fs = dout_fs ? dout_fs : (long long)oh * ow * p.dout_ps;
-    p.t = remap_t; p.b = remap_b; p.dz = dz; p.ws = ws; p.n = n; p.h = h; p.w = w; p.c = c; p.act = act; p.pool = pool;
+    p.t = remap_t; p.b = remap_b; p.ws = ws; p.k = ksums; p.dy = dy; p.s2d = s2d;
+    p.n = n; p.h = h; p.w = w; p.c = c; p.act = act; p.pool = pool;
     p.opix = (long long)n * oh * ow;
     p.chunk = stats_chunk(p.opix);
     p.dec = nullptr;
@@ -764,14 +784,13 @@ extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const flo
     VAD_REQUIRE(p.dout_ps % 4 == 0 && p.dout_fs % 4 == 0, "bn_act_pool_bwd: strides must be multiples of 4 floats");
     const int nb = (int)((p.opix + p.chunk - 1) / p.chunk);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_route_kernel, dim3(nb), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(nb), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, s, (const float*)ws, nb, c,
                        (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
-    const long long total = (long long)n * h * w * (c / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, y, stats, gamma, (const float*)ksums,
-                       (const float*)dz, dy, n, h, w, c, s2d, total);
+    p.dec = nullptr;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(p.opix * (c / 4))), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

@@ -14,7 +14,8 @@
 // Activation memory (fp32, per frame of H x W): every conv output before BatchNorm is kept (the backward recomputes
 // normalisation, activation and pooling from it), plus the pooled activations that feed the next conv and its weight
 // gradient: 30.4 MB per 256x256 frame; the ConvLSTM keeps its operand buffers [t][b][h][w][x|h], activated gates and
-// cell states for all t (BPTT).  Three scratch buffers of the largest activation size carry the gradients.
+// cell states for all t (BPTT).  Two scratch buffers of the largest activation size carry the gradients (the
+// BatchNorm backward re-derives the routed gradient instead of storing it).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -133,7 +134,9 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
         if (wg > max_wgrad) max_wgrad = wg;
     }
     p.dpre = take(N * (size_t)(H / 2) * (W / 2) * 32);
-    for (int i = 0; i < 3; ++i) p.g[i] = take(max_act);
+    p.g[0] = take(max_act);
+    p.g[2] = take(max_act);
+    p.g[1] = p.g[2];      // (was the materialised routed gradient; kept in the debug layout as an alias)
     p.ksums = take(2 * 1024);
     p.zeros = take(1024);
     p.chan_ws = take(max_chan);
@@ -146,7 +149,7 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
 }  // namespace
 
 // Debug: return from vad_vid_train_fwd_bwd right after the backward of decoder stage `j` (2, 1, 0), 10 + l after ConvLSTM
-// layer l, leaving the gradient scratch (g0 = gradient of that stage's input, g1 = dz, g2 = gradient of its conv output)
+// layer l, leaving the gradient scratch (g0 = gradient of that stage's input, g2 = gradient of its conv output)
 // in the workspace for inspection (tools/diag_stream.py).  -1 = run the whole step (default).
 static int g_vad_train_stop = -1;
 extern "C" int vad_debug_set_train_stop(int stage) { g_vad_train_stop = stage; return VAD_OK; }
@@ -268,7 +271,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         TRY(vad_bn_act_pool_fwd(u, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], ws + p.r[j], 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
     }
     // last layer + loss, forward and backward (models/video_autoencoder.py:259-260, train_video.py:55)
-    float *g0 = ws + p.g[0], *g1 = ws + p.g[1], *g2 = ws + p.g[2];
+    float *g0 = ws + p.g[0], *g2 = ws + p.g[2];
     TRY(vad_convt_to3_mse(ws + p.r[2], P + p.t_w, P + p.t_b, x, recon, g0, ws + p.dpre, loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, s));
 
     if (g_vad_train_stop == 20) return VAD_OK;      // debug: g0 = gradient of the last decoder activation, dpre intact
@@ -279,10 +282,13 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
         const float* in = j == 0 ? ws + p.hseq : ws + p.r[j - 1];
         // g0 = d r_j (dense, 2hj x 2wj) -> g2 = d u_j in the space-to-depth view [N][hj][wj][4*co]
-        TRY(vad_bn_act_pool_bwd(ws + p.u[j], ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g1, g2, 1, G + p.d_g[j], G + p.d_be[j],
+        TRY(vad_bn_act_pool_bwd(ws + p.u[j], ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.d_g[j], G + p.d_be[j],
                                 ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
         TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, s));
-        TRY(vad_chan_sum(g2, (long long)N * hj * wj * 4, co, G + p.d_b[j], ws + p.chan_ws, s));
+        // bias of a conv that feeds a batch-statistics BatchNorm: sum(dy) = gamma*invstd*(sum(dz) - M*k1 - k2*sum(xhat)) = 0
+        // exactly (the batch mean removes any constant).  Autograd returns ~1e-9 rounding noise there, which Adam turns
+        // into a +-lr random walk; an exact zero costs no pass over the tensor and leaves the bias where it is.
+        VAD_HIP_TRY(hipMemsetAsync(G + p.d_b[j], 0, (size_t)co * sizeof(float), s));
         TRY(vad_conv1x1(g2, ws + p.pk_d_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, s));     // g0 = d (input of convT j)
         if (g_vad_train_stop == j) return VAD_OK;
     }
@@ -311,12 +317,12 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     for (int k = 3; k >= 0; --k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         if (k == 3)
-            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.dcat[0], 0, L + Hd, T, B, g1, g2, 0,
+            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.dcat[0], 0, L + Hd, T, B, g2, 0,
                                     G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         else
-            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, g1, g2, 0,
+            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, g2, 0,
                                     G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
-        TRY(vad_chan_sum(g2, (long long)N * hk * wk, co, G + p.e_b[k], ws + p.chan_ws, s));
+        VAD_HIP_TRY(hipMemsetAsync(G + p.e_b[k], 0, (size_t)co * sizeof(float), s));      // structurally zero, see the decoder loop
         if (k == 0) {
             TRY(vad_conv_c3_wgrad(x, g2, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
         } else {

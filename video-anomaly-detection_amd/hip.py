@@ -87,7 +87,7 @@ SIGNATURES = {
     "vad_bn_stats": (_i, [_vp, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vad_chan_sum": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
     "vad_bn_act_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "vad_bn_act_pool_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+    "vad_bn_act_pool_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _i, _i, _vp]),
     "vad_lstm_gates_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _vp]),
     "vad_lstm_gates_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
