@@ -319,21 +319,32 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
     m = vad.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, 5).items()}, strict=True)
-    tr = vad.VideoTrainer(m.to(dev))
+    m = m.to(dev)
     x = vad.scoring.synth_frames_device(0xC0FFEE + 4, 0, clips * t, hw, hw, 3, dev).view(clips, t, 3, hw, hw)
-    first = None
-    for _ in range(warmup):
-        first = float(tr.step(x))
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tr.step(x)
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
-    out = {"value": round(clips * t / dt, 1), "unit": "frames/s trained", "ms_per_step": round(dt * 1e3, 3), "clips": clips, "t": t,
-           "dtype": "f32", "loss_first_last": [first, float(loss)], "workspace_GiB": round(tr._ws.numel() / 2**30, 2),
-           "algorithmic_tflops": round(3 * 3011510272.0 * (hw / 256.0) ** 2 * clips * t / dt / 1e12, 2)}
-    del tr, m, x
+    out = {"unit": "frames/s trained", "clips": clips, "t": t, "dtype": "f32"}
+    for precision in ("fp32", "split"):          # both start from the same weights: a fresh trainer re-reads the module
+        state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        tr = vad.VideoTrainer(m, precision=precision)
+        first = None
+        for _ in range(warmup):
+            first = float(tr.step(x))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(x)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        res = {"value": round(clips * t / dt, 1), "ms_per_step": round(dt * 1e3, 3), "loss_first_last": [first, float(loss)],
+               "algorithmic_tflops": round(3 * 3011510272.0 * (hw / 256.0) ** 2 * clips * t / dt / 1e12, 2)}
+        if precision == "fp32":
+            out.update(res)
+            out["workspace_GiB"] = round(tr._ws.numel() / 2**30, 2)
+        else:
+            out["split_precision"] = dict(res, arithmetic="3x3 / transposed convolutions (forward + data gradients) on split-fp16 operands, "
+                                                          "everything else fp32")
+        m.load_state_dict(state)
+        del tr
+    del m, x
     torch.cuda.empty_cache()
     return out
 

@@ -192,7 +192,8 @@ int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, const float* bi
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int vad_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, void* stream);
-/* Device-side operand packing of the CURRENT parameters (no BatchNorm folding in train mode):
+/* Device-side operand packing of the CURRENT parameters (no BatchNorm folding in train mode; the layout follows
+ * vad_set_precision like the host packers):
  * fwd = the forward kernels' order (vad_pack_conv3x3 / vad_pack_convt2x2 / vad_pack_conv3x3_c3 layouts);
  * dgrad = the data-gradient operand: for conv3x3 a conv3x3 weight with cin/cout swapped and taps rotated (run it
  * through vad_conv3x3), for convT a 1x1 weight with K = 4*cout (run vad_conv1x1 on the space-to-depth gradient). */
@@ -203,7 +204,8 @@ int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* s
 /* ------------------------------------------------------------------ whole training step (row f-1)
  * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim ==
  * latent_dim, lstm_num_layers): train-mode forward (batch-statistics BatchNorm, running stats updated when `running`
- * is given), nn.MSELoss, and the full backward.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
+ * is given), nn.MSELoss, and the full backward.  Exact fp32 by default; under vad_set_precision(1) the 3x3 and
+ * transposed convolutions (forward + data gradients) use the split-fp16 operands, the rest stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
  * floats, torch layouts in named_parameters() order (see csrc/train_step.hip); running: vad_vid_train_nstats floats,
  * {running_mean, running_var} per BatchNorm in module order.  x [B,T,3,H,W]; loss: device float[1];
  * recon (nullable) [B,T,3,H,W].  Every gradient is overwritten (no accumulation), so there is no zero_grad.

@@ -174,7 +174,19 @@ def test_lstm_gates_forward_backward(vad, nb, hw, hid, first):
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 32, 32), (3, 6, 10, 64, 32), (2, 16, 16, 256, 512), (40, 32, 32, 32, 64),
                                             (1, 2, 2, 128, 128), (2, 3, 3, 64, 128), (4, 7, 7, 128, 64), (2, 5, 3, 64, 128)])
-def test_conv3x3_weight_and_data_gradients(vad, n, h, w, cin, cout):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_conv3x3_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
+    """precision 1: the device packers emit the split-fp16 operand form and the forward / data-gradient convolutions run
+    on it (the weight gradient is fp32 in both modes)."""
+    l = vad.hip.lib()
+    assert l.vad_set_precision(precision) == 0
+    try:
+        _check_conv3x3_gradients(vad, n, h, w, cin, cout)
+    finally:
+        l.vad_set_precision(0)
+
+
+def _check_conv3x3_gradients(vad, n, h, w, cin, cout):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin + cout + h)
     a = rng.standard_normal((n, cin, h, w)).astype(np.float32)
@@ -205,7 +217,17 @@ def test_conv3x3_weight_and_data_gradients(vad, n, h, w, cin, cout):
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 4, 4, 128, 128), (3, 8, 6, 128, 64), (2, 16, 16, 64, 32), (8, 32, 32, 64, 32),
                                             (4, 28, 28, 64, 32), (4, 7, 7, 32, 128), (2, 5, 3, 128, 64)])
-def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
+    l = vad.hip.lib()
+    assert l.vad_set_precision(precision) == 0
+    try:
+        _check_convt2x2_gradients(vad, n, h, w, cin, cout)
+    finally:
+        l.vad_set_precision(0)
+
+
+def _check_convt2x2_gradients(vad, n, h, w, cin, cout):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin * 3 + cout + h)
     a = rng.standard_normal((n, cin, h, w)).astype(np.float32)

@@ -649,24 +649,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 
 // ------------------------------------------------------------------------------------------------ operand packing
 // torch layouts -> the kernels' MFMA operand orders, on the device (the parameters change every step)
-__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad) {
+// split != 0: the split-fp16 operand form of the same weights (csrc/pack.cpp, conv_pkernel.h): per 16 input channels and
+// output channel, two halves h of [8 x hi | 8 x lo] fp16 with hi = fp16(w), lo = fp16((w - hi) * 2^11); same byte count.
+__device__ __forceinline__ void put_split(float* dst, size_t group16, int k, float v) {      // k = channel index inside the 16
+    _Float16* o = (_Float16*)dst + (group16 * 2 + ((k >> 3) & 1)) * 16;
+    const _Float16 hi = (_Float16)v;
+    o[k & 7] = hi;
+    o[8 + (k & 7)] = (_Float16)((v - (float)hi) * 2048.0f);
+}
+
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad, int split) {
     const long long total = (long long)cout * cin * 9;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int tap = (int)(idx % 9), ci = (int)((idx / 9) % cin), co = (int)(idx / (9ll * cin));
         const float v = w[idx];
-        if (fwd) fwd[(((size_t)tap * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
         // data gradient = the same convolution with the taps rotated by 180 degrees and the channel roles swapped
-        if (dgrad) dgrad[(((size_t)(8 - tap) * (cout / 8) + co / 8) * cin + ci) * 8 + (co & 7)] = v;
+        if (split) {
+            if (fwd) put_split(fwd, ((size_t)tap * (cin / 16) + ci / 16) * cout + co, ci & 15, v);
+            if (dgrad) put_split(dgrad, ((size_t)(8 - tap) * (cout / 16) + co / 16) * cin + ci, co & 15, v);
+        } else {
+            if (fwd) fwd[(((size_t)tap * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
+            if (dgrad) dgrad[(((size_t)(8 - tap) * (cout / 8) + co / 8) * cin + ci) * 8 + (co & 7)] = v;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int cin, int cout, float* fwd, float* dgrad) {
+__global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int cin, int cout, float* fwd, float* dgrad, int split) {
     const long long total = (long long)cin * cout * 4;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int q = (int)(idx & 3), co = (int)((idx >> 2) % cout), ci = (int)(idx / (4ll * cout));
         const float v = w[idx];
-        if (fwd) fwd[(((size_t)q * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
-        // data gradient = 1x1 convolution over the space-to-depth gradient: K index q*cout+co, N index ci
+        if (fwd) {
+            if (split) put_split(fwd, ((size_t)q * (cin / 16) + ci / 16) * cout + co, ci & 15, v);
+            else fwd[(((size_t)q * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
+        }
+        // data gradient = 1x1 convolution over the space-to-depth gradient (K index q*cout+co, N index ci); that GEMM
+        // runs in exact fp32 in either mode
         if (dgrad) { const int kk = q * cout + co; dgrad[(((size_t)(kk / 8)) * cin + ci) * 8 + (kk & 7)] = v; }
     }
 }
@@ -937,14 +955,18 @@ extern "C" int vad_adam_step(float* p, const float* g, float* m, float* v, long 
 
 extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream) {
     VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv3x3: bad arguments");
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(9ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad);
+    const int split = vad_get_precision() == 1;       // the packed layout follows the arithmetic mode, like the host packers
+    VAD_REQUIRE(!split || (cin % 16 == 0 && (!dgrad || cout % 16 == 0)), "train_pack_conv3x3: split precision needs channel counts in multiples of 16");
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(9ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad, split);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
 
 extern "C" int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream) {
     VAD_REQUIRE(w_iohw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || (4 * cout) % 8 == 0), "train_pack_convt2x2: bad arguments");
-    hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad);
+    const int split = vad_get_precision() == 1;
+    VAD_REQUIRE(!split || cin % 16 == 0, "train_pack_convt2x2: split precision needs cin in multiples of 16");
+    hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad, split);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

@@ -204,7 +204,9 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
                                      const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
                                      float* loss, float* recon, void* stream) {
     VAD_REQUIRE(x && params && grads && workspace && loss, "vid_train_fwd_bwd: null pointer");
-    VAD_REQUIRE(vad_get_precision() == 0, "vid_train_fwd_bwd: training runs in exact fp32 (vad_set_precision(0))");
+    // Arithmetic mode (vad_set_precision): 0 = exact fp32 everywhere (the parity path); 1 = the 3x3 and transposed
+    // convolutions (forward and data gradients) take split-fp16 operands (22-bit products, fp32 accumulate), everything
+    // else - first layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam - stays fp32.
     Plan p;
     VAD_REQUIRE(make_plan(p, b, t, h, w, latent, hid, layers),
                 "vid_train_fwd_bwd: unsupported configuration (B=%d T=%d %dx%d latent=%d hid=%d layers=%d): H, W multiples of 16, "

@@ -47,7 +47,7 @@ class VideoTrainer:
     """Adam-on-MSE training steps for a `VideoAutoencoder` living on a GPU (exact fp32)."""
 
     def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
-                 eps: float = 1e-8, process_group=None):
+                 eps: float = 1e-8, process_group=None, precision: str = "fp32"):
         if not isinstance(model, VideoAutoencoder):
             raise hip.VadError("VideoTrainer drives a VideoAutoencoder")
         params = list(model.parameters())
@@ -56,6 +56,11 @@ class VideoTrainer:
         if model.in_channels != 3 or model.lstm_hidden_dim != model.latent_dim:
             raise hip.VadError("native training supports in_channels == 3 and lstm_hidden_dim == latent_dim "
                                f"(got {model.in_channels}, {model.lstm_hidden_dim} vs {model.latent_dim})")
+        if precision not in ("fp32", "split"):
+            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
+        #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
+        #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32
+        self.precision = precision
         self.model, self.group = model, process_group
         self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
         self.device = params[0].device
@@ -117,11 +122,16 @@ class VideoTrainer:
         out = torch.empty_like(x) if recon else None
         l = hip.lib()
         with torch.cuda.device(self.device):
-            if l.vad_get_precision() != 0:
-                hip.check(l.vad_set_precision(0), "vad_set_precision")
-            hip.check(l.vad_vid_train_fwd_bwd(x.data_ptr(), b, t, h, w, *self.cfg, self.flat.data_ptr(), self.grad.data_ptr(),
-                                              self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._loss.data_ptr(),
-                                              hip.ptr(out), hip.current_stream()), "vad_vid_train_fwd_bwd")
+            mode, before = (1 if self.precision == "split" else 0), l.vad_get_precision()
+            if before != mode:
+                hip.check(l.vad_set_precision(mode), "vad_set_precision")
+            try:
+                hip.check(l.vad_vid_train_fwd_bwd(x.data_ptr(), b, t, h, w, *self.cfg, self.flat.data_ptr(), self.grad.data_ptr(),
+                                                  self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._loss.data_ptr(),
+                                                  hip.ptr(out), hip.current_stream()), "vad_vid_train_fwd_bwd")
+            finally:
+                if before != mode:           # the switch is process-wide: leave it as found
+                    l.vad_set_precision(before)
         for m in self.bns:
             m.num_batches_tracked += 1
         hip.calls["train_step"] = hip.calls.get("train_step", 0) + 1
