@@ -173,7 +173,8 @@ int vad_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, 
  *   taps 9, layout 0: Conv2d k3 p1 weight gradient, dw OIHW (ncols, cin, 3, 3)
  *   taps 1, layout 1: ConvTranspose2d k2 s2 weight gradient from the space-to-depth output gradient
  *                     (ncols = 4*cout, column q*cout+co), dw IOHW (cin, cout, 2, 2)
- *   taps 1, layout 3: ConvTranspose2d(32->3) from the 32-column dpre of vad_convt_to3_mse, dw (32, 3, 2, 2) */
+ *   taps 1, layout 3: ConvTranspose2d(32->3) from the 32-column dpre of vad_convt_to3_mse, dw (32, 3, 2, 2)
+ *   taps 1, layout 4: Conv2d k1 (VideoAutoencoder.proj) weight gradient, dw OIHW (ncols, cin, 1, 1) */
 size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int ncols);
 int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
                    int taps, int layout, void* stream);
@@ -200,10 +201,12 @@ int vad_adam_step(float* p, const float* g, float* m, float* v, long long n, flo
 int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
 int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream);
 int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* stream);
+/* Conv2d k1 (cout, cin, 1, 1): fwd = vad_pack_conv1x1 layout; dgrad = the transposed 1x1 weight (K = cout, N = cin). */
+int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
 
 /* ------------------------------------------------------------------ whole training step (row f-1)
- * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim ==
- * latent_dim, lstm_num_layers): train-mode forward (batch-statistics BatchNorm, running stats updated when `running`
+ * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim,
+ * lstm_num_layers) (both dims multiples of 32, hidden <= 256; `proj` is the 1x1 conv when they differ): train-mode forward (batch-statistics BatchNorm, running stats updated when `running`
  * is given), nn.MSELoss, and the full backward.  Exact fp32 by default; under vad_set_precision(1) the 3x3 and
  * transposed convolutions (forward + data gradients) use the split-fp16 operands, the rest stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
  * floats, torch layouts in named_parameters() order (see csrc/train_step.hip); running: vad_vid_train_nstats floats,

@@ -20,6 +20,16 @@ pytestmark = pytest.mark.gpu
 LR, WD = 1e-4, 1e-5
 
 
+def _dims(latent):
+    """`latent` parameters may be (latent_dim, lstm_hidden_dim); a plain int means both are equal (proj = Identity)."""
+    return latent if isinstance(latent, tuple) else (latent, latent)
+
+
+def _make(vad, latent, layers):
+    lat, hid = _dims(latent)
+    return vad.VideoAutoencoder(in_channels=3, latent_dim=lat, lstm_hidden_dim=hid, lstm_num_layers=layers)
+
+
 def _bn_fed_biases(model):
     """names of conv / convT biases directly followed by BatchNorm (true gradient zero in train mode)"""
     names = []
@@ -32,7 +42,7 @@ def _bn_fed_biases(model):
 
 
 def _reference_steps(vad, latent, layers, wseed, x, steps):
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    m = _make(vad, latent, layers)
     load_synthetic(vad, m, wseed)
     m.train()
     opt = torch.optim.Adam(m.parameters(), lr=LR, weight_decay=WD)
@@ -51,7 +61,7 @@ def _reference_steps(vad, latent, layers, wseed, x, steps):
 
 def _fp64_grads(vad, latent, layers, wseed, x):
     """First-step gradients in float64 (same composition): the yardstick for BOTH fp32 evaluations."""
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    m = _make(vad, latent, layers)
     load_synthetic(vad, m, wseed)
     m = m.double().train()
     nn.MSELoss()(m(x.double()), x.double()).backward()
@@ -111,13 +121,14 @@ def _check_params(model, got_state, ref_state, init_state, steps):
 # batches, most encoder gradients by ~4e-3.  No fixed bound separates that from a real error (a looser one nearly hid the
 # E[x^2]-mean^2 variance defect of vad_bn_stats, found this way and fixed), so those sizes are checked exactly instead:
 # test_train_step_gradients_match_decision_conditioned_float64 below.
-@pytest.mark.parametrize("latent,layers,b,t,hw,wseed", [(64, 2, 2, 3, 32, 41), (64, 1, 3, 2, 32, 42), (32, 3, 1, 4, 64, 43)])
+@pytest.mark.parametrize("latent,layers,b,t,hw,wseed", [(64, 2, 2, 3, 32, 41), (64, 1, 3, 2, 32, 42), (32, 3, 1, 4, 64, 43),
+                                                        ((32, 64), 2, 2, 3, 32, 48)])
 def test_train_step_matches_autograd(vad, latent, layers, b, t, hw, wseed):
     steps = 3
     x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, hw, hw))
     ref_model, ref_losses, ref_grads = _reference_steps(vad, latent, layers, wseed, x, steps)
 
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    m = _make(vad, latent, layers)
     load_synthetic(vad, m, wseed)
     init = {k: v.detach().clone().numpy() for k, v in m.state_dict().items()}
     m = m.cuda()
@@ -139,8 +150,8 @@ def test_train_step_matches_autograd(vad, latent, layers, b, t, hw, wseed):
     got_state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     ref_state = {k: v.detach().numpy() for k, v in ref_model.state_dict().items()}
     _check_params(m, got_state, ref_state, init, steps)
-    if latent % 64:
-        return          # the eval-mode scoring kernels need lstm_hidden_dim % 64 == 0
+    if isinstance(latent, tuple) or latent % 64:
+        return          # the eval-mode scoring kernels need lstm_hidden_dim % 64 == 0 (and the oracle call below equal dims)
     # the trained weights are what the eval-mode scoring path now uses (packed-weight cache invalidated)
     m.eval()
     ref_model.eval()
@@ -158,7 +169,7 @@ def test_train_step_matches_reference_golden(vad, golden):
     g = golden("train_vid_l32.npz")
     latent, layers, b, t, hw, wseed, xseed, steps = (int(g[k]) for k in ("latent", "layers", "b", "t", "hw", "wseed", "xseed", "steps"))
     x = torch.from_numpy(vad.synth.clips(xseed, 0, b, t, 3, hw, hw)).cuda()
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    m = _make(vad, latent, layers)
     load_synthetic(vad, m, wseed)
     init = {k: v.detach().clone().numpy() for k, v in m.state_dict().items()}
     m = m.cuda()
@@ -198,8 +209,12 @@ def test_train_step_matches_reference_golden(vad, golden):
 def test_trainer_rejects_unsupported_models(vad):
     with pytest.raises(vad.hip.VadError, match="GPU"):
         vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32))
-    with pytest.raises(vad.hip.VadError, match="lstm_hidden_dim == latent_dim"):
-        vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=64, lstm_hidden_dim=32).cuda())
+    with pytest.raises(vad.hip.VadError, match="in_channels == 3"):
+        vad.VideoTrainer(vad.VideoAutoencoder(in_channels=1, latent_dim=32, lstm_hidden_dim=32).cuda())
+    with pytest.raises(vad.hip.VadError, match="does not support this configuration"):
+        vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=288).cuda())       # hidden > 256
+    with pytest.raises(vad.hip.VadError, match="precision"):
+        vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32).cuda(), precision="bf16")
     tr = vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32).cuda())
     with pytest.raises(vad.hip.VadError, match="multiples of 16"):
         tr.step(torch.zeros(1, 2, 3, 24, 24, device="cuda"))
@@ -242,7 +257,7 @@ def _record_decisions(vad, tr, x):
 def _conditioned_float64(vad, latent, layers, wseed, x, decisions):
     """float64 loss + gradients of the reference composition with the given branch decisions imposed; also returns, per
     stage, how many decisions differ from the float64 model's own and the largest margin among those."""
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    m = _make(vad, latent, layers)
     load_synthetic(vad, m, wseed)
     m = m.double().train()
     b, t, _, h, w = x.shape
@@ -265,8 +280,9 @@ def _conditioned_float64(vad, latent, layers, wseed, x, decisions):
             margins = torch.cat([gap.abs().reshape(-1), chosen[diff_sign].abs().reshape(-1)])
             report.append((f"enc{k}", int(diff_am.sum() + diff_sign.sum()), float(margins.max()) if margins.numel() else 0.0, d.numel()))
     h16, w16 = h // 16, w // 16
-    hs, _ = m.convlstm(cur.view(b, t, latent, h16, w16))
-    cur = hs.reshape(n, latent, h16, w16)
+    lat, hid = _dims(latent)
+    hs, _ = m.convlstm(cur.view(b, t, lat, h16, w16))
+    cur = m.proj(hs.reshape(n, hid, h16, w16))            # Identity, or the 1x1 conv when hidden != latent
     dec = list(m.decoder.decoder)
     for j in range(3):
         v = dec[3 * j + 1](dec[3 * j](cur))
@@ -282,14 +298,15 @@ def _conditioned_float64(vad, latent, layers, wseed, x, decisions):
 
 @pytest.mark.parametrize("latent,layers,b,t,hw,wseed", [(32, 3, 1, 4, 48, 43), (32, 3, 1, 4, 80, 43), (32, 3, 1, 4, 112, 43),
                                                         (32, 3, 1, 4, 64, 43), (64, 2, 2, 3, 32, 41), (64, 1, 2, 2, 96, 44),
-                                                        (32, 2, 2, 2, (48, 80), 45), (64, 2, 1, 3, (64, 32), 46)])
+                                                        (32, 2, 2, 2, (48, 80), 45), (64, 2, 1, 3, (64, 32), 46),
+                                                        ((32, 64), 2, 2, 3, 32, 48), ((64, 32), 1, 1, 3, 48, 49)])
 @pytest.mark.parametrize("precision", ["fp32", "split"])
 def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, layers, b, t, hw, wseed, precision):
     """precision "split": the 3x3 / transposed convolutions (forward and data gradients) on split-fp16 operands (22-bit
     products); same bounds - the mode is meant to be indistinguishable from fp32 at this level."""
     h, w = hw if isinstance(hw, tuple) else (hw, hw)          # non-square cases: H and W are carried separately everywhere
     x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, h, w))
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    m = _make(vad, latent, layers)
     load_synthetic(vad, m, wseed)
     m = m.cuda()
     tr = vad.VideoTrainer(m, lr=LR, weight_decay=WD, precision=precision)
@@ -328,7 +345,7 @@ def test_loss_curve_follows_cpu_autograd_over_many_steps(vad, precision):
     latent, layers, b, t, hw, wseed, steps = 64, 2, 2, 3, 32, 47, 25
     x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, hw, hw))
     lr = 1e-3                                    # larger than the reference's default so that 25 steps move the loss
-    ref = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    ref = _make(vad, latent, layers)
     load_synthetic(vad, ref, wseed)
     ref.train()
     opt, crit, want = torch.optim.Adam(ref.parameters(), lr=lr, weight_decay=WD), nn.MSELoss(), []
@@ -338,7 +355,7 @@ def test_loss_curve_follows_cpu_autograd_over_many_steps(vad, precision):
         loss.backward()
         opt.step()
         want.append(float(loss.detach()))
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=latent, lstm_num_layers=layers)
+    m = _make(vad, latent, layers)
     load_synthetic(vad, m, wseed)
     tr = vad.VideoTrainer(m.cuda(), lr=lr, weight_decay=WD, precision=precision)
     xd = x.cuda()

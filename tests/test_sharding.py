@@ -106,4 +106,5 @@ def test_training_layout_matches_module_parameters(vad, latent, hid, layers):
     assert l.vad_vid_train_nstats(latent, hid, layers) == sum(2 * b.num_features for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
     assert l.vad_vid_train_workspace_bytes(2, 3, 64, 64, latent, hid, layers) > 0
     assert l.vad_vid_train_workspace_bytes(2, 3, 60, 64, latent, hid, layers) == 0          # H not a multiple of 16
-    assert l.vad_vid_train_nparams(latent, hid + 32, layers) == 0                             # proj not supported natively
+    m2 = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid + 32, lstm_num_layers=layers)     # with proj
+    assert l.vad_vid_train_nparams(latent, hid + 32, layers) == (sum(p.numel() for p in m2.parameters()) if hid + 32 <= 256 else 0)

@@ -518,6 +518,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
 //   layout 1: ConvTranspose2d IOHW   col = q*cout + co -> dst[(ci*cout + co)*4 + q]    (taps 1, ncols = 4*cout)
 //   layout 2: first layer OIHW       rows k = c*9+tap of 32 -> dst[col*27 + k], k < 27 (taps 1, cin = 32 rows)
 //   layout 3: ConvTranspose2d(->3)   col = q*3 + c < 12 -> dst[(ci*3 + c)*4 + q]       (taps 1, ncols = 32)
+//   layout 4: Conv2d k1 OIHW         dst[col*cin + ci]                                 (taps 1)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int splits, int taps, int cin, int ncols, int layout,
                                                            float* dst) {
     // 64 consecutive elements x 4 slices of the split range per work-group; slice sums combined in a fixed order
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
     if (layout == 0) dst[((size_t)col * cin + ci) * 9 + tap] = s;
     else if (layout == 1) { const int cout = ncols / 4, q = col / cout, co = col - q * cout; dst[((size_t)ci * cout + co) * 4 + q] = s; }
     else if (layout == 2) { if (ci < 27) dst[(size_t)col * 27 + ci] = s; }
+    else if (layout == 4) dst[(size_t)col * cin + ci] = s;
     else if (col < 12) { const int q = col / 3, c = col - q * 3; dst[((size_t)ci * 3 + c) * 4 + q] = s; }
 }
 
@@ -686,6 +688,16 @@ __global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int 
         // data gradient = 1x1 convolution over the space-to-depth gradient (K index q*cout+co, N index ci); that GEMM
         // runs in exact fp32 in either mode
         if (dgrad) { const int kk = q * cout + co; dgrad[(((size_t)(kk / 8)) * cin + ci) * 8 + (kk & 7)] = v; }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_conv1x1_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad) {
+    const long long total = (long long)cout * cin;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int ci = (int)(idx % cin), co = (int)(idx / cin);
+        const float v = w[idx];
+        if (fwd) fwd[(((size_t)(ci / 8)) * cout + co) * 8 + (ci & 7)] = v;          // K = ci, N = co
+        if (dgrad) dgrad[(((size_t)(co / 8)) * cin + ci) * 8 + (co & 7)] = v;       // K = co, N = ci
     }
 }
 
@@ -855,7 +867,7 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
                               int taps, int layout, void* stream) {
     VAD_REQUIRE(a && g && dw && ws && n > 0 && h > 0 && w > 0, "conv_wgrad: bad arguments");
     VAD_REQUIRE(cin % 32 == 0 && ncols % 32 == 0 && cin > 0 && ncols > 0, "conv_wgrad: cin=%d ncols=%d must be multiples of 32", cin, ncols);
-    VAD_REQUIRE((taps == 9 && layout == 0) || (taps == 1 && (layout == 1 || layout == 3)), "conv_wgrad: taps/layout mismatch");
+    VAD_REQUIRE((taps == 9 && layout == 0) || (taps == 1 && (layout == 1 || layout == 3 || layout == 4)), "conv_wgrad: taps/layout mismatch");
     VAD_REQUIRE(layout != 1 || ncols % 128 == 0, "conv_wgrad: convT gradient needs ncols = 4*cout");
     VAD_REQUIRE(layout != 3 || (ncols == 32), "conv_wgrad: to3 gradient needs 32 columns");
     VAD_REQUIRE((long long)h * w * cin * 4 < (1ll << 31) && (long long)h * w * ncols * 4 < (1ll << 31), "conv_wgrad: frame too large for 32-bit offsets");
@@ -967,6 +979,13 @@ extern "C" int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, f
     const int split = vad_get_precision() == 1;
     VAD_REQUIRE(!split || cin % 16 == 0, "train_pack_convt2x2: split precision needs cin in multiples of 16");
     hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad, split);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream) {
+    VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv1x1: bad arguments");
+    hipLaunchKernelGGL(pack_conv1x1_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

@@ -7,6 +7,7 @@
 // data-parallel run needs one all-reduce.  Order (models/video_autoencoder.py:191-215, 299-316, 242-261):
 //   encoder.encoder.{0,4,8,12}: conv w (OIHW), conv b, then BatchNorm gamma, beta   channels 3->32->64->128->latent
 //   convlstm.cells.l.conv: w (4*hid, cin_l+hid, 3, 3), b                            cin_0 = latent, cin_l = hid
+//   proj (only when hid != latent): w (latent, hid, 1, 1), b                        models/video_autoencoder.py:311
 //   decoder.decoder.{0,3,6}: convT w (IOHW), b, BatchNorm gamma, beta               latent->128->64->32
 //   decoder.decoder.9: convT w (32,3,2,2), b
 // Running statistics: one flat buffer, {running_mean[c], running_var[c]} per BatchNorm in the order above.
@@ -33,13 +34,14 @@ struct Plan {
     int encC[5], decC[4];
     // parameter offsets (floats) into the flat buffer
     size_t e_w[4], e_b[4], e_g[4], e_be[4];
-    size_t l_w[8], l_b[8];
+    size_t l_w[8], l_b[8], pj_w, pj_b;
+    bool proj;
     size_t d_w[3], d_b[3], d_g[3], d_be[3];
     size_t t_w, t_b, nparams;
     size_t e_rs[4], d_rs[3], nstats;             // running stats offsets (mean at +0, var at +c)
     // workspace offsets (floats)
     size_t pk_e[4], pk_e_dg[4], pk_l[8], pk_l_dg[8], pk_d[3], pk_d_dg[3];
-    size_t y[4], a[3], st_e[4], cat[8], z[8], c[8], hseq, u[3], r[3], st_d[3], dpre;
+    size_t y[4], a[3], st_e[4], cat[8], z[8], c[8], hseq, pseq, pk_pj, pk_pj_dg, u[3], r[3], st_d[3], dpre;
     size_t g[3], dcat[8], dzl[8], dc, ksums, zeros, chan_ws, wgrad_ws, to3_ws;
     size_t ws_floats;
     int lstm_cin(int l) const { return l == 0 ? L : Hd; }
@@ -48,9 +50,10 @@ struct Plan {
 size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
-    if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16 || L <= 0 || L % 32 || Hd != L || NL < 1 || NL > 8) return false;
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16 || L <= 0 || L % 32 || Hd <= 0 || Hd % 32 || Hd > 256 || NL < 1 || NL > 8) return false;
     if ((long long)B * T > (1 << 20)) return false;
     p.B = B; p.T = T; p.H = H; p.W = W; p.L = L; p.Hd = Hd; p.NL = NL; p.N = B * T;
+    p.proj = Hd != L;
     p.h16 = H / 16; p.w16 = W / 16; p.hw = p.h16 * p.w16;
     for (int i = 0; i < 5; ++i) p.encC[i] = ENC_C[i];
     p.encC[4] = L;
@@ -68,6 +71,11 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     for (int l = 0; l < NL; ++l) {
         p.l_w[l] = o; o += (size_t)4 * Hd * (p.lstm_cin(l) + Hd) * 9;
         p.l_b[l] = o; o += (size_t)4 * Hd;
+    }
+    p.pj_w = p.pj_b = 0;
+    if (p.proj) {
+        p.pj_w = o; o += (size_t)L * Hd;
+        p.pj_b = o; o += L;
     }
     for (int j = 0; j < 3; ++j) {
         const int ci = p.decC[j], co = p.decC[j + 1];
@@ -116,6 +124,15 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     }
     p.dc = take((size_t)B * p.hw * Hd);
     p.hseq = take(N * p.hw * Hd);
+    p.pseq = p.pk_pj = p.pk_pj_dg = 0;
+    if (p.proj) {
+        p.pseq = take(N * p.hw * L);
+        p.pk_pj = take(vad_pack_conv1x1_floats(L, Hd));
+        p.pk_pj_dg = take(vad_pack_conv1x1_floats(Hd, L));
+        chan((long long)N * p.hw, L);
+        const size_t wg = vad_conv_wgrad_ws_floats(p.N, p.h16, 1, Hd, L);
+        if (wg > max_wgrad) max_wgrad = wg;
+    }
     for (int j = 0; j < 3; ++j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
         p.pk_d[j] = take(vad_pack_convt2x2_floats(ci, co));
@@ -210,7 +227,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     Plan p;
     VAD_REQUIRE(make_plan(p, b, t, h, w, latent, hid, layers),
                 "vid_train_fwd_bwd: unsupported configuration (B=%d T=%d %dx%d latent=%d hid=%d layers=%d): H, W multiples of 16, "
-                "latent multiple of 32, lstm_hidden_dim == latent_dim, 1..8 layers", b, t, h, w, latent, hid, layers);
+                "latent and hidden multiples of 32, hidden <= 256, 1..8 layers", b, t, h, w, latent, hid, layers);
     if (workspace_bytes < p.ws_floats * sizeof(float))
         return vad_fail(VAD_ERR_WS, "vid_train_fwd_bwd: workspace %zu bytes < %zu needed", workspace_bytes, p.ws_floats * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
@@ -230,6 +247,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         TRY(vad_train_pack_conv3x3(P + p.l_w[l], 4 * Hd, p.lstm_cin(l) + Hd, ws + p.pk_l[l], ws + p.pk_l_dg[l], s));
     for (int j = 0; j < 3; ++j)
         TRY(vad_train_pack_convt2x2(P + p.d_w[j], p.decC[j], p.decC[j + 1], ws + p.pk_d[j], ws + p.pk_d_dg[j], s));
+    if (p.proj) TRY(vad_train_pack_conv1x1(P + p.pj_w, L, Hd, ws + p.pk_pj, ws + p.pk_pj_dg, s));
 
     // ================================================================================== forward
     // encoder (models/video_autoencoder.py:191-215): conv -> BatchNorm(batch stats) -> LeakyReLU(0.2) -> MaxPool2
@@ -262,10 +280,16 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
             TRY(vad_lstm_gates_fwd(zt, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, h1, (long long)hw * cin, cin, h2, h2_fs, h2_ps, B, hw, Hd, s));
         }
     }
+    // proj (models/video_autoencoder.py:311-312, 346-349): Conv2d k1 hidden -> latent when the two differ, else Identity
+    const float* dec_in = ws + p.hseq;
+    if (p.proj) {
+        TRY(vad_conv1x1(ws + p.hseq, ws + p.pk_pj, P + p.pj_b, ws + p.pseq, (long long)N * hw, Hd, L, s));
+        dec_in = ws + p.pseq;
+    }
     // decoder (models/video_autoencoder.py:242-256): convT -> BatchNorm -> ReLU, three times
     for (int j = 0; j < 3; ++j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
-        const float* in = j == 0 ? ws + p.hseq : ws + p.r[j - 1];
+        const float* in = j == 0 ? dec_in : ws + p.r[j - 1];
         float* u = ws + p.u[j];
         TRY(vad_convt2x2(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, s));
         float* rs = running ? running + p.d_rs[j] : nullptr;
@@ -282,7 +306,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     TRY(vad_conv_wgrad(ws + p.r[2], ws + p.dpre, G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, s));
     for (int j = 2; j >= 0; --j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
-        const float* in = j == 0 ? ws + p.hseq : ws + p.r[j - 1];
+        const float* in = j == 0 ? dec_in : ws + p.r[j - 1];
         // g0 = d r_j (dense, 2hj x 2wj) -> g2 = d u_j in the space-to-depth view [N][hj][wj][4*co]
         TRY(vad_bn_act_pool_bwd(ws + p.u[j], ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.d_g[j], G + p.d_be[j],
                                 ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
@@ -294,14 +318,22 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         TRY(vad_conv1x1(g2, ws + p.pk_d_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, s));     // g0 = d (input of convT j)
         if (g_vad_train_stop == j) return VAD_OK;
     }
-    // g0 = d hseq [b*T+t][hw][Hd].  BPTT, top layer first.
+    // g0 = gradient of the decoder input [b*T+t][hw][L]; through proj when present
+    const float* dhseq = g0;
+    if (p.proj) {
+        TRY(vad_conv_wgrad(ws + p.hseq, g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, s));
+        TRY(vad_chan_sum(g0, (long long)N * hw, L, G + p.pj_b, ws + p.chan_ws, s));
+        TRY(vad_conv1x1(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, s));
+        dhseq = g2;
+    }
+    // dhseq = d hseq [b*T+t][hw][Hd].  BPTT, top layer first.
     for (int l = NL - 1; l >= 0; --l) {
         const int cx = p.lstm_cin(l), cin = cx + Hd;
         const size_t slab = (size_t)B * hw * cin;
         float* dc = ws + p.dc;
         for (int tt = T - 1; tt >= 0; --tt) {
             const float* dh1; long long dh1_fs; int dh1_ps;
-            if (l == NL - 1) { dh1 = g0 + (size_t)tt * hw * Hd; dh1_ps = Hd; dh1_fs = (long long)T * hw * Hd; }
+            if (l == NL - 1) { dh1 = dhseq + (size_t)tt * hw * Hd; dh1_ps = Hd; dh1_fs = (long long)T * hw * Hd; }
             else { dh1 = ws + p.dcat[l + 1] + (size_t)tt * B * hw * 2 * Hd; dh1_ps = 2 * Hd; dh1_fs = (long long)hw * dh1_ps; }
             const float* dh2 = tt + 1 < T ? ws + p.dcat[l] + (tt + 1) * slab + cx : nullptr;
             float* dzt = ws + p.dzl[l] + (size_t)tt * B * hw * 4 * Hd;

@@ -53,9 +53,8 @@ class VideoTrainer:
         params = list(model.parameters())
         if not params or not all(p.is_cuda for p in params):
             raise hip.VadError("VideoTrainer needs the model on a GPU: model.cuda() first (there is no CPU fallback)")
-        if model.in_channels != 3 or model.lstm_hidden_dim != model.latent_dim:
-            raise hip.VadError("native training supports in_channels == 3 and lstm_hidden_dim == latent_dim "
-                               f"(got {model.in_channels}, {model.lstm_hidden_dim} vs {model.latent_dim})")
+        if model.in_channels != 3:
+            raise hip.VadError(f"native training supports in_channels == 3 (got {model.in_channels})")
         if precision not in ("fp32", "split"):
             raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
         #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
