@@ -299,7 +299,8 @@ def _conditioned_float64(vad, latent, layers, wseed, x, decisions):
 @pytest.mark.parametrize("latent,layers,b,t,hw,wseed", [(32, 3, 1, 4, 48, 43), (32, 3, 1, 4, 80, 43), (32, 3, 1, 4, 112, 43),
                                                         (32, 3, 1, 4, 64, 43), (64, 2, 2, 3, 32, 41), (64, 1, 2, 2, 96, 44),
                                                         (32, 2, 2, 2, (48, 80), 45), (64, 2, 1, 3, (64, 32), 46),
-                                                        ((32, 64), 2, 2, 3, 32, 48), ((64, 32), 1, 1, 3, 48, 49)])
+                                                        ((32, 64), 2, 2, 3, 32, 48), ((64, 32), 1, 1, 3, 48, 49),
+                                                        (32, 1, 1, 1, 16, 50), (32, 2, 1, 2, (16, 32), 51), (64, 2, 3, 1, 32, 52)])
 @pytest.mark.parametrize("precision", ["fp32", "split"])
 def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, layers, b, t, hw, wseed, precision):
     """precision "split": the 3x3 / transposed convolutions (forward and data gradients) on split-fp16 operands (22-bit
