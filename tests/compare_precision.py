@@ -1,5 +1,9 @@
+"""Developer check (not collected by pytest): exact-fp32 vs split-fp16 scores of the image model against the CPU oracle
+and a float64 evaluation.  Lives under tests/ because it uses oracle/ as its checker.  Run on a GPU box:
+    python tests/compare_precision.py"""
 import importlib, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 vad = importlib.import_module("video-anomaly-detection_amd")
 from oracle import torch_oracle
 def synth_load(module, seed):
