@@ -364,3 +364,66 @@ def test_loss_curve_follows_cpu_autograd_over_many_steps(vad, precision):
     rel = [abs(a - r) / r for a, r in zip(got, want)]
     assert max(rel) < 5e-4, f"loss curves diverge: max rel {max(rel):.2e} at step {int(np.argmax(rel))}: {got[-3:]} vs {want[-3:]}"
     assert got[-1] < 0.8 * got[0], (got[0], got[-1])
+
+
+def test_optimizer_state_moves_between_native_trainer_and_torch_adam(vad, tmp_path):
+    """Checkpoint / resume (train_video.py:241-285 stores model_state_dict + optimizer_state_dict): run two steps in one
+    implementation, save both dicts with torch.save, load them into the OTHER implementation, take one more step in each -
+    the third-step loss and the parameters must agree, in both directions."""
+    latent, layers, b, t, hw, wseed = 64, 2, 2, 3, 32, 53
+    x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, hw, hw))
+    crit = nn.MSELoss()
+
+    def torch_steps(model, opt, n):
+        out = []
+        for _ in range(n):
+            loss = crit(model(x), x)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        return out
+
+    # --- native -> torch
+    m = _make(vad, latent, layers)
+    load_synthetic(vad, m, wseed)
+    tr = vad.VideoTrainer(m.cuda(), lr=LR, weight_decay=WD)
+    for _ in range(2):
+        tr.step(x.cuda())
+    torch.save({"model_state_dict": m.state_dict(), "optimizer_state_dict": tr.state_dict()}, tmp_path / "native.pth")
+    native_third = float(tr.step(x.cuda()))
+    ck = torch.load(tmp_path / "native.pth", map_location="cpu", weights_only=True)
+    ref = _make(vad, latent, layers)
+    ref.load_state_dict(ck["model_state_dict"])
+    ref.train()
+    opt = torch.optim.Adam(ref.parameters(), lr=LR, weight_decay=WD)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    torch_third = torch_steps(ref, opt, 1)[0]
+    assert abs(native_third - torch_third) < 2e-5 * torch_third
+    got, want = {k: v.cpu() for k, v in m.state_dict().items()}, ref.state_dict()
+    zero_true = _bn_fed_biases(m)
+    for k in want:
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(want[k])
+        elif k not in zero_true and "running_" not in k:
+            assert float((got[k] - want[k]).abs().mean()) < 0.02 * LR, k
+
+    # --- torch -> native
+    ref2 = _make(vad, latent, layers)
+    load_synthetic(vad, ref2, wseed)
+    ref2.train()
+    opt2 = torch.optim.Adam(ref2.parameters(), lr=LR, weight_decay=WD)
+    torch_steps(ref2, opt2, 2)
+    torch.save({"model_state_dict": ref2.state_dict(), "optimizer_state_dict": opt2.state_dict()}, tmp_path / "torch.pth")
+    torch_third = torch_steps(ref2, opt2, 1)[0]
+    ck = torch.load(tmp_path / "torch.pth", map_location="cpu", weights_only=True)
+    m2 = _make(vad, latent, layers)
+    m2.load_state_dict(ck["model_state_dict"])
+    tr2 = vad.VideoTrainer(m2.cuda(), lr=123.0)                 # hyper-parameters come from the checkpoint
+    tr2.load_state_dict(ck["optimizer_state_dict"])
+    assert tr2.steps == 2 and tr2.lr == LR and tr2.weight_decay == WD
+    native_third = float(tr2.step(x.cuda()))
+    assert abs(native_third - torch_third) < 2e-5 * torch_third
+    for k, v in ref2.state_dict().items():
+        if not k.endswith("num_batches_tracked") and k not in zero_true and "running_" not in k:
+            assert float((m2.state_dict()[k].cpu() - v).abs().mean()) < 0.02 * LR, k

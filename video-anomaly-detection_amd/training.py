@@ -146,6 +146,53 @@ class VideoTrainer:
                       "vad_adam_step")
         self.model._hip.key = None       # the eval-mode packed-weight cache is stale now
 
+    # ------------------------------------------------------------------------------------------- checkpoint / resume
+    def state_dict(self) -> dict:
+        """Optimiser state in `torch.optim.Adam.state_dict()` format (what train_video.py:244,279 stores as
+        'optimizer_state_dict'): loadable by a stock Adam over the same module, and vice versa."""
+        params = list(self.model.parameters())
+        state, off = {}, 0
+        for i, p in enumerate(params):
+            k = p.numel()
+            if self.steps > 0:
+                state[i] = {"step": torch.tensor(float(self.steps)),
+                            "exp_avg": self.exp_avg[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + k].view(p.shape).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Resume from a `torch.optim.Adam.state_dict()` (or this class's own): moments, step count and hyper-parameters."""
+        groups = sd.get("param_groups", [])
+        params = list(self.model.parameters())
+        if len(groups) != 1 or list(groups[0].get("params", [])) != list(range(len(params))):
+            raise hip.VadError("optimizer state does not describe one parameter group over this module's parameters")
+        g = groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("decoupled_weight_decay"):
+            raise hip.VadError("only plain Adam (no amsgrad / maximize / decoupled weight decay) is implemented")
+        self.lr, self.betas = float(g["lr"]), tuple(float(b) for b in g["betas"])
+        self.eps, self.weight_decay = float(g["eps"]), float(g["weight_decay"])
+        st = sd.get("state", {})
+        steps = {int(float(v["step"])) for v in st.values()}
+        if len(steps) > 1 or (st and len(st) != len(params)):
+            raise hip.VadError("per-parameter step counts differ: not a state this single-step-count optimiser can resume")
+        self.steps = steps.pop() if steps else 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        off = 0
+        for i, p in enumerate(params):
+            k = p.numel()
+            if st:
+                e = st[i] if i in st else st[str(i)]
+                if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                    raise hip.VadError(f"optimizer state of parameter {i} has shape {tuple(e['exp_avg'].shape)}, expected {tuple(p.shape)}")
+                self.exp_avg[off:off + k].copy_(e["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(e["exp_avg_sq"].reshape(-1))
+            off += k
+
     def step(self, clips: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's batch; with a process group the gradients are summed over ranks with ONE
         all-reduce of the flat buffer and averaged inside the optimiser kernel (DistributedDataParallel semantics)."""
