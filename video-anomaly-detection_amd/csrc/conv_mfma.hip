@@ -535,6 +535,123 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
     }
 }
 
+// Persistent form of the first layer.  The exact-fp32 floor of this layer is the matrix pipe, not HBM: K = 27 -> 28 costs 14
+// v_mfma_f32_32x32x2_f32 per 32-pixel M-tile (0.85 us per 256x256 frame when the pipe never idles), so the kernel is built
+// around keeping it fed: a work-group walks tiles of 32 rows x 16 columns (grid = resident slots), the 14 B fragments and
+// the bias live in registers for its whole life, every wave runs FOUR independent accumulator chains (its 4 M-tiles of
+// 2 rows x 16 columns) interleaved k-step by k-step, and the input halo of the NEXT tile is fetched into registers while
+// the current one is computed (3 planes x 34 x 18 values = 8 per thread).
+template <int POOL, int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
+    constexpr int MTW = 4, TH = 2 * MTW * 4, LH = TH + 2, RS = 20, NE = 3 * LH * 18, NST = (NE + 255) / 256;
+    __shared__ float tile[3 * LH * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int prow = (li >> 1) & 1, pcol = 2 * (li >> 2) + (li & 1);
+    int koff[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int o0 = ((k0 / 9) * LH + (k0 % 9) / 3) * RS + (k0 % 3);
+        const int o1 = (k1 < 27) ? ((k1 / 9) * LH + (k1 % 9) / 3) * RS + (k1 % 3) : 0;
+        koff[s] = lh ? o1 : o0;
+    }
+    const int ctiles = p.cout / 32;            // output-channel tiles, one after the other (one for every reference layer)
+    float pre[NST];
+    // staging element e = tid + 256*j -> (plane c, halo row ly, halo column lx); recomputed, not held in registers
+    auto fetch = [&](unsigned L) {
+        const int tx = L % p.tiles_x; L /= p.tiles_x;
+        const int ty = L % p.tiles_y;
+        const int n = L / p.tiles_y;
+        const float* xin = p.x + (size_t)n * 3 * p.h * p.w_;
+        const unsigned char* xin8 = (const unsigned char*)p.x + (size_t)n * 3 * p.h * p.w_;
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int e = tid + 256 * j, lx = e % 18, t = e / 18, ly = t % LH, c = t / LH;
+            const int gy = ty * TH - 1 + ly, gx = tx * 16 - 1 + lx;
+            float v = 0.f;
+            if (e < NE && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
+                v = p.xu8 ? vad_norm_u8(xin8[((size_t)gy * p.w_ + gx) * 3 + c]) : xin[((size_t)c * p.h + gy) * p.w_ + gx];
+            pre[j] = v;
+        }
+    };
+    // B fragments + bias: ONE register set, (re)loaded only when the channel tile changes - once per work-group for every
+    // reference layer.  (Without restrict the compiler cannot hoist loads out of the tile loop past the stores.)
+    float b[14], bv = 0.f;
+    int have = -1;
+    unsigned L = blockIdx.x;
+    if (L < p.nblocks) fetch(L);
+    for (; L < p.nblocks; L += gridDim.x) {
+        __syncthreads();                                   // every wave is done reading the previous tile
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int e = tid + 256 * j, lx = e % 18, t = e / 18;
+            if (e < NE) tile[((t / LH) * LH + t % LH) * RS + lx] = pre[j];
+        }
+        __syncthreads();
+        const unsigned Ln = L + gridDim.x;
+        if (Ln < p.nblocks) fetch(Ln);                     // in flight during the MFMAs below
+        unsigned t_ = L;
+        const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
+        const int ty = t_ % p.tiles_y;
+        const int n = t_ / p.tiles_y;
+        const int y0 = ty * TH, x0 = tx * 16;
+        for (int nt = 0; nt < ctiles; ++nt) {
+            const int co = nt * 32 + li;
+            if (have != nt) {
+#pragma unroll
+                for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
+                bv = p.bias[co];
+                have = nt;
+            }
+            f32x16 acc[MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] = bv;
+            // A operands through a two-deep register pipeline (4 LDS values per k-step), fenced per step: left alone the
+            // compiler hoists all 56 reads of a tile into registers and spills
+            const int abase = (2 * wave * MTW + prow) * RS + pcol;
+            float av[2][MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) av[0][mt] = tile[abase + 2 * mt * RS + koff[0]];
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                if (s + 1 < 14) {
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) av[(s + 1) & 1][mt] = tile[abase + 2 * mt * RS + koff[s + 1]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) acc[mt] = MFMA32(av[s & 1][mt], b[s], acc[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int wq = 2 * q + lh;
+                    float v[4];
+#pragma unroll
+                    for (int pos = 0; pos < 4; ++pos) v[pos] = vad_act(acc[mt][4 * q + pos], ACT);
+                    if (POOL) {
+                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        const int oy = (y0 >> 1) + (wave * MTW + mt), ox = (x0 >> 1) + wq;
+                        if (oy < (p.h >> 1) && ox < (p.w_ >> 1))
+                            p.out[(((size_t)n * (p.h >> 1) + oy) * (p.w_ >> 1) + ox) * p.cout + co] = m;
+                    } else {
+#pragma unroll
+                        for (int pos = 0; pos < 4; ++pos) {
+                            const int y = y0 + 2 * (wave * MTW + mt) + (pos >> 1), x = x0 + 2 * wq + (pos & 1);
+                            if (y < p.h && x < p.w_)
+                                p.out[(((size_t)n * p.h + y) * p.w_ + x) * p.cout + co] = v[pos];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 extern "C" int vad_conv3x3_c3(const float* x, const float* w, const float* bias, float* out,
                               int n, int h, int wd, int cout, int act, int pool, void* stream) {
     return vad_conv3x3_c3_fmt(x, VAD_X_F32_NCHW, w, bias, out, n, h, wd, cout, act, pool, stream);
@@ -547,12 +664,38 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && cout > 0 && cout % 32 == 0, "conv3x3_c3: bad shape");
     VAD_REQUIRE(!pool || (h % 2 == 0 && wd % 2 == 0), "conv3x3_c3: pooling needs even H,W");
     VAD_REQUIRE(act == VAD_ACT_LEAKY || act == VAD_ACT_RELU || act == VAD_ACT_NONE, "conv3x3_c3: bad act");
+    hipStream_t s = (hipStream_t)stream;
+    // persistent kernel (tiles of 32 rows x 16 columns) for the pooled form; the un-pooled form (training forward) writes
+    // 8.4 MB per 256x256 frame and is faster with many small work-groups in flight (measured 4.0 vs 6.5 us/frame)
+    if (g_vad_conv_variant != 0 && pool) {
+        ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 31) / 32, 0, fmt == VAD_X_U8_NHWC};
+        const long long nb = (long long)n * p.tiles_x * p.tiles_y;
+        VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");
+        p.nblocks = (unsigned)nb;
+#define C3P_LAUNCH(POOL, ACT)                                                                              \
+    {                                                                                                      \
+        static unsigned cap = 0;                                                                           \
+        if (!cap) cap = persistent_grid(conv3x3_c3_pkernel<POOL, ACT>, ~0u);                               \
+        hipLaunchKernelGGL((conv3x3_c3_pkernel<POOL, ACT>), dim3(p.nblocks < cap ? p.nblocks : cap), dim3(256), 0, s, p); \
+    }
+        if (pool) {
+            if (act == VAD_ACT_LEAKY) C3P_LAUNCH(1, VAD_ACT_LEAKY)
+            else if (act == VAD_ACT_RELU) C3P_LAUNCH(1, VAD_ACT_RELU)
+            else C3P_LAUNCH(1, VAD_ACT_NONE)
+        } else {
+            if (act == VAD_ACT_LEAKY) C3P_LAUNCH(0, VAD_ACT_LEAKY)
+            else if (act == VAD_ACT_RELU) C3P_LAUNCH(0, VAD_ACT_RELU)
+            else C3P_LAUNCH(0, VAD_ACT_NONE)
+        }
+#undef C3P_LAUNCH
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
     ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 15) / 16, 0, fmt == VAD_X_U8_NHWC};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");
     p.nblocks = (unsigned)nb;
     dim3 g((unsigned)nb), b(256);
-    hipStream_t s = (hipStream_t)stream;
 #define C3_LAUNCH(POOL, ACT) hipLaunchKernelGGL((conv3x3_c3_kernel<2, POOL, ACT>), g, b, 0, s, p)
     if (pool) {
         if (act == VAD_ACT_LEAKY) C3_LAUNCH(1, VAD_ACT_LEAKY);
