@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
             }
             const int x = x0 + (s - 7) + cg;
             if (y < H && x < W) {
-                const float rc[3] = {tanhf(r1[0] + b0), tanhf(r1[1] + b1), tanhf(r1[2] + b2)};
+                const float rc[3] = {vad_tanh(r1[0] + b0), vad_tanh(r1[1] + b1), vad_tanh(r1[2] + b2)};
                 const size_t o = (size_t)n * 3 * plane + (size_t)y * W + x;
                 float e = 0.f;
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
                 float2 xv;
                 if (p.xu8) xv = make_float2(tail_x(p, nx, co, 2 * y + a, 2 * x, h2, w2), tail_x(p, nx, co, 2 * y + a, 2 * x + 1, h2, w2));
                 else xv = *(const float2*)(p.x + ox + co * plane);
-                const float r0 = tanhf(acc[co * 4 + a * 2 + 0]), r1 = tanhf(acc[co * 4 + a * 2 + 1]);
+                const float r0 = vad_tanh(acc[co * 4 + a * 2 + 0]), r1 = vad_tanh(acc[co * 4 + a * 2 + 1]);
                 const float d0 = xv.x - r0, d1 = xv.y - r1;
                 ea[0] += d0 * d0;
                 ea[1] += d1 * d1;
