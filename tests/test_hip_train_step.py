@@ -20,6 +20,17 @@ pytestmark = pytest.mark.gpu
 LR, WD = 1e-4, 1e-5
 
 
+@pytest.fixture(autouse=True)
+def _fixed_cpu_threads():
+    """The CPU side of these comparisons (fp32 autograd) sums in an order that depends on the thread count; on a host with
+    a different core count IT could take the other branch on a near-zero activation (see the notes below).  Pin it, so the
+    reference trajectory is the same on every box."""
+    before = torch.get_num_threads()
+    torch.set_num_threads(4)
+    yield
+    torch.set_num_threads(before)
+
+
 def _dims(latent):
     """`latent` parameters may be (latent_dim, lstm_hidden_dim); a plain int means both are equal (proj = Identity)."""
     return latent if isinstance(latent, tuple) else (latent, latent)
