@@ -11,6 +11,16 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fixed_cpu_threads():
+    """CPU autograd is the reference here; its summation order (hence which side of zero a borderline activation falls on)
+    depends on the thread count.  Pinned so the reference is the same on every host."""
+    before = torch.get_num_threads()
+    torch.set_num_threads(4)
+    yield
+    torch.set_num_threads(before)
+
+
 def _rng(seed):
     return np.random.default_rng(seed)
 
