@@ -131,6 +131,13 @@ int vad_nchw_to_nhwc(const float* in, float* out, int n, int h, int w, int c, vo
 size_t vad_ssim_workspace_floats(long long planes, int h, int w);
 int vad_ssim_mse(const float* pred, const float* target, long long planes, int h, int w, int window_size,
                  float alpha, float* workspace, float* out3, void* stream);
+/* Gradient of out3[2] = (1-alpha)*MSE + alpha*(1 - mean SSIM) with respect to pred (alpha = 1: SSIMLoss, alpha = 0: MSE),
+ * times the upstream gradient grad_out (DEVICE scalar, so autograd needs no host synchronisation).  What autograd derives
+ * for utils/losses.py:51-121 when train.py:41-46 back-propagates through the criterion.  Two fused passes; workspace:
+ * vad_ssim_grad_workspace_floats floats (three adjoint maps). */
+size_t vad_ssim_grad_workspace_floats(long long planes, int h, int w);
+int vad_ssim_mse_backward(const float* pred, const float* target, long long planes, int h, int w, int window_size,
+                          float alpha, const float* grad_out, float* workspace, float* grad_pred, void* stream);
 
 /* ------------------------------------------------------------------ training-step kernels
  * The pieces of one optimisation step of train_video.py:44-65 (model.train(); MSELoss; backward; Adam), exact fp32,

@@ -315,8 +315,8 @@ def test_ssim_combined_losses_match_reference_golden(vad, golden):
 @pytest.mark.parametrize("shape,window", [((1, 3, 256, 256), 11), ((3, 1, 37, 53), 11), ((2, 3, 7, 5), 11),
                                           ((2, 2, 64, 33), 3), ((1, 3, 40, 40), 15), ((2, 3, 33, 64), 1)])
 def test_ssim_kernel_vs_torch_composition(vad, shape, window):
-    """Ragged sizes (tiles cut by the image edge, images smaller than the window) against the stock torch composition
-    of the same criterion evaluated on the CPU in fp64-free fp32, and the differentiable path is left untouched."""
+    """Ragged sizes (tiles cut by the image edge, images smaller than the window): forward against the stock torch
+    composition on the CPU, gradient with respect to the prediction against its float64 autograd."""
     rng = np.random.default_rng(shape[2] * 131 + window)
     t = torch.from_numpy(rng.uniform(-1, 1, shape).astype(np.float32))
     p = (t + torch.from_numpy(rng.normal(0, 0.2, shape).astype(np.float32))).clamp(-1, 1)
@@ -329,13 +329,31 @@ def test_ssim_kernel_vs_torch_composition(vad, shape, window):
         got = float(crit(p.cuda(), t.cuda()))
         got_ssim = float(crit.ssim(p.cuda(), t.cuda()))
     assert abs(got - ref) < 1e-5 * max(1.0, abs(ref)) and abs(got_ssim - ref_ssim) < 1e-5
-    # gradient wanted -> autograd path on the GPU, same value
+    # gradient wanted for the prediction -> HIP forward + HIP backward (vad_ssim_mse_backward), against float64 autograd of
+    # the composition on the CPU
+    crit64 = vad.CombinedLoss(alpha=0.4, window_size=window).double()
+    crit64.ssim.window = vad.losses._gaussian_window(window, shape[1]).double()
+    p64 = p.double().requires_grad_(True)
+    crit64(p64, t.double()).backward()
+    s64 = p.double().requires_grad_(True)
+    crit64.ssim(s64, t.double()).backward()
+    nf, nb = vad.hip.calls.get("ssim", 0), vad.hip.calls.get("ssim_backward", 0)
     pg = p.cuda().requires_grad_(True)
-    n0 = vad.hip.calls.get("ssim", 0)
     loss = crit(pg, t.cuda())
-    loss.backward()
-    assert vad.hip.calls.get("ssim", 0) == n0 and pg.grad is not None and abs(float(loss.detach()) - ref) < 1e-5
-
+    (loss * 3.0).backward()                                   # a non-trivial upstream gradient
+    sg = p.cuda().requires_grad_(True)
+    crit.ssim(sg, t.cuda()).backward()
+    assert vad.hip.calls["ssim"] == nf + 2 and vad.hip.calls["ssim_backward"] == nb + 2
+    assert abs(float(loss.detach()) - ref) < 1e-5
+    for got_g, want_g, scale in ((pg.grad.cpu() / 3.0, p64.grad, None), (sg.grad.cpu(), s64.grad, None)):
+        mx = float(want_g.abs().max())
+        assert float((got_g.double() - want_g).abs().max()) < 2e-4 * mx + 1e-12, f"gradient off by {float((got_g.double() - want_g).abs().max()):.3e} of {mx:.3e}"
+    # a target that needs a gradient falls back to the torch composition (autograd handles both inputs)
+    tg, pg2 = t.cuda().requires_grad_(True), p.cuda().requires_grad_(True)
+    nf = vad.hip.calls["ssim"]
+    crit(pg2, tg).backward()
+    assert vad.hip.calls["ssim"] == nf and tg.grad is not None
+    assert float((pg2.grad.cpu().double() - p64.grad).abs().max()) < 2e-4 * float(p64.grad.abs().max()) + 1e-12
 
 
 def test_ssim_rejects_unsupported_window(vad):

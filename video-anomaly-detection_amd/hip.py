@@ -83,6 +83,8 @@ SIGNATURES = {
     "vad_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_ssim_workspace_floats": (_sz, [_ll, _i, _i]),
     "vad_ssim_mse": (_i, [_vp, _vp, _ll, _i, _i, _i, C.c_float, _vp, _vp, _vp]),
+    "vad_ssim_grad_workspace_floats": (_sz, [_ll, _i, _i]),
+    "vad_ssim_mse_backward": (_i, [_vp, _vp, _ll, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "vad_chan_ws_floats": (_sz, [_ll, _i]),
     "vad_bn_stats": (_i, [_vp, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vad_chan_sum": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),

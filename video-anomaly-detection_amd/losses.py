@@ -1,11 +1,11 @@
 """`SSIMLoss` / `CombinedLoss` (reference utils/losses.py:14-121).
 
-Two paths, chosen by what the caller needs:
-* evaluation (GPU tensors that need no gradient: `torch.no_grad()` or inputs without `requires_grad`) runs the fused
-  HIP pass `vad_ssim_mse` (csrc/ssim.hip): both inputs are read once, the five blurred maps and the SSIM map never
-  reach memory, one launch returns 1-SSIM, MSE and their combination;
-* the differentiable training criterion (reference train.py:149-158 back-propagates through it) stays the stock
-  torch composition, on any device, so autograd works exactly as in the reference.
+On GPU fp32 tensors both directions are hand-written HIP (csrc/ssim.hip), wrapped in one `torch.autograd.Function`:
+* forward `vad_ssim_mse`: both inputs are read once, the five blurred maps and the SSIM map never reach memory, one launch
+  returns 1-SSIM, MSE and their combination;
+* backward `vad_ssim_mse_backward` (what reference train.py:41-46 needs when it back-propagates through the criterion):
+  the analytic adjoint in two fused passes, gradient with respect to the prediction.
+The stock torch composition remains for CPU tensors and for the unusual case where the TARGET needs a gradient.
 """
 from __future__ import annotations
 
@@ -27,9 +27,9 @@ def _gaussian_window(size: int, channels: int) -> torch.Tensor:
 
 
 def _hip_eligible(pred: torch.Tensor, target: torch.Tensor) -> bool:
-    """GPU tensors, fp32 [B,C,H,W], same shape, no gradient wanted: the fused HIP pass applies."""
-    needs_grad = torch.is_grad_enabled() and (pred.requires_grad or target.requires_grad)
-    return (pred.is_cuda and target.is_cuda and not needs_grad and pred.dim() == 4 and pred.shape == target.shape
+    """GPU tensors, fp32 [B,C,H,W], same shape, and no gradient wanted for the target: the fused HIP passes apply."""
+    target_grad = torch.is_grad_enabled() and target.requires_grad
+    return (pred.is_cuda and target.is_cuda and not target_grad and pred.dim() == 4 and pred.shape == target.shape
             and pred.dtype == torch.float32 and target.dtype == torch.float32)
 
 
@@ -51,6 +51,40 @@ def _hip_criteria(pred: torch.Tensor, target: torch.Tensor, window_size: int, al
     return out
 
 
+class _HipCriterion(torch.autograd.Function):
+    """(pred, target) -> out3[which]; backward = vad_ssim_mse_backward with the matching alpha (which 0: SSIM only -> 1,
+    which 2: the combination -> alpha)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, window_size, alpha, which):
+        out = _hip_criteria(pred.detach(), target.detach(), window_size, alpha)
+        ctx.save_for_backward(pred.detach(), target.detach())
+        ctx.window_size, ctx.alpha = int(window_size), (1.0 if which == 0 else float(alpha))
+        return out[which].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, target = ctx.saved_tensors
+        pred, target = pred.contiguous(), target.contiguous()
+        l = hip.lib()
+        b, c, h, w = pred.shape
+        ws = torch.empty(l.vad_ssim_grad_workspace_floats(b * c, h, w), dtype=torch.float32, device=pred.device)
+        grad = torch.empty_like(pred)
+        go = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(pred.device):
+            hip.check(l.vad_ssim_mse_backward(pred.data_ptr(), target.data_ptr(), b * c, h, w, ctx.window_size, ctx.alpha,
+                                              go.data_ptr(), ws.data_ptr(), grad.data_ptr(), hip.current_stream()),
+                      "vad_ssim_mse_backward")
+        hip.calls["ssim_backward"] = hip.calls.get("ssim_backward", 0) + 1
+        return grad, None, None, None, None
+
+
+def _hip_loss(pred, target, window_size, alpha, which):
+    if torch.is_grad_enabled() and pred.requires_grad:
+        return _HipCriterion.apply(pred, target, window_size, alpha, which)
+    return _hip_criteria(pred, target, window_size, alpha)[which]
+
+
 class SSIMLoss(nn.Module):
     """1 - mean SSIM with an 11x11 sigma-1.5 Gaussian window (reference utils/losses.py:14-93)."""
 
@@ -62,7 +96,7 @@ class SSIMLoss(nn.Module):
 
     def forward(self, pred: torch.Tensor, target: torch.Tensor):
         if _hip_eligible(pred, target):
-            return _hip_criteria(pred, target, self.window_size, 1.0)[0]
+            return _hip_loss(pred, target, self.window_size, 1.0, 0)
         if self.window.device != pred.device:
             self.window = self.window.to(pred.device)
         groups, pad, win = pred.shape[1], self.window_size // 2, self.window
@@ -89,5 +123,5 @@ class CombinedLoss(nn.Module):
 
     def forward(self, pred: torch.Tensor, target: torch.Tensor):
         if _hip_eligible(pred, target):
-            return _hip_criteria(pred, target, self.ssim.window_size, float(self.alpha))[2]
+            return _hip_loss(pred, target, self.ssim.window_size, float(self.alpha), 2)
         return (1 - self.alpha) * self.mse(pred, target) + self.alpha * self.ssim(pred, target)
