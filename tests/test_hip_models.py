@@ -360,3 +360,44 @@ def test_ssim_rejects_unsupported_window(vad):
     x = torch.zeros(1, 3, 32, 32, device="cuda")
     with torch.no_grad(), pytest.raises(vad.hip.VadError, match="window_size"):
         vad.SSIMLoss(window_size=17)(x, x)
+
+
+# ------------------------------------------------------------------------------------------------ error contract of the C ABI
+def test_c_abi_reports_errors_before_launching(vad):
+    """include/vad_hip.h: every entry point returns VAD_OK or a negative VAD_ERR_* and vad_last_error() carries the text.
+    Argument, workspace and configuration errors are detected on the host, before any kernel is launched."""
+    l = vad.hip.lib()
+    ERR_ARG, ERR_WS = -1, -3
+    m, _ = _img_model(vad, 64, 5)
+    x = vad.scoring.synth_frames_device(1, 0, 2, 64, 64)
+    packed = m._packed(x.device)
+    need = l.vad_img_workspace_bytes(2, 64, 64, 64)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    scores = torch.full((2,), float("nan"), device="cuda")
+    s = vad.hip.current_stream()
+    # too small a workspace
+    rc = l.vad_img_score(x.data_ptr(), 2, 64, 64, 64, packed.data_ptr(), ws.data_ptr(), need - 1, 2, scores.data_ptr(), None, None, None, s)
+    assert rc == ERR_WS and b"workspace" in l.vad_last_error()
+    # null input, no output requested, frame size not a multiple of 16
+    assert l.vad_img_score(None, 2, 64, 64, 64, packed.data_ptr(), ws.data_ptr(), need, 2, scores.data_ptr(), None, None, None, s) == ERR_ARG
+    assert l.vad_img_score(x.data_ptr(), 2, 64, 64, 64, packed.data_ptr(), ws.data_ptr(), need, 2, None, None, None, None, s) == ERR_ARG
+    assert l.vad_img_workspace_bytes(2, 60, 64, 64) == 0 and l.vad_img_packed_floats(1, 64) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(scores).all()                       # nothing ran
+    # the same call with a correct workspace works
+    assert l.vad_img_score(x.data_ptr(), 2, 64, 64, 64, packed.data_ptr(), ws.data_ptr(), need, 2, scores.data_ptr(), None, None, None, s) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(scores).all()
+    # training entry point: workspace and configuration errors
+    cfg = (32, 32, 1)
+    n = l.vad_vid_train_nparams(*cfg)
+    flat, grad, loss = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+    clips = torch.zeros(1, 2, 3, 32, 32, device="cuda")
+    tb = l.vad_vid_train_workspace_bytes(1, 2, 32, 32, *cfg)
+    tws = torch.empty(tb, dtype=torch.uint8, device="cuda")
+    assert l.vad_vid_train_fwd_bwd(clips.data_ptr(), 1, 2, 32, 32, *cfg, flat.data_ptr(), grad.data_ptr(), None, tws.data_ptr(), tb - 1,
+                                   loss.data_ptr(), None, s) == ERR_WS
+    assert l.vad_vid_train_fwd_bwd(clips.data_ptr(), 1, 2, 24, 32, *cfg, flat.data_ptr(), grad.data_ptr(), None, tws.data_ptr(), tb,
+                                   loss.data_ptr(), None, s) == ERR_ARG and b"multiples of 16" in l.vad_last_error()
+    assert l.vad_adam_step(flat.data_ptr(), grad.data_ptr(), flat.data_ptr(), flat.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1.0, s) == ERR_ARG   # step >= 1
+    assert l.vad_set_precision(7) == ERR_ARG and l.vad_get_precision() == 0
