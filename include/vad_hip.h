@@ -208,6 +208,16 @@ int vad_adam_step(float* p, const float* g, float* m, float* v, long long n, flo
 int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
 int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream);
 int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* stream);
+/* Conv2d(cin->3) k3 (ConvAutoencoder's last conv, models/autoencoder.py:134): fwd = vad_pack_conv3x3_to3 layout for the
+ * scoring tail kernel; dgrad_c3 = the rotated weights in vad_pack_conv3x3_c3 form (vad_pack_conv3x3_c3_floats(cin) floats):
+ * the data gradient is a 3->cin first-layer convolution of the pre-activation gradient. */
+int vad_train_pack_conv3x3_to3(const float* w_oihw, int cin, float* fwd, float* dgrad_c3, void* stream);
+/* Backward of Conv2d(32->3,k3,p1)+Tanh: recon = tanh(conv(in)) [n,3,h,w]; the upstream gradient is either drecon [n,3,h,w]
+ * or (drecon NULL) that of nn.MSELoss against x.  Outputs: dpre scratch [n,3,h,w], din [n,h,w,32], dw (3,32,3,3), db3 [3]. */
+size_t vad_conv3x3_to3_bwd_ws_floats(int n, int h, int w, int cin);
+int vad_conv3x3_to3_tanh_bwd(const float* in_nhwc, const float* recon, const float* x, const float* drecon,
+                             const float* w_dgrad_c3, float* dpre, float* din, float* dw, float* db3, float* ws,
+                             int n, int h, int w, int cin, void* stream);
 /* Conv2d k1 (cout, cin, 1, 1): fwd = vad_pack_conv1x1 layout; dgrad = the transposed 1x1 weight (K = cout, N = cin). */
 int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
 

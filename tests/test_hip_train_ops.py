@@ -340,3 +340,43 @@ def test_adam_matches_torch_optim(vad):
         assert d < 2e-7, f"step {step}: parameter difference {d:.3e} (updates are ~1e-4)"
     # the update itself (not just p) agrees: compare the accumulated displacement
     _close(pd.cpu().numpy() - p0, pt.detach().numpy() - p0, 2e-3, "displacement")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 32, 48), (5, 64, 64), (1, 48, 16)])
+@pytest.mark.parametrize("given_drecon", [False, True])
+def test_image_last_layer_conv_tanh_backward(vad, n, h, w, given_drecon):
+    """ConvAutoencoder's last layer in train mode (models/autoencoder.py:134-135): forward through the scoring tail kernel on
+    device-packed weights; backward with the gradient either of nn.MSELoss (computed inside) or handed in (the SSIM /
+    combined criterion's)."""
+    import hip_helpers as H
+    l, rng = vad.hip.lib(), _rng(n * 7 + h + w)
+    a = np.maximum(rng.standard_normal((n, 32, h, w)), 0).astype(np.float32)
+    x = rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((3, 32, 3, 3)) / np.sqrt(288)).astype(np.float32)
+    b = (rng.standard_normal(3) * 0.1).astype(np.float32)
+    R = rng.standard_normal((n, 3, h, w)).astype(np.float32)
+    at, wtt, bt = (torch.from_numpy(v).requires_grad_(True) for v in (a, wt, b))
+    rec = torch.tanh(F.conv2d(at, wtt, bt, padding=1))
+    loss = (rec * torch.from_numpy(R)).sum() if given_drecon else F.mse_loss(rec, torch.from_numpy(x))
+    loss.backward()
+
+    ad, xd, wd, bd = H.nhwc(a), H.dev(x), H.dev(wt), H.dev(b)
+    fwd = _ws(l.vad_pack_conv3x3_to3_floats(32))
+    dgr = torch.zeros(l.vad_pack_conv3x3_c3_floats(32), device="cuda")
+    vad.hip.check(l.vad_train_pack_conv3x3_to3(wd.data_ptr(), 32, fwd.data_ptr(), dgr.data_ptr(), H.stream()))
+    recon = torch.full((n, 3, h, w), float("nan"), device="cuda")
+    parts = _ws(n * l.vad_score_partials(0, h, w))
+    vad.hip.check(l.vad_conv3x3_to3_score(ad.data_ptr(), fwd.data_ptr(), bd.data_ptr(), xd.data_ptr(), parts.data_ptr(), recon.data_ptr(), None,
+                                          n, h, w, 32, H.stream()))
+    _close(recon.cpu().numpy(), rec.detach().numpy(), 2e-6, "recon")
+    dpre = torch.full((n, 3, h, w), float("nan"), device="cuda")
+    din = torch.full((n, h, w, 32), float("nan"), device="cuda")
+    dw, db = torch.full((3, 32, 3, 3), float("nan"), device="cuda"), _ws(3)
+    ws = _ws(l.vad_conv3x3_to3_bwd_ws_floats(n, h, w, 32))
+    Rd = H.dev(R)
+    vad.hip.check(l.vad_conv3x3_to3_tanh_bwd(ad.data_ptr(), recon.data_ptr(), None if given_drecon else xd.data_ptr(),
+                                             Rd.data_ptr() if given_drecon else None, dgr.data_ptr(), dpre.data_ptr(), din.data_ptr(),
+                                             dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, h, w, 32, H.stream()))
+    _close(H.to_nchw(din), at.grad.numpy(), 1e-4, "d input")
+    _close(dw.cpu().numpy(), wtt.grad.numpy(), 1e-4, "dW")
+    _close(db.cpu().numpy(), bt.grad.numpy(), 1e-4, "d bias")

@@ -709,6 +709,65 @@ __global__ __launch_bounds__(256) void pack_conv3x3_c3_kernel(const float* w, in
     }
 }
 
+// ------------------------------------------------------------------------------------ image autoencoder: last layer
+// Conv2d(32->3, k3, p1) + Tanh (models/autoencoder.py:134-135) in train mode.  Forward = the scoring tail kernel on
+// device-packed weights.  Backward: dpre = d(recon) * (1 - recon^2) as three NCHW planes; with the roles swapped the first
+// layer's kernels do the rest - the data gradient is a 3->32 convolution of dpre with the rotated weights
+// (vad_conv3x3_c3), the weight gradient is the first-layer weight gradient of (x := dpre, g := input activation), read back
+// with taps mirrored.
+__global__ __launch_bounds__(256) void pack_conv3x3_to3_train_kernel(const float* w, int cin, float* fwd, float* dgrad_c3) {
+    const int total = 3 * cin * 9;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int tap = idx % 9, ci = (idx / 9) % cin, co = idx / (9 * cin);
+        const float v = w[idx];
+        if (fwd) fwd[(size_t)(ci / 4) * 108 + tap * 12 + (ci & 3) * 3 + co] = v;
+        if (dgrad_c3) {
+            dgrad_c3[(size_t)(co * 9 + (8 - tap)) * cin + ci] = v;           // row k = c*9 + tap' of the [28][cin] first-layer form
+            if (co == 0 && tap == 0) dgrad_c3[(size_t)27 * cin + ci] = 0.f;  // padding row
+        }
+    }
+}
+
+// dpre[n][c][y][x] = g * (1 - recon^2), g = drecon (given) or gscale * (recon - x); per-block partial sums of dpre for the
+// bias gradient: parts[(n*3 + c) * chunks + chunk]
+__global__ __launch_bounds__(256) void tanh_bwd_planes_kernel(const float* recon, const float* x, const float* drecon, float gscale,
+                                                              float* dpre, float* parts, long long plane, int chunks) {
+    __shared__ float red[4];
+    const long long pl = blockIdx.y, base = pl * plane;
+    const long long per = (plane + chunks - 1) / chunks, i0 = (long long)blockIdx.x * per, i1 = (i0 + per < plane) ? i0 + per : plane;
+    float s = 0.f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float r = recon[base + i];
+        const float g = drecon ? drecon[base + i] : gscale * (r - x[base + i]);
+        const float d = g * (1.f - r * r);
+        dpre[base + i] = d;
+        s += d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[pl * chunks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void bias3_finalize_kernel(const float* parts, int n, int chunks, float* db3) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n * chunks; i += 64) s += (double)parts[((size_t)(i / chunks) * 3 + c) * chunks + i % chunks];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) db3[c] = (float)s;
+}
+
+// dW[c][ci][tap] = tmp[ci][c][8 - tap]   (tmp = first-layer weight gradient of the swapped-role problem, OIHW (cin,3,3,3))
+__global__ __launch_bounds__(256) void mirror_last_wgrad_kernel(const float* tmp, int cin, float* dw) {
+    const int total = 3 * cin * 9;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int tap = idx % 9, ci = (idx / 9) % cin, c = idx / (9 * cin);
+        dw[idx] = tmp[((size_t)ci * 3 + c) * 9 + (8 - tap)];
+    }
+}
+
 unsigned grid_for(long long total) {
     long long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
@@ -993,6 +1052,49 @@ extern "C" int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, fl
 extern "C" int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* stream) {
     VAD_REQUIRE(w_oihw && fwd && cout > 0, "train_pack_conv3x3_c3: bad arguments");
     hipLaunchKernelGGL(pack_conv3x3_c3_kernel, dim3(grid_for(28ll * cout)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, fwd);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// ------------------------------------------------------------------------------------ image autoencoder: last layer (host)
+extern "C" int vad_train_pack_conv3x3_to3(const float* w_oihw, int cin, float* fwd, float* dgrad_c3, void* stream) {
+    VAD_REQUIRE(w_oihw && (fwd || dgrad_c3) && cin > 0 && cin % 4 == 0, "train_pack_conv3x3_to3: bad arguments");
+    hipLaunchKernelGGL(pack_conv3x3_to3_train_kernel, dim3(grid_for(27ll * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cin, fwd, dgrad_c3);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+static int to3_chunks(int h, int w) { const long long plane = (long long)h * w; return (int)((plane + 16383) / 16384); }
+
+// ws = [bias partials n*3*chunks][64: zero bias for the data-gradient conv][tmp weight gradient cin*27][first-layer wgrad ws]
+extern "C" size_t vad_conv3x3_to3_bwd_ws_floats(int n, int h, int w, int cin) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cin % 32) return 0;
+    return (size_t)n * 3 * to3_chunks(h, w) + 64 + (size_t)cin * 27 + vad_conv_c3_wgrad_ws_floats(n, h, cin);
+}
+
+extern "C" int vad_conv3x3_to3_tanh_bwd(const float* in_nhwc, const float* recon, const float* x, const float* drecon,
+                                        const float* w_dgrad_c3, float* dpre, float* din, float* dw, float* db3, float* ws,
+                                        int n, int h, int w, int cin, void* stream) {
+    VAD_REQUIRE(in_nhwc && recon && (x || drecon) && w_dgrad_c3 && dpre && din && dw && db3 && ws, "conv3x3_to3_tanh_bwd: null pointer");
+    VAD_REQUIRE(n > 0 && h > 0 && w > 0 && cin == 32, "conv3x3_to3_tanh_bwd: bad shape (the reference's last conv has 32 input channels)");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = to3_chunks(h, w);
+    float* parts = ws;
+    float* zero_bias = ws + (size_t)n * 3 * chunks;
+    float* tmp = zero_bias + 64;
+    float* wws = tmp + (size_t)cin * 27;
+    VAD_HIP_TRY(hipMemsetAsync(zero_bias, 0, 64 * sizeof(float), s));
+    const double count = (double)n * 3.0 * h * w;
+    hipLaunchKernelGGL(tanh_bwd_planes_kernel, dim3(chunks, n * 3), dim3(256), 0, s, recon, x, drecon, (float)(2.0 / count), dpre, parts,
+                       (long long)h * w, chunks);
+    VAD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias3_finalize_kernel, dim3(3), dim3(64), 0, s, (const float*)parts, n, chunks, db3);
+    VAD_LAUNCH_CHECK();
+    int rc = vad_conv3x3_c3(dpre, w_dgrad_c3, zero_bias, din, n, h, w, cin, VAD_ACT_NONE, 0, stream);      // data gradient
+    if (rc != VAD_OK) return rc;
+    rc = vad_conv_c3_wgrad(dpre, in_nhwc, tmp, wws, n, h, w, cin, stream);                                  // swapped-role weight gradient
+    if (rc != VAD_OK) return rc;
+    hipLaunchKernelGGL(mirror_last_wgrad_kernel, dim3(grid_for(27ll * cin)), dim3(256), 0, s, (const float*)tmp, cin, dw);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

@@ -104,6 +104,9 @@ SIGNATURES = {
     "vad_train_pack_convt2x2": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "vad_train_pack_conv3x3_c3": (_i, [_vp, _i, _vp, _vp]),
     "vad_train_pack_conv1x1": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "vad_train_pack_conv3x3_to3": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "vad_conv3x3_to3_bwd_ws_floats": (_sz, [_i, _i, _i, _i]),
+    "vad_conv3x3_to3_tanh_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_vid_train_nparams": (_sz, [_i, _i, _i]),
     "vad_vid_train_nstats": (_sz, [_i, _i, _i]),
     "vad_vid_train_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
