@@ -245,6 +245,16 @@ int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent
                           const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
                           float* loss, float* recon, void* stream);
 
+/* Image autoencoder counterpart (train.py:28-52; not a SURVEY section 8 row): ConvAutoencoder(in_channels=3, latent_dim), x
+ * [N,3,H,W]; loss_kind 0 = nn.MSELoss (train.py default), 1 = SSIMLoss(window_size), 2 = CombinedLoss(alpha, window_size)
+ * (train.py:149-158).  Same flat-buffer conventions as the video step; exact fp32 only. */
+size_t vad_img_train_nparams(int latent);
+size_t vad_img_train_nstats(int latent);
+size_t vad_img_train_workspace_bytes(int n, int h, int w, int latent);
+int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int latent, const float* params, float* grads,
+                          float* running, void* workspace, size_t workspace_bytes, int loss_kind, float alpha,
+                          int window_size, float* loss, float* recon, void* stream);
+
 /* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1]. */
 int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_frame, long long n,
                      int c, int h, int w, int anomalies, void* stream);

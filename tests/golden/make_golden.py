@@ -200,6 +200,39 @@ def train_fixture(name, latent=32, layers=2, b=2, t=3, hw=32, wseed=61, xseed=16
           hw=np.array(hw), wseed=np.array(wseed), xseed=np.array(xseed), steps=np.array(steps), stride=np.array(stride), **arrays)
 
 
+def train_img_fixture(name, latent=32, n=3, hw=32, wseed=71, xseed=171, steps=3, stride=23):
+    """The reference's image training step (train.py:28-52,149-159): ConvAutoencoder.train(), nn.MSELoss (the default
+    criterion) and CombinedLoss(alpha=0.5) from the reference's utils/losses.py, torch.optim.Adam(lr 1e-3, weight_decay 1e-5),
+    `steps` steps on one seeded batch.  Stored per criterion: losses, norms + strided samples of the first-step gradients,
+    strided samples of the final state dict."""
+    arrays = {}
+    x = torch.from_numpy(synth.frames(xseed, 0, n, 3, hw, hw))
+    for tag, crit in (("mse", torch.nn.MSELoss()), ("combined", ref_losses.CombinedLoss(alpha=0.5))):
+        m = ref_ae.ConvAutoencoder(in_channels=3, latent_dim=latent)
+        _load_synth(m, wseed)
+        m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        losses = []
+        for s in range(steps):
+            loss = crit(m(x), x)
+            opt.zero_grad()
+            loss.backward()
+            if s == 0:
+                arrays["param_keys"] = np.array([k for k, _ in m.named_parameters()])
+                arrays[f"{tag}_grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+                for i, (_, p) in enumerate(m.named_parameters()):
+                    arrays[f"{tag}_grad_{i}"] = p.grad.detach().reshape(-1)[::stride].numpy().copy()
+            opt.step()
+            losses.append(float(loss.detach()))
+        arrays[f"{tag}_losses"] = np.array(losses)
+        st = m.state_dict()
+        arrays["state_keys"] = np.array(list(st.keys()))
+        for i, (k, v) in enumerate(st.items()):
+            arrays[f"{tag}_state_{i}"] = (v.detach().reshape(-1)[::stride] if v.dim() else v.detach().reshape(1)).numpy().copy()
+    _save(name, latent=np.array(latent), n=np.array(n), hw=np.array(hw), wseed=np.array(wseed), xseed=np.array(xseed),
+          steps=np.array(steps), stride=np.array(stride), **arrays)
+
+
 def trained_fixture(name, latent=64, epochs=12):
     """Precision gate of SURVEY.md section 8(d): a TRAINED, low-residual model.  Recipe: the reference's own synthetic
     dataset generator (utils/download_data.py:85-184, loaded by file path; numpy + PIL only), its model class, Adam(lr
@@ -267,3 +300,4 @@ if __name__ == "__main__":
     init_fixture("init.npz")
     trained_fixture("img_trained_l64.npz")
     train_fixture("train_vid_l32.npz")
+    train_img_fixture("train_img_l32.npz")

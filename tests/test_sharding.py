@@ -108,3 +108,15 @@ def test_training_layout_matches_module_parameters(vad, latent, hid, layers):
     assert l.vad_vid_train_workspace_bytes(2, 3, 60, 64, latent, hid, layers) == 0          # H not a multiple of 16
     m2 = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid + 32, lstm_num_layers=layers)     # with proj
     assert l.vad_vid_train_nparams(latent, hid + 32, layers) == (sum(p.numel() for p in m2.parameters()) if hid + 32 <= 256 else 0)
+
+
+@pytest.mark.parametrize("latent", [256, 64, 32, 96])
+def test_image_training_layout_matches_module_parameters(vad, latent):
+    """Flat parameter / running-statistics layout of csrc/train_step_img.hip == ConvAutoencoder.named_parameters() /
+    BatchNorm order (sizes only, no GPU)."""
+    l = vad.hip.lib()
+    m = vad.ConvAutoencoder(in_channels=3, latent_dim=latent)
+    assert l.vad_img_train_nparams(latent) == sum(p.numel() for p in m.parameters())
+    assert l.vad_img_train_nstats(latent) == sum(2 * b.num_features for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
+    assert l.vad_img_train_workspace_bytes(4, 64, 48, latent) > 0 and l.vad_img_train_workspace_bytes(4, 60, 48, latent) == 0
+    assert l.vad_img_train_nparams(latent + 8) == 0

@@ -11,5 +11,5 @@ from .video_autoencoder import (ConvLSTM, ConvLSTMCell, VideoAutoencoder,    # n
 from . import losses                                                   # noqa: F401
 from .losses import CombinedLoss, SSIMLoss                           # noqa: F401
 from . import training                                                 # noqa: F401
-from .training import VideoTrainer                                    # noqa: F401
+from .training import ImageTrainer, VideoTrainer                                    # noqa: F401
 from . import scoring                                                 # noqa: F401

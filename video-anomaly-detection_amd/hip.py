@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
-SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "vad_api.hip", "pack.cpp"]
+SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
 HEADERS = ["vad_common.h", "vad_layout.h"]
 
 VAD_OK = 0
@@ -115,6 +115,10 @@ SIGNATURES = {
     "vad_debug_set_train_stop": (_i, [_i]),
     "vad_vid_train_debug_layout": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "vad_vid_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "vad_img_train_nparams": (_sz, [_i]),
+    "vad_img_train_nstats": (_sz, [_i]),
+    "vad_img_train_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "vad_img_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _f, _i, _vp, _vp, _vp]),
     "vad_synth_frames": (_i, [_vp, C.c_ulonglong, _ll, _ll, _i, _i, _i, _i, _vp]),
     "vad_img_packed_floats": (_sz, [_i, _i]),
     "vad_img_pack": (_i, [_vp, _i, _i, _i, _vp]),

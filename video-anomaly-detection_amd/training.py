@@ -43,37 +43,20 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
     return world
 
 
-class VideoTrainer:
-    """Adam-on-MSE training steps for a `VideoAutoencoder` living on a GPU (exact fp32)."""
+class _FlatTrainer:
+    """Shared host logic of the native trainers: the module's parameters / BatchNorm buffers become views of flat device
+    buffers (one optimiser launch, one gradient all-reduce), torch.optim.Adam semantics and state-dict format."""
 
-    def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
-                 eps: float = 1e-8, process_group=None, precision: str = "fp32"):
-        if not isinstance(model, VideoAutoencoder):
-            raise hip.VadError("VideoTrainer drives a VideoAutoencoder")
+    def __init__(self, model: nn.Module, nparams: int, nstats: int, lr, weight_decay, betas, eps, process_group):
         params = list(model.parameters())
-        if not params or not all(p.is_cuda for p in params):
-            raise hip.VadError("VideoTrainer needs the model on a GPU: model.cuda() first (there is no CPU fallback)")
-        if model.in_channels != 3:
-            raise hip.VadError(f"native training supports in_channels == 3 (got {model.in_channels})")
-        if precision not in ("fp32", "split"):
-            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
-        #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
-        #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32
-        self.precision = precision
         self.model, self.group = model, process_group
         self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
         self.device = params[0].device
-        l = hip.lib()
-        cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
-        n = l.vad_vid_train_nparams(*cfg)
-        if n == 0 or n != sum(p.numel() for p in params):
-            raise hip.VadError(f"native training does not support this configuration {cfg} "
-                               f"({sum(p.numel() for p in params)} parameters vs layout {n})")
-        self.cfg = cfg
-        # flat parameter / gradient / moment buffers; the module's parameters become views (named_parameters order ==
-        # the order train_step.hip documents: encoder, convlstm cells, decoder)
-        self.flat = torch.empty(n, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=self.device)
+        if nparams == 0 or nparams != sum(p.numel() for p in params):
+            raise hip.VadError(f"native training does not support this configuration ({sum(p.numel() for p in params)} "
+                               f"parameters vs layout {nparams})")
+        self.flat = torch.empty(nparams, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(nparams, dtype=torch.float32, device=self.device)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         off = 0
@@ -84,10 +67,9 @@ class VideoTrainer:
             p.grad = self.grad[off:off + k].view(p.shape)
             off += k
         self.bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
-        ns = l.vad_vid_train_nstats(*cfg)
-        if ns != sum(2 * m.num_features for m in self.bns):
+        if nstats != sum(2 * m.num_features for m in self.bns):
             raise hip.VadError("unexpected BatchNorm layout")
-        self.running = torch.empty(ns, dtype=torch.float32, device=self.device)
+        self.running = torch.empty(nstats, dtype=torch.float32, device=self.device)
         off = 0
         for m in self.bns:
             c = m.num_features
@@ -100,15 +82,50 @@ class VideoTrainer:
         self._ws: Optional[torch.Tensor] = None
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
+    @staticmethod
+    def _check_model(model, cls, name):
+        if not isinstance(model, cls):
+            raise hip.VadError(f"{name} drives a {cls.__name__}")
+        params = list(model.parameters())
+        if not params or not all(p.is_cuda for p in params):
+            raise hip.VadError(f"{name} needs the model on a GPU: model.cuda() first (there is no CPU fallback)")
+        if model.in_channels != 3:
+            raise hip.VadError(f"native training supports in_channels == 3 (got {model.in_channels})")
+
+    def _ensure_ws(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _after_forward_backward(self, counter: str) -> None:
+        for m in self.bns:
+            m.num_batches_tracked += 1
+        hip.calls[counter] = hip.calls.get(counter, 0) + 1
+
+
+class VideoTrainer(_FlatTrainer):
+    """Adam-on-MSE training steps for a `VideoAutoencoder` living on a GPU (exact fp32, or split-fp16 convolutions)."""
+
+    def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
+                 eps: float = 1e-8, process_group=None, precision: str = "fp32"):
+        self._check_model(model, VideoAutoencoder, "VideoTrainer")
+        if precision not in ("fp32", "split"):
+            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
+        #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
+        #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32
+        self.precision = precision
+        l = hip.lib()
+        self.cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
+        super().__init__(model, l.vad_vid_train_nparams(*self.cfg), l.vad_vid_train_nstats(*self.cfg), lr, weight_decay, betas, eps,
+                         process_group)
+
     # ------------------------------------------------------------------------------------------------------------
     def _workspace(self, b, t, h, w) -> torch.Tensor:
         nbytes = hip.lib().vad_vid_train_workspace_bytes(b, t, h, w, *self.cfg)
         if nbytes == 0:
             raise hip.VadError(f"unsupported training shape B={b} T={t} {h}x{w}: H and W must be multiples of 16")
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+        return self._ensure_ws(nbytes)
 
     def forward_backward(self, clips: torch.Tensor, recon: bool = False):
         """Loss and gradients of one batch (train-mode forward, MSE, full backward) without the optimiser update.
@@ -131,9 +148,7 @@ class VideoTrainer:
             finally:
                 if before != mode:           # the switch is process-wide: leave it as found
                     l.vad_set_precision(before)
-        for m in self.bns:
-            m.num_batches_tracked += 1
-        hip.calls["train_step"] = hip.calls.get("train_step", 0) + 1
+        self._after_forward_backward("train_step")
         return self._loss[0].clone(), out
 
     def optimizer_step(self, grad_scale: float = 1.0) -> None:
@@ -200,3 +215,53 @@ class VideoTrainer:
         world = allreduce_sum_(self.grad, self.group)
         self.optimizer_step(1.0 / world)
         return loss
+
+
+class ImageTrainer(_FlatTrainer):
+    """Native training step for `ConvAutoencoder` (reference train.py:28-52): `loss` is 'mse' (train.py's default),
+    'ssim' or 'combined' (train.py:149-158, `--ssim-weight` = alpha); Adam(lr 1e-3, weight_decay 1e-5) as in train.py:159."""
+
+    _KINDS = {"mse": 0, "ssim": 1, "combined": 2}
+
+    def __init__(self, model, lr: float = 1e-3, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group=None, loss: str = "mse", ssim_weight: float = 0.5, window_size: int = 11):
+        from .autoencoder import ConvAutoencoder
+        self._check_model(model, ConvAutoencoder, "ImageTrainer")
+        if loss not in self._KINDS:
+            raise hip.VadError(f"loss must be one of {sorted(self._KINDS)}, got {loss!r}")
+        self.loss, self.ssim_weight, self.window_size = loss, float(ssim_weight), int(window_size)
+        l = hip.lib()
+        self.latent = model.latent_dim
+        super().__init__(model, l.vad_img_train_nparams(self.latent), l.vad_img_train_nstats(self.latent), lr, weight_decay, betas, eps,
+                         process_group)
+
+    def forward_backward(self, images: torch.Tensor, recon: bool = False):
+        if images.dim() != 4 or images.shape[1] != 3 or not images.is_cuda:
+            raise hip.VadError(f"expected GPU images [B,3,H,W], got {tuple(images.shape)} on {images.device}")
+        x = images.contiguous().float()
+        b, _, h, w = x.shape
+        l = hip.lib()
+        nbytes = l.vad_img_train_workspace_bytes(b, h, w, self.latent)
+        if nbytes == 0:
+            raise hip.VadError(f"unsupported training shape B={b} {h}x{w}: H and W must be multiples of 16")
+        ws = self._ensure_ws(nbytes)
+        out = torch.empty_like(x) if recon else None
+        with torch.cuda.device(self.device):
+            before = l.vad_get_precision()
+            if before != 0:
+                hip.check(l.vad_set_precision(0), "vad_set_precision")
+            try:
+                hip.check(l.vad_img_train_fwd_bwd(x.data_ptr(), b, h, w, self.latent, self.flat.data_ptr(), self.grad.data_ptr(),
+                                                  self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._KINDS[self.loss],
+                                                  self.ssim_weight, self.window_size, self._loss.data_ptr(), hip.ptr(out),
+                                                  hip.current_stream()), "vad_img_train_fwd_bwd")
+            finally:
+                if before != 0:
+                    l.vad_set_precision(before)
+        self._after_forward_backward("train_step_img")
+        return self._loss[0].clone(), out
+
+    optimizer_step = VideoTrainer.optimizer_step
+    state_dict = VideoTrainer.state_dict
+    load_state_dict = VideoTrainer.load_state_dict
+    step = VideoTrainer.step
