@@ -247,7 +247,7 @@ int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent
 
 /* Image autoencoder counterpart (train.py:28-52; not a SURVEY section 8 row): ConvAutoencoder(in_channels=3, latent_dim), x
  * [N,3,H,W]; loss_kind 0 = nn.MSELoss (train.py default), 1 = SSIMLoss(window_size), 2 = CombinedLoss(alpha, window_size)
- * (train.py:149-158).  Same flat-buffer conventions as the video step; exact fp32 only. */
+ * (train.py:149-158).  Same flat-buffer conventions and arithmetic modes as the video step. */
 size_t vad_img_train_nparams(int latent);
 size_t vad_img_train_nstats(int latent);
 size_t vad_img_train_workspace_bytes(int n, int h, int w, int latent);

@@ -141,11 +141,12 @@ def _conditioned_float64(vad, latent, wseed, x, decisions, loss, alpha, window):
 @pytest.mark.parametrize("latent,n,hw,loss,alpha,window,wseed", [
     (32, 2, 32, "mse", 0.5, 11, 81), (64, 3, (48, 80), "combined", 0.3, 11, 82), (256, 1, 64, "ssim", 0.5, 11, 83),
     (32, 2, 16, "mse", 0.5, 11, 84), (32, 2, (32, 64), "combined", 0.5, 7, 85), (96, 2, 96, "mse", 0.5, 11, 86)])
-def test_image_train_step_gradients_match_decision_conditioned_float64(vad, latent, n, hw, loss, alpha, window, wseed):
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_image_train_step_gradients_match_decision_conditioned_float64(vad, latent, n, hw, loss, alpha, window, wseed, precision):
     h, w = hw if isinstance(hw, tuple) else (hw, hw)
     x = torch.from_numpy(vad.synth.frames(wseed + 100, 0, n, 3, h, w))
     m = _make(vad, latent, wseed).cuda()
-    tr = vad.ImageTrainer(m, lr=LR, weight_decay=WD, loss=loss, ssim_weight=alpha, window_size=window)
+    tr = vad.ImageTrainer(m, lr=LR, weight_decay=WD, loss=loss, ssim_weight=alpha, window_size=window, precision=precision)
     loss_gpu, decisions = _record_decisions(vad, tr, x.cuda())
     got = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
     loss64, want, report = _conditioned_float64(vad, latent, wseed, x, decisions, loss, alpha, window)
@@ -153,6 +154,7 @@ def test_image_train_step_gradients_match_decision_conditioned_float64(vad, late
         assert ndiff <= max(3, total // 100000), f"{stage}: {ndiff} of {total} branch decisions differ from float64"
         assert margin < 2e-4, f"{stage}: a differing decision has margin {margin:.3e}"
     assert abs(loss_gpu - loss64) < 5e-6 * abs(loss64), (loss_gpu, loss64)
+    bound = 2e-4 if precision == "fp32" else 1e-3          # split: 22-bit products through 15 BatchNorm backward stages
     zero_true, worst = _bn_fed_biases(m), 0.0
     assert len(zero_true) == 15
     for k, r in want.items():
@@ -162,8 +164,8 @@ def test_image_train_step_gradients_match_decision_conditioned_float64(vad, late
         scale = max(float(np.abs(r).max()), 1e-12)
         err = float(np.abs(got[k] - r).max()) / scale
         worst = max(worst, err)
-        assert err < 2e-4, f"grad {k}: {err:.3e} of max |g| {scale:.3e} (differing decisions {[(s, c_) for s, c_, _, _ in report if c_]})"
-    print(f"[{latent},{n},{hw},{loss}] worst gradient deviation {worst:.2e}; differing decisions {[(s, c_) for s, c_, _, _ in report if c_]}")
+        assert err < bound, f"grad {k}: {err:.3e} of max |g| {scale:.3e} (differing decisions {[(s, c_) for s, c_, _, _ in report if c_]})"
+    print(f"[{precision},{latent},{n},{hw},{loss}] worst gradient deviation {worst:.2e}; differing decisions {[(s, c_) for s, c_, _, _ in report if c_]}")
 
 
 @pytest.mark.parametrize("tag", ["mse", "combined"])

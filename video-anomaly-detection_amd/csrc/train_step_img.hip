@@ -143,7 +143,8 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
                                      float* running, void* workspace, size_t workspace_bytes, int loss_kind, float alpha,
                                      int window_size, float* loss, float* recon_out, void* stream) {
     VAD_REQUIRE(x && params && grads && workspace && loss, "img_train_fwd_bwd: null pointer");
-    VAD_REQUIRE(vad_get_precision() == 0, "img_train_fwd_bwd: exact fp32 only (vad_set_precision(0))");
+    // vad_set_precision(1): the 3x3 / transposed convolutions (forward + data gradients) on split-fp16 operands, as in the
+    // video step; first layer, last layer, weight gradients, BatchNorm, criterion and Adam stay fp32
     VAD_REQUIRE(loss_kind >= 0 && loss_kind <= 2, "img_train_fwd_bwd: loss_kind must be 0 (mse), 1 (ssim) or 2 (combined)");
     ImgPlan p;
     VAD_REQUIRE(make_plan(p, n, h, w, latent), "img_train_fwd_bwd: unsupported configuration (N=%d %dx%d latent=%d): H, W multiples "

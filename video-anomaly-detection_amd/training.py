@@ -224,9 +224,12 @@ class ImageTrainer(_FlatTrainer):
     _KINDS = {"mse": 0, "ssim": 1, "combined": 2}
 
     def __init__(self, model, lr: float = 1e-3, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, loss: str = "mse", ssim_weight: float = 0.5, window_size: int = 11):
+                 process_group=None, loss: str = "mse", ssim_weight: float = 0.5, window_size: int = 11, precision: str = "fp32"):
         from .autoencoder import ConvAutoencoder
         self._check_model(model, ConvAutoencoder, "ImageTrainer")
+        if precision not in ("fp32", "split"):
+            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
+        self.precision = precision
         if loss not in self._KINDS:
             raise hip.VadError(f"loss must be one of {sorted(self._KINDS)}, got {loss!r}")
         self.loss, self.ssim_weight, self.window_size = loss, float(ssim_weight), int(window_size)
@@ -247,16 +250,16 @@ class ImageTrainer(_FlatTrainer):
         ws = self._ensure_ws(nbytes)
         out = torch.empty_like(x) if recon else None
         with torch.cuda.device(self.device):
-            before = l.vad_get_precision()
-            if before != 0:
-                hip.check(l.vad_set_precision(0), "vad_set_precision")
+            mode, before = (1 if self.precision == "split" else 0), l.vad_get_precision()
+            if before != mode:
+                hip.check(l.vad_set_precision(mode), "vad_set_precision")
             try:
                 hip.check(l.vad_img_train_fwd_bwd(x.data_ptr(), b, h, w, self.latent, self.flat.data_ptr(), self.grad.data_ptr(),
                                                   self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._KINDS[self.loss],
                                                   self.ssim_weight, self.window_size, self._loss.data_ptr(), hip.ptr(out),
                                                   hip.current_stream()), "vad_img_train_fwd_bwd")
             finally:
-                if before != 0:
+                if before != mode:
                     l.vad_set_precision(before)
         self._after_forward_backward("train_step_img")
         return self._loss[0].clone(), out
