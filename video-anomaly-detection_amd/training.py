@@ -104,53 +104,6 @@ class _FlatTrainer:
         hip.calls[counter] = hip.calls.get(counter, 0) + 1
 
 
-class VideoTrainer(_FlatTrainer):
-    """Adam-on-MSE training steps for a `VideoAutoencoder` living on a GPU (exact fp32, or split-fp16 convolutions)."""
-
-    def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
-                 eps: float = 1e-8, process_group=None, precision: str = "fp32"):
-        self._check_model(model, VideoAutoencoder, "VideoTrainer")
-        if precision not in ("fp32", "split"):
-            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
-        #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
-        #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32
-        self.precision = precision
-        l = hip.lib()
-        self.cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
-        super().__init__(model, l.vad_vid_train_nparams(*self.cfg), l.vad_vid_train_nstats(*self.cfg), lr, weight_decay, betas, eps,
-                         process_group)
-
-    # ------------------------------------------------------------------------------------------------------------
-    def _workspace(self, b, t, h, w) -> torch.Tensor:
-        nbytes = hip.lib().vad_vid_train_workspace_bytes(b, t, h, w, *self.cfg)
-        if nbytes == 0:
-            raise hip.VadError(f"unsupported training shape B={b} T={t} {h}x{w}: H and W must be multiples of 16")
-        return self._ensure_ws(nbytes)
-
-    def forward_backward(self, clips: torch.Tensor, recon: bool = False):
-        """Loss and gradients of one batch (train-mode forward, MSE, full backward) without the optimiser update.
-        Returns (loss 0-dim device tensor, reconstruction or None); gradients are in `p.grad` of every parameter."""
-        if clips.dim() != 5 or clips.shape[2] != 3 or not clips.is_cuda:
-            raise hip.VadError(f"expected GPU clips [B,T,3,H,W], got {tuple(clips.shape)} on {clips.device}")
-        x = clips.contiguous().float()
-        b, t, _, h, w = x.shape
-        ws = self._workspace(b, t, h, w)
-        out = torch.empty_like(x) if recon else None
-        l = hip.lib()
-        with torch.cuda.device(self.device):
-            mode, before = (1 if self.precision == "split" else 0), l.vad_get_precision()
-            if before != mode:
-                hip.check(l.vad_set_precision(mode), "vad_set_precision")
-            try:
-                hip.check(l.vad_vid_train_fwd_bwd(x.data_ptr(), b, t, h, w, *self.cfg, self.flat.data_ptr(), self.grad.data_ptr(),
-                                                  self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._loss.data_ptr(),
-                                                  hip.ptr(out), hip.current_stream()), "vad_vid_train_fwd_bwd")
-            finally:
-                if before != mode:           # the switch is process-wide: leave it as found
-                    l.vad_set_precision(before)
-        self._after_forward_backward("train_step")
-        return self._loss[0].clone(), out
-
     def optimizer_step(self, grad_scale: float = 1.0) -> None:
         """torch.optim.Adam semantics (L2 weight decay added to the gradient) over the flat buffers."""
         self.steps += 1
@@ -208,13 +161,61 @@ class VideoTrainer(_FlatTrainer):
                 self.exp_avg_sq[off:off + k].copy_(e["exp_avg_sq"].reshape(-1))
             off += k
 
-    def step(self, clips: torch.Tensor) -> torch.Tensor:
+    def step(self, batch: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's batch; with a process group the gradients are summed over ranks with ONE
         all-reduce of the flat buffer and averaged inside the optimiser kernel (DistributedDataParallel semantics)."""
-        loss, _ = self.forward_backward(clips)
+        loss, _ = self.forward_backward(batch)
         world = allreduce_sum_(self.grad, self.group)
         self.optimizer_step(1.0 / world)
         return loss
+
+
+class VideoTrainer(_FlatTrainer):
+    """Adam-on-MSE training steps for a `VideoAutoencoder` living on a GPU (exact fp32, or split-fp16 convolutions)."""
+
+    def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
+                 eps: float = 1e-8, process_group=None, precision: str = "fp32"):
+        self._check_model(model, VideoAutoencoder, "VideoTrainer")
+        if precision not in ("fp32", "split"):
+            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
+        #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
+        #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32
+        self.precision = precision
+        l = hip.lib()
+        self.cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
+        super().__init__(model, l.vad_vid_train_nparams(*self.cfg), l.vad_vid_train_nstats(*self.cfg), lr, weight_decay, betas, eps,
+                         process_group)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _workspace(self, b, t, h, w) -> torch.Tensor:
+        nbytes = hip.lib().vad_vid_train_workspace_bytes(b, t, h, w, *self.cfg)
+        if nbytes == 0:
+            raise hip.VadError(f"unsupported training shape B={b} T={t} {h}x{w}: H and W must be multiples of 16")
+        return self._ensure_ws(nbytes)
+
+    def forward_backward(self, clips: torch.Tensor, recon: bool = False):
+        """Loss and gradients of one batch (train-mode forward, MSE, full backward) without the optimiser update.
+        Returns (loss 0-dim device tensor, reconstruction or None); gradients are in `p.grad` of every parameter."""
+        if clips.dim() != 5 or clips.shape[2] != 3 or not clips.is_cuda:
+            raise hip.VadError(f"expected GPU clips [B,T,3,H,W], got {tuple(clips.shape)} on {clips.device}")
+        x = clips.contiguous().float()
+        b, t, _, h, w = x.shape
+        ws = self._workspace(b, t, h, w)
+        out = torch.empty_like(x) if recon else None
+        l = hip.lib()
+        with torch.cuda.device(self.device):
+            mode, before = (1 if self.precision == "split" else 0), l.vad_get_precision()
+            if before != mode:
+                hip.check(l.vad_set_precision(mode), "vad_set_precision")
+            try:
+                hip.check(l.vad_vid_train_fwd_bwd(x.data_ptr(), b, t, h, w, *self.cfg, self.flat.data_ptr(), self.grad.data_ptr(),
+                                                  self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._loss.data_ptr(),
+                                                  hip.ptr(out), hip.current_stream()), "vad_vid_train_fwd_bwd")
+            finally:
+                if before != mode:           # the switch is process-wide: leave it as found
+                    l.vad_set_precision(before)
+        self._after_forward_backward("train_step")
+        return self._loss[0].clone(), out
 
 
 class ImageTrainer(_FlatTrainer):
@@ -264,7 +265,3 @@ class ImageTrainer(_FlatTrainer):
         self._after_forward_backward("train_step_img")
         return self._loss[0].clone(), out
 
-    optimizer_step = VideoTrainer.optimizer_step
-    state_dict = VideoTrainer.state_dict
-    load_state_dict = VideoTrainer.load_state_dict
-    step = VideoTrainer.step
