@@ -1,6 +1,7 @@
 """A/B of the first-layer kernel (variant 0 = one tile per work-group, 1 = persistent) in one process: time and bit-equality."""
 import importlib, sys, time, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent)); sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
 import numpy as np
 vad = importlib.import_module("video-anomaly-detection_amd"); l = vad.hip.lib()
 import hip_helpers as H

@@ -2,7 +2,9 @@
 workspace vs float64), and the number of sign disagreements of v per decoder stage / max-pool+LeakyReLU disagreements are
 left for later.  Also reports how accurate the GPU's v is overall."""
 import sys, importlib, ctypes as C, numpy as np, torch
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+from pathlib import Path
+_R = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(_R / "tests")); sys.path.insert(0, str(_R))
 from conftest import load_synthetic
 vad = importlib.import_module("video-anomaly-detection_amd"); l = vad.hip.lib()
 latent, layers, b, t, wseed = 32, 3, 1, 4, 43

@@ -1,7 +1,9 @@
 """Per-tensor deviation of first-step gradients from float64, in BACKWARD order, to locate the stage where the odd-size
 error enters (open item in tests/test_hip_train_step.py)."""
 import sys, importlib, numpy as np, torch
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+from pathlib import Path
+_R = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(_R / "tests")); sys.path.insert(0, str(_R))
 import test_hip_train_step as T
 from conftest import load_synthetic
 vad = importlib.import_module("video-anomaly-detection_amd")

@@ -2,7 +2,8 @@
 memory, as the reference's loop hands them over (`images.to(device)`, evaluate.py:58), fp32 NCHW or raw uint8 NHWC."""
 import importlib, json, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 vad = importlib.import_module("video-anomaly-detection_amd")
 m = vad.ConvAutoencoder().cuda().eval()
 shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}

@@ -1,7 +1,8 @@
 """SSIM / combined criterion, forward + backward: fused HIP passes (losses.CombinedLoss on GPU tensors) vs the stock torch
 composition on the same GPU (the reference's utils/losses.py arithmetic run by PyTorch-ROCm)."""
 import importlib, json, sys, time, torch
-sys.path.insert(0, ".")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 vad = importlib.import_module("video-anomaly-detection_amd")
 crit = vad.CombinedLoss(alpha=0.5)
 res = {}
