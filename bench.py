@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["image", "video", "dense"], default="image")
+    ap.add_argument("--stream-frames", type=int, default=0,
+                    help="configs[3] on the side: also time scoring.score_stream over this many frames (image workload, reported as `stream`)")
     ap.add_argument("--stride", type=int, default=1, help="dense workload: window stride")
     ap.add_argument("--precision", choices=["fp32", "split"], default="fp32",
                     help="fp32 = exact fp32 MFMA (headline); split = opt-in 3 x fp16 MFMA with fp32 accumulate")
@@ -301,6 +303,20 @@ def main():
     # exact fp32, 32 clips x 10 frames at the bench resolution.  Never part of `value` / `roofline`.
     if rank == 0 and world == 1 and not args.no_train and args.workload == "image" and args.precision == "fp32":
         out["training_step"] = training_step(vad, dev, hw)
+    # configs[3] (opt-in: --stream-frames 100000): the frame stream generated on the device in chunks of 512, block-partitioned
+    # over the ranks, ONE all_gather at the end; generation is inside the timed region
+    if args.stream_frames > 0 and args.workload == "image" and args.precision == "fp32":
+        fence()
+        t1 = time.perf_counter()
+        sv = vad.scoring.score_stream(model, seed + 2, args.stream_frames, chunk=512, h=hw, w=hw, rank=rank, world=world, device=dev)
+        fence()
+        el3 = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([el3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el3 = float(tt.item())
+        out["stream"] = {"frames": args.stream_frames, "seconds": round(el3, 4), "value": round(args.stream_frames / el3, 1), "unit": "frames/s",
+                         "includes": "on-device frame generation, scoring, one all_gather", "checksum": float(sv.double().sum())}
     if args.workload == "dense":
         out["unique_frames_per_sec"] = round(((per_gpu - 1) * args.stride + t) * world * args.steps / elapsed, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "dense":

@@ -401,3 +401,23 @@ def test_c_abi_reports_errors_before_launching(vad):
                                    loss.data_ptr(), None, s) == ERR_ARG and b"multiples of 16" in l.vad_last_error()
     assert l.vad_adam_step(flat.data_ptr(), grad.data_ptr(), flat.data_ptr(), flat.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1.0, s) == ERR_ARG   # step >= 1
     assert l.vad_set_precision(7) == ERR_ARG and l.vad_get_precision() == 0
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]: frame stream
+def test_frame_stream_in_chunks_matches_oracle_on_a_strided_subset(vad):
+    """BASELINE configs[3] at reduced scale (the full case is 100,000 frames over 8 ranks): a 2,100-frame stream at 256x256
+    generated on the device in chunks of 512 and never materialised; parity on a strided subset regenerated on the CPU
+    with the same counter-based generator, and bit-equality with scoring those frames directly."""
+    m, st = _img_model(vad, 256, 9)
+    seed, n = 0xC0FFEE + 3, 2100
+    scores = vad.scoring.score_stream(m, seed, n, chunk=512)
+    assert scores.shape == (n,) and torch.isfinite(scores).all()
+    idx = list(range(5, n, 419))                                        # 5, 424, ..., crosses every chunk boundary region
+    x = np.concatenate([vad.synth.frames(seed, i, 1, 3, 256, 256) for i in idx])
+    ref = torch_oracle.img_scores({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, torch.from_numpy(x))
+    assert rel_err(scores[idx].cpu().numpy(), ref["scores"].numpy()) < SCORE_RTOL
+    with torch.no_grad():
+        direct = m.get_reconstruction_error(torch.from_numpy(x).cuda())
+    assert torch.equal(direct, scores[idx])
+    # chunking of the stream is invisible in the result
+    assert torch.equal(vad.scoring.score_stream(m, seed, n, chunk=300), scores)

@@ -126,3 +126,24 @@ def sharded_scores(score_block: Callable[[int, int], torch.Tensor], n_items: int
         gathered = local
     out = gathered[:n_items]
     return out[:, 0] if width == 1 else out
+
+
+def score_stream(model, seed: int, n_frames: int, chunk: int = 512, h: int = 256, w: int = 256, rank: int = 0,
+                 world: int = 1, device="cuda", anomalies: bool = False, group=None) -> torch.Tensor:
+    """BASELINE configs[3]: score a long synthetic frame stream without ever materialising it.  The stream is
+    block-partitioned over ranks; each rank regenerates its frames on the device `chunk` at a time (the counter-based
+    generator makes any sub-range reproducible, on any rank and on the CPU), scores them with
+    `model.get_reconstruction_error`, and ONE all_gather returns float32[n_frames] in stream order on every rank."""
+    dev = torch.device(device)
+    buf = torch.empty(min(chunk, max(n_frames, 1)), 3, h, w, dtype=torch.float32, device=dev)
+
+    def score_block(first: int, count: int) -> torch.Tensor:
+        out = torch.empty(count, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for s in range(0, count, buf.shape[0]):
+                k = min(buf.shape[0], count - s)
+                synth_frames_device(seed, first + s, k, h, w, 3, dev, anomalies, out=buf[:k])
+                out[s:s + k] = model.get_reconstruction_error(buf[:k])
+        return out
+
+    return sharded_scores(score_block, n_frames, 1, rank, world, dev, group)
