@@ -906,7 +906,9 @@ extern "C" int vad_lstm_gates_bwd(const float* gates, const float* c_prev, const
     return VAD_OK;
 }
 
-// split-K factor: enough waves to fill the chip (~4096), never more splits than image rows
+// split-K factor: enough waves to fill the chip (~4096), never more splits than image rows.  Measured on both training
+// steps (32 clips / 128 images): a 2048-wave target is within noise of 4096 (35.8 vs 35.6-36.0 ms, 38.5 vs 39.0 ms), 1024
+// is 13 % slower; the partial buffers are small either way.
 static int wgrad_splits(long long tiles, int total_rows) {
     long long s = (4096 + tiles - 1) / tiles;
     if (s > total_rows) s = total_rows;
