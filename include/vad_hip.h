@@ -255,7 +255,8 @@ int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int latent, const
                           float* running, void* workspace, size_t workspace_bytes, int loss_kind, float alpha,
                           int window_size, float* loss, float* recon, void* stream);
 
-/* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1]. */
+/* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1].  anomalies: 0 = none,
+ * 1 = labelled frames carry a saturated 32 x 32 patch, k >= 2 = a k x k patch. */
 int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_frame, long long n,
                      int c, int h, int w, int anomalies, void* stream);
 

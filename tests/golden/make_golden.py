@@ -6,7 +6,8 @@ deterministic synthetic state dict (same generator, so weights are not stored) a
 outputs.  The reference modules are loaded by file path under private names, because this repository
 has its own drop-in `models` package.
 
-    python tests/golden/make_golden.py            # rewrites every fixture
+    python tests/golden/make_golden.py                     # rewrites every fixture
+    python tests/golden/make_golden.py clip_loop_64.npz    # rewrites the named ones
 """
 from __future__ import annotations
 
@@ -130,9 +131,11 @@ def convlstm_fixture(name):
           c_last=cl.numpy())
 
 
-def auroc_fixture(name):
+def auroc_fixture(name, patch=10):
     """configs[0]: 64 synthetic 256x256 frames in batches of 16 through the reference model, AUROC by the
-    same sklearn call evaluate.compute_auroc makes (reference evaluate.py:56-74)."""
+    same sklearn call evaluate.compute_auroc makes (reference evaluate.py:56-74).  Labelled frames carry a saturated
+    `patch` x `patch` square: at 10 pixels it moves a score by about one standard deviation of the normal frames'
+    scores, so the AUROC lands well inside (0.5, 1) and a wrong ranking changes it (a 32-pixel patch gave 1.0)."""
     from sklearn.metrics import roc_auc_score
     seed = 0xC0FFEE
     torch.manual_seed(0)
@@ -141,11 +144,38 @@ def auroc_fixture(name):
     scores = []
     with torch.no_grad():
         for s in range(0, 64, 16):   # batch_size=16: reference evaluate.py:240
-            x = torch.from_numpy(synth.frames(seed, s, 16, 3, 256, 256, anomalies=True))
+            x = torch.from_numpy(synth.frames(seed, s, 16, 3, 256, 256, anomalies=patch))
             scores.extend(model.get_reconstruction_error(x, per_pixel=False).numpy())
     scores = np.array(scores, dtype=np.float32)
-    _save(name, seed=np.array(seed), wseed=np.array(7), labels=labels, scores=scores,
-          auroc=np.array(roc_auc_score(labels, scores)))
+    auroc = roc_auc_score(labels, scores)
+    print(f"  configs[0] AUROC {auroc:.4f} (patch {patch})")
+    assert 0.6 < auroc < 0.95, "the AUROC fixture must not be degenerate"
+    _save(name, seed=np.array(seed), wseed=np.array(7), patch=np.array(patch), labels=labels, scores=scores,
+          auroc=np.array(auroc))
+
+
+def clip_loop_fixture(name, n=10, t=6, hw=64, batch=4, wseed=24, xseed=204):
+    """Row a12: the clip loop of the reference's evaluate_video.evaluate (evaluate_video.py:137-154) over `n` seeded
+    clips in batches of `batch` (its --batch_size default, evaluate_video.py:416; the last batch is ragged): per batch
+    `get_reconstruction_error(sequences, per_frame=False)` extended into the clip scores and, because the batch carries
+    frame labels, a second forward `per_frame=True` extended into the frame scores.  Default model dimensions."""
+    torch.manual_seed(0)
+    model = _load_synth(ref_vae.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128,
+                                                 lstm_num_layers=2), wseed)
+    labels = synth.frame_label(xseed, np.arange(n))
+    all_scores, all_frame_scores = [], []
+    with torch.no_grad():
+        for s in range(0, n, batch):
+            k = min(batch, n - s)
+            sequences = torch.from_numpy(synth.clips(xseed, s, k, t, 3, hw, hw))
+            seq_errors = model.get_reconstruction_error(sequences, per_frame=False)
+            all_scores.extend(seq_errors.cpu().numpy())
+            frame_errors = model.get_reconstruction_error(sequences, per_frame=True)
+            for frame_err in frame_errors.cpu().numpy():
+                all_frame_scores.extend(frame_err)
+    _save(name, n=np.array(n), t=np.array(t), hw=np.array(hw), batch=np.array(batch), wseed=np.array(wseed),
+          xseed=np.array(xseed), labels=labels, seq_scores=np.array(all_scores, dtype=np.float32),
+          frame_scores=np.array(all_frame_scores, dtype=np.float32).reshape(n, t))
 
 
 def losses_fixture(name):
@@ -286,18 +316,24 @@ def trained_fixture(name, latent=64, epochs=12):
           auroc=np.array(roc_auc_score(labels, scores)), errmap0_sub=emap0[:, :, ::8, ::8], **st)
 
 
+FIXTURES = {
+    "img_l32_32.npz": lambda n: image_fixture(n, latent=32, wseed=11, xseed=101, n=3, hw=32, intermediates=True),
+    "img_l256_64.npz": lambda n: image_fixture(n, latent=256, wseed=12, xseed=102, n=2, hw=64),
+    "img_l256_256.npz": lambda n: image_fixture(n, latent=256, wseed=13, xseed=103, n=1, hw=256, subsample=8),
+    "vid_default_64.npz": lambda n: video_fixture(n, latent=128, hid=128, layers=2, wseed=21, xseed=201, b=2, t=3, hw=64),
+    "vid_proj_32.npz": lambda n: video_fixture(n, latent=32, hid=64, layers=1, wseed=22, xseed=202, b=1, t=4, hw=32),
+    "vid_l3_32.npz": lambda n: video_fixture(n, latent=64, hid=64, layers=3, wseed=23, xseed=203, b=2, t=2, hw=32),
+    "convlstm_unit.npz": convlstm_fixture,
+    "auroc_cfg0.npz": auroc_fixture,
+    "clip_loop_64.npz": clip_loop_fixture,
+    "losses.npz": losses_fixture,
+    "init.npz": init_fixture,
+    "img_trained_l64.npz": trained_fixture,
+    "train_vid_l32.npz": train_fixture,
+    "train_img_l32.npz": train_img_fixture,
+}
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    image_fixture("img_l32_32.npz", latent=32, wseed=11, xseed=101, n=3, hw=32, intermediates=True)
-    image_fixture("img_l256_64.npz", latent=256, wseed=12, xseed=102, n=2, hw=64)
-    image_fixture("img_l256_256.npz", latent=256, wseed=13, xseed=103, n=1, hw=256, subsample=8)
-    video_fixture("vid_default_64.npz", latent=128, hid=128, layers=2, wseed=21, xseed=201, b=2, t=3, hw=64)
-    video_fixture("vid_proj_32.npz", latent=32, hid=64, layers=1, wseed=22, xseed=202, b=1, t=4, hw=32)
-    video_fixture("vid_l3_32.npz", latent=64, hid=64, layers=3, wseed=23, xseed=203, b=2, t=2, hw=32)
-    convlstm_fixture("convlstm_unit.npz")
-    auroc_fixture("auroc_cfg0.npz")
-    losses_fixture("losses.npz")
-    init_fixture("init.npz")
-    trained_fixture("img_trained_l64.npz")
-    train_fixture("train_vid_l32.npz")
-    train_img_fixture("train_img_l32.npz")
+    for fixture in (sys.argv[1:] or list(FIXTURES)):     # optional arguments: the fixtures to rewrite (default: all)
+        FIXTURES[fixture](fixture)

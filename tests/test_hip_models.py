@@ -67,7 +67,9 @@ def test_image_config0_scores_and_auroc(vad, golden):
     seed = int(g["seed"])
     m, _ = _img_model(vad, 256, int(g["wseed"]))
     labels = vad.synth.frame_label(seed, np.arange(64))
-    batches = [{"image": vad.scoring.synth_frames_device(seed, s, 16, anomalies=True), "label": labels[s:s + 16],
+    patch = int(g["patch"])                                      # small patch: AUROC 0.82, not the trivially separable 1.0
+    assert 0.6 < float(g["auroc"]) < 0.95
+    batches = [{"image": vad.scoring.synth_frames_device(seed, s, 16, anomalies=patch), "label": labels[s:s + 16],
                 "defect_type": ["defect" if l else "good" for l in labels[s:s + 16]]} for s in range(0, 64, 16)]
     auroc, lab, scores, per_defect = vad.scoring.compute_auroc(m, batches, "cuda")
     assert rel_err(scores, g["scores"]) < SCORE_RTOL
@@ -144,6 +146,53 @@ def test_video_matches_reference_golden(vad, golden, name):
     assert max_abs(emap.cpu().numpy(), g["errmap"]) < ACT_ATOL
     assert torch.equal(both, emap)                                  # per_pixel wins (reference :373)
     assert torch.equal(allo["seq"], seq) and torch.equal(allo["frame"], frame) and torch.equal(allo["recon"], recon)
+
+
+def test_clip_loop_matches_reference_golden(vad, golden):
+    """Row a12: `scoring.score_clips` (the build's counterpart of the clip loop of evaluate_video.evaluate,
+    reference evaluate_video.py:137-154) against the clip / frame scores the REFERENCE's loop produced for the same
+    seeded clips in batches of 4 with a ragged last batch (tests/golden/clip_loop_64.npz, make_golden.clip_loop_fixture)."""
+    g = golden("clip_loop_64.npz")
+    n, t, hw, batch = int(g["n"]), int(g["t"]), int(g["hw"]), int(g["batch"])
+    m, _ = _vid_model(vad, 128, 128, 2, int(g["wseed"]))
+    labels = vad.synth.frame_label(int(g["xseed"]), np.arange(n))
+
+    def loader():
+        for s in range(0, n, batch):
+            k = min(batch, n - s)
+            yield {"frames": torch.from_numpy(vad.synth.clips(int(g["xseed"]), s, k, t, 3, hw, hw)), "label": labels[s:s + k]}
+
+    before = vad.hip.calls["vid_score"]
+    seq, lab = vad.scoring.score_clips(m, loader(), "cuda")
+    seq2, lab2, frm = vad.scoring.score_clips(m, loader(), "cuda", per_frame=True)
+    assert vad.hip.calls["vid_score"] == before + 2 * 3          # one native pass per batch, also with per_frame
+    assert seq.shape == (n,) and frm.shape == (n, t) and seq.dtype == np.float32 and frm.dtype == np.float32
+    assert rel_err(seq, g["seq_scores"]) < SCORE_RTOL and rel_err(frm, g["frame_scores"]) < SCORE_RTOL
+    assert np.array_equal(seq, seq2) and np.array_equal(lab, g["labels"]) and np.array_equal(lab2, g["labels"])
+    assert vad.scoring.roc_auc(lab, seq) == vad.scoring.roc_auc(g["labels"], g["seq_scores"])
+
+
+def test_video_config2_full_size_vs_oracle(vad):
+    """BASELINE configs[2] at its stated size - 64 clips x 10 frames x 256x256, default model, one launch group of 64
+    clips (the grids and tile variants the benchmark runs): first / middle / last clip against the CPU oracle at 1e-5,
+    and bit-equality with the same clips scored alone."""
+    m, st = _vid_model(vad, 128, 128, 2, 8)
+    seed = 0xC0FFEE + 2
+    x = vad.scoring.synth_frames_device(seed, 0, 640).view(64, 10, 3, 256, 256)
+    with torch.no_grad():
+        out = m.score_seq_and_frames(x)
+        idx = [0, 31, 63]
+        alone = [m.score_seq_and_frames(x[i:i + 1]) for i in idx]
+    assert out["seq"].shape == (64,) and out["frame"].shape == (64, 10)
+    for i, a in zip(idx, alone):
+        assert torch.equal(a["seq"], out["seq"][i:i + 1]) and torch.equal(a["frame"], out["frame"][i:i + 1])
+    tst = {k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}
+    xs = torch.from_numpy(np.stack([vad.synth.clips(seed, i, 1, 10, 3, 256, 256)[0] for i in idx]))
+    assert torch.equal(xs, x[idx].cpu())                           # device generator == numpy generator
+    torch.set_num_threads(16)
+    ref = torch_oracle.vid_scores(tst, xs, 128, 2)
+    assert rel_err(out["seq"][idx].cpu().numpy(), ref["seq"].numpy()) < SCORE_RTOL
+    assert rel_err(out["frame"][idx].cpu().numpy(), ref["frame"].numpy()) < SCORE_RTOL
 
 
 def test_video_causal_and_clip_independent(vad):

@@ -116,10 +116,30 @@ def test_auroc_config0(vad, golden):
     torch.set_num_threads(8)
     with torch.no_grad():
         for s in range(0, 64, 16):
-            x = torch.from_numpy(vad.synth.frames(seed, s, 16, 3, 256, 256, anomalies=True))
+            x = torch.from_numpy(vad.synth.frames(seed, s, 16, 3, 256, 256, anomalies=int(g["patch"])))
             scores.extend(torch_oracle.img_scores(st, x)["scores"].numpy())
     assert rel_err(scores, g["scores"]) < SCORE_RTOL
+    assert 0.6 < float(g["auroc"]) < 0.95                      # a live check: a wrong ranking moves it
     assert abs(vad.scoring.roc_auc(labels, scores) - float(g["auroc"])) < 1e-12
+
+
+def test_clip_loop_fixture_oracle(vad, golden):
+    """Row a12 on the CPU: the oracle reproduces the clip / frame scores the reference's evaluate_video clip loop
+    (evaluate_video.py:137-154, batches of 4, ragged last batch) produced for the seeded clips."""
+    g = golden("clip_loop_64.npz")
+    n, t, hw, batch = int(g["n"]), int(g["t"]), int(g["hw"]), int(g["batch"])
+    import importlib
+    va = importlib.import_module("video-anomaly-detection_amd.video_autoencoder")
+    shapes = {k: tuple(v.shape) for k, v in va.VideoAutoencoder().state_dict().items()}
+    st = _tstate(vad.synth.synthetic_state(shapes, int(g["wseed"])))
+    seq, frm = [], []
+    with torch.no_grad():
+        for s in range(0, n, batch):
+            o = torch_oracle.vid_scores(st, torch.from_numpy(vad.synth.clips(int(g["xseed"]), s, min(batch, n - s), t, 3, hw, hw)), 128, 2)
+            seq.extend(o["seq"].numpy())
+            frm.extend(o["frame"].numpy())
+    assert rel_err(seq, g["seq_scores"]) < SCORE_RTOL and rel_err(np.array(frm), g["frame_scores"]) < SCORE_RTOL
+    assert np.array_equal(vad.synth.frame_label(int(g["xseed"]), np.arange(n)), g["labels"])
 
 
 def test_trained_model_gate_oracle(vad, golden):

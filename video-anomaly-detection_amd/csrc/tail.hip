@@ -385,11 +385,12 @@ __global__ __launch_bounds__(256) void synth_frames_kernel(float* out, unsigned 
             const unsigned long long lab = mix64((unsigned long long)f + (seed ^ 0x5DEECE66Dull) * golden) >> 63;
             if (lab) {
                 const unsigned long long z = mix64((unsigned long long)f + (seed ^ 0xB5297A4Dull) * golden);
-                const int ph = h - 32 + 1 > 1 ? h - 32 + 1 : 1, pw = w - 32 + 1 > 1 ? w - 32 + 1 : 1;
+                const int side = anomalies == 1 ? 32 : anomalies;     // synth.patch_side
+                const int ph = h - side + 1 > 1 ? h - side + 1 : 1, pw = w - side + 1 > 1 ? w - side + 1 : 1;
                 const int py = (int)((z & 0xFFFF) % (unsigned)ph), px = (int)(((z >> 16) & 0xFFFF) % (unsigned)pw);
                 const long long rem = i % per;
                 const int yy = (int)((rem / w) % h), xx = (int)(rem % w);
-                if (yy >= py && yy < py + 32 && xx >= px && xx < px + 32) u8 = 255;
+                if (yy >= py && yy < py + side && xx >= px && xx < px + side) u8 = 255;
             }
         }
         float f32 = (float)u8;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void synth_frames_kernel(float* out, unsigned 
 
 extern "C" int vad_synth_frames(float* out, unsigned long long seed, long long first_frame, long long n,
                                 int c, int h, int w, int anomalies, void* stream) {
-    VAD_REQUIRE(out && n > 0 && c > 0 && h > 0 && w > 0 && first_frame >= 0, "synth_frames: bad arguments");
+    VAD_REQUIRE(out && n > 0 && c > 0 && h > 0 && w > 0 && first_frame >= 0 && anomalies >= 0, "synth_frames: bad arguments");
     const long long total = n * c * h * w;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;

@@ -64,15 +64,16 @@ def compute_auroc(model, test_loader: Iterable[dict], device):
 
 
 def score_clips(model, loader: Iterable[dict], device, per_frame: bool = False):
-    """Clip loop of the reference's evaluate_video.evaluate (evaluate_video.py:138-154): returns
+    """Clip loop of the reference's evaluate_video.evaluate (evaluate_video.py:137-154): returns
     (clip scores float32[N], labels) and, when per_frame, also float32[N,T] frame scores computed in
-    the SAME pass (the reference would run a second forward)."""
+    the SAME pass (the reference runs a second forward, evaluate_video.py:147-149).  Only the two score
+    vectors are produced: no reconstruction or error map is written."""
     seq, frm, labels = [], [], []
     with torch.no_grad():
         for batch in loader:
             frames = batch["frames"].to(device)
-            if per_frame and hasattr(model, "score_all"):
-                out = model.score_all(frames)
+            if per_frame:
+                out = model.score_seq_and_frames(frames)
                 seq.extend(out["seq"].cpu().numpy())
                 frm.extend(out["frame"].cpu().numpy())
             else:

@@ -19,7 +19,14 @@ _GOLDEN = np.uint64(0x9E3779B97F4A7C15)
 _M1 = np.uint64(0xBF58476D1CE4E5B9)
 _M2 = np.uint64(0x94D049BB133111EB)
 
-PATCH = 32  # side of the additive "defect" patch used for the AUROC check
+PATCH = 32  # default side of the saturated "defect" patch used for the AUROC check
+
+
+def patch_side(anomalies) -> int:
+    """`anomalies` argument -> patch side: False/0 = no patches, True/1 = PATCH, k >= 2 = k pixels (a small patch moves
+    a frame's score by about one standard deviation of the normal scores, so the AUROC is not trivially 1)."""
+    k = int(anomalies)
+    return PATCH if k == 1 else k
 
 
 def mix64(z: np.ndarray) -> np.ndarray:
@@ -54,29 +61,30 @@ def frame_label(seed: int, frame_idx: np.ndarray) -> np.ndarray:
     return (mix64(z) >> np.uint64(63)).astype(np.int64)
 
 
-def _patch_origin(seed: int, frame_idx: int, h: int, w: int):
+def _patch_origin(seed: int, frame_idx: int, h: int, w: int, side: int = PATCH):
     with np.errstate(over="ignore"):
         z = mix64(np.uint64(frame_idx) + np.uint64((seed ^ 0xB5297A4D) & 0xFFFFFFFFFFFFFFFF) * _GOLDEN)
     z = int(z)
-    py = (z & 0xFFFF) % max(h - PATCH + 1, 1)
-    px = ((z >> 16) & 0xFFFF) % max(w - PATCH + 1, 1)
+    py = (z & 0xFFFF) % max(h - side + 1, 1)
+    px = ((z >> 16) & 0xFFFF) % max(w - side + 1, 1)
     return py, px
 
 
-def frames_u8(seed: int, first_frame: int, n: int, c: int, h: int, w: int, anomalies: bool = False) -> np.ndarray:
-    """uint8 [n, c, h, w]; element (f, ch, y, x) = hash(seed, ((f*c+ch)*h+y)*w+x) >> 56."""
+def frames_u8(seed: int, first_frame: int, n: int, c: int, h: int, w: int, anomalies=False) -> np.ndarray:
+    """uint8 [n, c, h, w]; element (f, ch, y, x) = hash(seed, ((f*c+ch)*h+y)*w+x) >> 56.  `anomalies`: see patch_side."""
     per = c * h * w
     out = (_stream(seed, first_frame * per, n * per) >> np.uint64(56)).astype(np.uint8).reshape(n, c, h, w)
-    if anomalies:
+    side = patch_side(anomalies)
+    if side:
         lab = frame_label(seed, np.arange(first_frame, first_frame + n))
         for i in range(n):
             if lab[i]:
-                py, px = _patch_origin(seed, first_frame + i, h, w)
-                out[i, :, py:py + PATCH, px:px + PATCH] = 255
+                py, px = _patch_origin(seed, first_frame + i, h, w, side)
+                out[i, :, py:py + side, px:px + side] = 255
     return out
 
 
-def frames(seed: int, first_frame: int, n: int, c: int = 3, h: int = 256, w: int = 256, anomalies: bool = False) -> np.ndarray:
+def frames(seed: int, first_frame: int, n: int, c: int = 3, h: int = 256, w: int = 256, anomalies=False) -> np.ndarray:
     """fp32 NCHW frames in [-1, 1]."""
     return u8_to_unit(frames_u8(seed, first_frame, n, c, h, w, anomalies))
 

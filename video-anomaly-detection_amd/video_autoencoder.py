@@ -290,6 +290,13 @@ class VideoAutoencoder(nn.Module):
         hip.calls["vid_score"] += 1
         return out
 
+    def score_seq_and_frames(self, x):
+        """One pass returning {'seq': [B], 'frame': [B,T]} and nothing else (the reference's clip loop runs two forwards
+        for these, evaluate_video.py:143-149); unlike `score_all` no reconstruction or error map is written."""
+        if not self._use_hip():
+            raise hip.VadError("score_seq_and_frames is an inference entry point: call under eval() and torch.no_grad()")
+        return self._run_hip(x, seq=True, frame=True)
+
     def score_all(self, x):
         """One pass returning recon, error maps, frame and clip scores (the reference's dense video mode
         runs three forwards per window for these: evaluate_video.py:350-352)."""
