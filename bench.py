@@ -246,13 +246,14 @@ def main():
         ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
         # (tools/pmc_traffic.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); only valid for the default shape.
-        traffic = None
-        pmc = REPO / "profiles" / f"r01_pmc_traffic_{args.workload}.json"
-        if pmc.exists() and hw == 256 and not args.batch and int(model.chunk) == (128 if args.workload == "image" else 64):
-            traffic = round(json.loads(pmc.read_text())["traffic_bytes_per_launch"])
-        roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (fp32 32x32x2 MFMA; all launches)",
+        traffic, traffic_source = None, None
+        pmcs = sorted((REPO / "profiles").glob(f"r*_pmc_traffic_{args.workload}.json"))     # newest round last
+        if pmcs and hw == 256 and not args.batch and int(model.chunk) == (128 if args.workload == "image" else 64) and (args.workload != "video" or t == 10):
+            traffic = round(json.loads(pmcs[-1].read_text())["traffic_bytes_per_launch"])
+            traffic_source = f"profiles/{pmcs[-1].name} (separate rocprofv3 --pmc passes of this command, not this run)"
+        roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_pkernel (fp32 32x32x2 MFMA; all launches)",
                     "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_flop_per_launch": round(mf_flop / max(mf_launch, 1)),
                     "avg_launch_ms": round(mf_ms / max(mf_launch, 1), 4), "launches": mf_launch,
                     "whole_path_tflops": round(fps / world * flop_per_frame / 1e12, 2),
@@ -321,6 +322,8 @@ def main():
         out["unique_frames_per_sec"] = round(((per_gpu - 1) * args.stride + t) * world * args.steps / elapsed, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "dense":
         out["cpu_baseline"] = cpu_baseline(vad, state, args, scores, seed, hw)
+    if world > 1:
+        out["multi_gpu"] = multi_gpu_evidence(vad, dist, args, state, scores, seed, hw, per_gpu, width, rank, world, dev, local_rank)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -363,6 +366,54 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
     del m, x
     torch.cuda.empty_cache()
     return out
+
+
+def multi_gpu_evidence(vad, dist, args, state, scores, seed, hw, per_gpu, width, rank, world, dev, local_rank):
+    """N > 1 makes the run self-verifying: which device every rank really used, the wall time of the one collective, and
+    rank 0's parity check of the GATHERED vector against the CPU oracle on one item from every rank's block (so a rank that
+    scored the wrong block, or a gather in the wrong order, fails here and not silently)."""
+    from oracle import torch_oracle
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "name": torch.cuda.get_device_name(dev),
+            "uuid": str(getattr(props, "uuid", "")), "cus": props.multi_processor_count, "hbm_GiB": round(props.total_memory / 2**30, 1)}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, mine)
+    # the collective alone: `per * width` floats per rank, as in every step
+    local = torch.zeros(per_gpu, width, dtype=torch.float32, device=dev)
+    gathered = torch.empty(world * per_gpu, width, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        dist.all_gather_into_tensor(gathered, local)
+    torch.cuda.synchronize()
+    dist.barrier()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(gathered, local)
+    torch.cuda.synchronize()
+    ag_ms = (time.perf_counter() - t0) / reps * 1e3
+    tt = torch.tensor([ag_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ev = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
+          "distinct_devices": len({(r["uuid"], r["device_index"]) for r in ranks}),
+          "allgather_ms": round(float(tt.item()), 4), "allgather_bytes_per_rank": per_gpu * width * 4}
+    if rank == 0 and args.workload != "dense" and not args.no_cpu_baseline:
+        torch.set_num_threads(host_cores())
+        items = [r * per_gpu + (37 * r + 5) % per_gpu for r in range(world)]       # one item out of every rank's block
+        with torch.no_grad():
+            if args.workload == "image":
+                xs = torch.from_numpy(np.concatenate([vad.synth.frames(seed, i, 1, 3, hw, hw) for i in items]))
+                ref = torch_oracle.img_scores(state, xs)["scores"]
+            else:
+                t = args.clip_len
+                xs = torch.from_numpy(np.concatenate([vad.synth.clips(seed, i, 1, t, 3, hw, hw) for i in items]))
+                ref = torch_oracle.vid_scores(state, xs, 128, 2)["frame"]
+        got = scores[items].cpu()
+        rel = float(((got - ref).abs() / ref.abs()).max())
+        ev["parity"] = {"checked_items": items, "oracle": "oracle/torch_oracle.py on rank 0's host cores",
+                        "max_rel_score_err_vs_cpu": rel, "within_1e-4": bool(rel < 1e-4)}
+        if not rel < 1e-4:
+            raise SystemExit(f"multi-GPU parity check failed: gathered scores differ from the CPU oracle by {rel:.3e} on items {items}")
+    return ev
 
 
 def host_cores() -> int:

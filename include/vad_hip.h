@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define VAD_ABI_VERSION 1
+#define VAD_ABI_VERSION 2   /* 2: the arithmetic mode is an argument of every packer / launcher; no process-wide switch */
 #define VAD_OK 0
 #define VAD_ERR_ARG (-1)   /* bad argument / unsupported shape */
 #define VAD_ERR_HIP (-2)   /* HIP runtime error */
@@ -25,8 +25,20 @@ extern "C" {
 #define VAD_ACT_LEAKY 1    /* LeakyReLU(0.2): models/autoencoder.py:41, models/video_autoencoder.py:195 */
 #define VAD_ACT_RELU 2     /* ReLU: models/autoencoder.py:106 */
 
+/* Arithmetic of the 3x3 / transposed convolutions.  It is an ARGUMENT (`precision`) of every entry point whose operand
+ * layout or kernel depends on it - never process state - so two models with different modes can be scored from two
+ * threads at once (the reference's UI calls one global model from worker threads, main.py:50,274).  Weights must be packed
+ * and launched with the same value; the model blobs carry it in their header (see vad_img_pack).
+ *   VAD_PREC_FP32  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain (the parity path);
+ *   VAD_PREC_SPLIT split fp16: every fp32 operand v is used as hi = fp16(v), lo = fp16((v-hi)*2^11) and a*b is evaluated
+ *      as ah*bh + (ah*bl + al*bh)*2^-11 with three v_mfma_f32_32x32x16_f16 and fp32 accumulation.  fp16 products are
+ *      exact in fp32, so each product carries 22 significant bits (fp32 has 24); activations and outputs in HBM stay
+ *      fp32.  Needs |activation| < 65504.  Opt-in; gated by the same golden-vector and trained-model tests. */
+#define VAD_PREC_FP32 0
+#define VAD_PREC_SPLIT 1
+
 int vad_abi_version(void);
-const char* vad_last_error(void);
+const char* vad_last_error(void);   /* per thread */
 
 /* ------------------------------------------------------------------ weight packing (host, CPU)
  * Folds eval-mode BatchNorm2d (eps 1e-5; y = (x-mean)/sqrt(var+eps)*gamma+beta) into the preceding
@@ -38,9 +50,9 @@ const char* vad_last_error(void);
  * models/video_autoencoder.py:46-52,191-215. */
 size_t vad_pack_conv3x3_floats(int cout, int cin);
 int vad_pack_conv3x3(const float* w_oihw, const float* bias, const float* const* bn,
-                     int cout, int cin, float* w_packed, float* bias_out);
+                     int cout, int cin, int precision, float* w_packed, float* bias_out);
 
-/* First-layer form (Cin == 3, K = 27 padded to 28): -> [14][2][Cout]. */
+/* First-layer form (Cin == 3, K = 27 padded to 28): -> [14][2][Cout], followed by the split-fp16 form (both modes). */
 size_t vad_pack_conv3x3_c3_floats(int cout);
 int vad_pack_conv3x3_c3(const float* w_oihw, const float* bias, const float* const* bn,
                         int cout, float* w_packed, float* bias_out);
@@ -49,7 +61,7 @@ int vad_pack_conv3x3_c3(const float* w_oihw, const float* bias, const float* con
  * Replaces models/autoencoder.py:104,113,122,131 and models/video_autoencoder.py:244-260. */
 size_t vad_pack_convt2x2_floats(int cin, int cout);
 int vad_pack_convt2x2(const float* w_iohw, const float* bias, const float* const* bn,
-                      int cin, int cout, float* w_packed, float* bias_out);
+                      int cin, int cout, int precision, float* w_packed, float* bias_out);
 
 /* Conv2d k1 (VideoAutoencoder.proj, models/video_autoencoder.py:311) -> [Cin/8][Cout][8]. */
 size_t vad_pack_conv1x1_floats(int cout, int cin);
@@ -68,18 +80,18 @@ int vad_conv3x3_c3(const float* x_nchw, const float* w_packed, const float* bias
  * MaxPool2d(2,2) in ONE launch; the 32-channel full-resolution map stays in LDS.  w0/b0 from
  * vad_pack_conv3x3_c3 (cout 32), w1/b1 from vad_pack_conv3x3 (32,32).  out NHWC [N,H/2,W/2,32]. */
 int vad_conv3x3_c3_fused(const float* x_nchw, const float* w0, const float* b0, const float* w1, const float* b1,
-                         float* out_nhwc, int n, int h, int w, void* stream);
+                         float* out_nhwc, int n, int h, int w, int precision, void* stream);
 
 /* NHWC conv3x3 p1 + bias + act (+ MaxPool2d(2,2) when pool != 0).  Cin multiple of 8 (32 for
  * speed), Cout multiple of 32.  pool needs even H, W. */
 int vad_conv3x3(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
                 float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,
-                int act, int pool, void* stream);
+                int act, int pool, int precision, void* stream);
 
 /* NHWC ConvTranspose2d k2 s2 + bias + act: [N,H,W,Cin] -> [N,2H,2W,Cout]. */
 int vad_convt2x2(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
                  float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,
-                 int act, void* stream);
+                 int act, int precision, void* stream);
 
 /* NHWC 1x1 conv + bias (no activation). */
 int vad_conv1x1(const float* in_nhwc, const float* w_packed, const float* bias, float* out_nhwc,
@@ -92,7 +104,7 @@ int vad_conv1x1(const float* in_nhwc, const float* w_packed, const float* bias, 
  * may alias c_prev). */
 int vad_convlstm_step(const float* x, long long x_fs, const float* h_prev, long long h_prev_fs,
                       const float* c_prev, const float* w_packed, const float* bias, float* h_out, long long h_out_fs,
-                      float* c_out, int n, int h, int w, int cin_x, int hid, void* stream);
+                      float* c_out, int n, int h, int w, int cin_x, int hid, int precision, void* stream);
 
 /* Scoring tails.  x is the ORIGINAL input, NCHW [N,3,H2,W2] with H2 = output size.
  * partials: [N][vad_score_partials(H2,W2)] per-tile sums of sum_c (x-recon)^2.
@@ -201,12 +213,12 @@ int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, const float* bi
 int vad_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* Device-side operand packing of the CURRENT parameters (no BatchNorm folding in train mode; the layout follows
- * vad_set_precision like the host packers):
+ * `precision` like the host packers):
  * fwd = the forward kernels' order (vad_pack_conv3x3 / vad_pack_convt2x2 / vad_pack_conv3x3_c3 layouts);
  * dgrad = the data-gradient operand: for conv3x3 a conv3x3 weight with cin/cout swapped and taps rotated (run it
  * through vad_conv3x3), for convT a 1x1 weight with K = 4*cout (run vad_conv1x1 on the space-to-depth gradient). */
-int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
-int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream);
+int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream);
+int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, int precision, void* stream);
 int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* stream);
 /* Conv2d(cin->3) k3 (ConvAutoencoder's last conv, models/autoencoder.py:134): fwd = vad_pack_conv3x3_to3 layout for the
  * scoring tail kernel; dgrad_c3 = the rotated weights in vad_pack_conv3x3_c3 form (vad_pack_conv3x3_c3_floats(cin) floats):
@@ -224,7 +236,7 @@ int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, f
 /* ------------------------------------------------------------------ whole training step (row f-1)
  * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim,
  * lstm_num_layers) (both dims multiples of 32, hidden <= 256; `proj` is the 1x1 conv when they differ): train-mode forward (batch-statistics BatchNorm, running stats updated when `running`
- * is given), nn.MSELoss, and the full backward.  Exact fp32 by default; under vad_set_precision(1) the 3x3 and
+ * is given), nn.MSELoss, and the full backward.  precision VAD_PREC_FP32: exact fp32; VAD_PREC_SPLIT: the 3x3 and
  * transposed convolutions (forward + data gradients) use the split-fp16 operands, the rest stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
  * floats, torch layouts in named_parameters() order (see csrc/train_step.hip); running: vad_vid_train_nstats floats,
  * {running_mean, running_var} per BatchNorm in module order.  x [B,T,3,H,W]; loss: device float[1];
@@ -243,7 +255,7 @@ int vad_debug_set_train_stop(int stage);   /* debug: stop vad_vid_train_fwd_bwd 
 int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent, int hid, int layers, long long* out, int cap);
 int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent, int hid, int layers,
                           const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
-                          float* loss, float* recon, void* stream);
+                          int precision, float* loss, float* recon, void* stream);
 
 /* Image autoencoder counterpart (train.py:28-52; not a SURVEY section 8 row): ConvAutoencoder(in_channels=3, latent_dim), x
  * [N,3,H,W]; loss_kind 0 = nn.MSELoss (train.py default), 1 = SSIMLoss(window_size), 2 = CombinedLoss(alpha, window_size)
@@ -253,7 +265,7 @@ size_t vad_img_train_nstats(int latent);
 size_t vad_img_train_workspace_bytes(int n, int h, int w, int latent);
 int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int latent, const float* params, float* grads,
                           float* running, void* workspace, size_t workspace_bytes, int loss_kind, float alpha,
-                          int window_size, float* loss, float* recon, void* stream);
+                          int window_size, int precision, float* loss, float* recon, void* stream);
 
 /* Synthetic frames on device, bit-identical to synth.frames() (numpy): NCHW fp32 in [-1,1].  anomalies: 0 = none,
  * 1 = labelled frames carry a saturated 32 x 32 patch, k >= 2 = a k x k patch. */
@@ -265,12 +277,18 @@ int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_f
  * (models/autoencoder.py:181-221) as driven by evaluate.compute_auroc (evaluate.py:56-64).
  * params: VAD_IMG_NPARAMS host pointers in state_dict order with num_batches_tracked removed. */
 #define VAD_IMG_NPARAMS 92
+/* The packed blob starts with a 16-byte header {magic "VADB", tag = abi<<16 | precision<<8 | model kind, dims}; the
+ * layers follow.  Pack with the precision the blob will be launched with: the kernel that finalises the scores compares
+ * the tag with the launch's `precision` on the device and returns NaN scores on a mismatch (never a silent wrong number).
+ * vad_blob_precision reads the mode back from a HOST copy of a blob (negative VAD_ERR_ARG if it is not one). */
 size_t vad_img_packed_floats(int in_ch, int latent);
-int vad_img_pack(const float* const* params, int nparams, int in_ch, int latent, float* packed_host);
+int vad_img_pack(const float* const* params, int nparams, int in_ch, int latent, int precision, float* packed_host);
+int vad_blob_precision(const float* packed_host);
 size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent);
 /* x NCHW [B,3,H,W] on device.  Frames are processed in chunks of `chunk` through `workspace`.
  * Outputs (device, any may be NULL): scores [B]; errmap [B,H,W]; recon NCHW [B,3,H,W];
- * latent NCHW [B,latent,H/16,W/16]. */
+ * latent NCHW [B,latent,H/16,W/16].  This short form is float input + VAD_PREC_FP32 (blob packed likewise);
+ * vad_img_score_x takes the input format and the arithmetic mode. */
 int vad_img_score(const float* x_nchw, long long b, int h, int w, int latent,
                   const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk,
                   float* scores, float* errmap, float* recon_nchw, float* latent_nchw, void* stream);
@@ -281,7 +299,7 @@ int vad_img_score(const float* x_nchw, long long b, int h, int w, int latent,
  *   4 x (conv w,b, bn g,b,m,v) ; layers x (cell w,b) ; [proj w,b] ; 3 x (convT w,b, bn g,b,m,v) ; convT w,b */
 int vad_vid_nparams(int layers, int has_proj);
 size_t vad_vid_packed_floats(int latent, int hid, int layers);
-int vad_vid_pack(const float* const* params, int nparams, int latent, int hid, int layers, float* packed_host);
+int vad_vid_pack(const float* const* params, int nparams, int latent, int hid, int layers, int precision, float* packed_host);
 size_t vad_vid_workspace_bytes(int chunk_clips, int t, int h, int w, int latent, int hid, int layers);
 /* x [B,T,3,H,W].  Outputs (any may be NULL): seq_scores [B]; frame_scores [B,T];
  * errmap [B,T,H,W]; recon [B,T,3,H,W]. */
@@ -289,18 +307,9 @@ int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, 
                   const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips,
                   float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
 
-/* Arithmetic of the 3x3 convolutions (process-wide; set it BEFORE packing weights — the packed layout follows it —
- * and do not change it while another thread is inside the library):
- *   0  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain (default; the parity path);
- *   1  split fp16: every fp32 operand v is used as hi = fp16(v), lo = fp16((v-hi)*2^11) and a*b is evaluated as
- *      ah*bh + (ah*bl + al*bh)*2^-11 with three v_mfma_f32_32x32x16_f16 and fp32 accumulation.  fp16 products are
- *      exact in fp32, so each product carries 22 significant bits (fp32 has 24); activations and outputs in HBM stay
- *      fp32.  Needs |activation| < 65504.  Opt-in; gated by the same golden-vector and trained-model tests. */
-int vad_set_precision(int mode);
-int vad_get_precision(void);
-
-/* Developer switch for A/B timing in one process: 0 = one tile per work-group, 1 = persistent work-groups with
- * register prefetch of the next stage (default).  Results are bit-identical. */
+/* Developer switches for A/B timing in one process (process-wide, debug only; the library never writes them itself and
+ * results are bit-identical): 0 = one tile per work-group, 1 = persistent work-groups with register prefetch of the next
+ * stage (default). */
 int vad_debug_set_conv_variant(int variant);
 /* Frames per dec4.0 -> scoring-tail sub-group inside vad_img_score (0 = whole launch group). */
 int vad_debug_set_tail_group(int frames);
@@ -311,16 +320,17 @@ int vad_debug_set_tail_group(int frames);
  *                       (reference utils/dataset.py:65-70, utils/video_dataset.py:62-66) is applied inside the first
  *                       convolution's staging load and inside the scoring tail, bit-identically to the fp32 path, so
  *                       the normalised fp32 frames (4x the bytes) never exist in memory.
- * All other arguments and outputs are those of vad_img_score / vad_vid_score / vad_vid_score_windows. */
+ * `precision` is the arithmetic mode the blob was packed for (VAD_PREC_*).  All other arguments and outputs are those of
+ * vad_img_score / vad_vid_score / vad_vid_score_windows (which are the float-input, VAD_PREC_FP32 short forms). */
 #define VAD_X_F32_NCHW 0
 #define VAD_X_U8_NHWC 1
-int vad_img_score_x(const void* x, int x_format, long long b, int h, int w, int latent, const float* packed_dev,
+int vad_img_score_x(const void* x, int x_format, int precision, long long b, int h, int w, int latent, const float* packed_dev,
                     void* workspace, size_t workspace_bytes, int chunk, float* scores, float* errmap, float* recon_nchw,
                     float* latent_nchw, void* stream);
-int vad_vid_score_x(const void* x, int x_format, long long b, int t, int h, int w, int latent, int hid, int layers,
+int vad_vid_score_x(const void* x, int x_format, int precision, long long b, int t, int h, int w, int latent, int hid, int layers,
                     const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips, float* seq_scores,
                     float* frame_scores, float* errmap, float* recon, void* stream);
-int vad_vid_score_windows_x(const void* frames, int x_format, long long nframes, int t, int stride, int h, int w,
+int vad_vid_score_windows_x(const void* frames, int x_format, int precision, long long nframes, int t, int stride, int h, int w,
                             int latent, int hid, int layers, const float* packed_dev, void* workspace,
                             size_t workspace_bytes, int chunk_windows, float* seq_scores, float* frame_scores,
                             float* errmap, float* recon, void* stream);
@@ -339,7 +349,8 @@ int vad_vid_score_windows(const float* frames, long long nframes, int t, int str
 /* ------------------------------------------------------------------ per-layer timing
  * When enabled, the model-level calls bracket every layer launch with hipEvents on `stream`.
  * vad_prof_read synchronises the events and returns the accumulated ms and launch count per
- * layer slot since the last vad_prof_reset. */
+ * layer slot since the last vad_prof_reset.  The record list is mutex-guarded: threads may score concurrently while
+ * profiling is on (their records are pooled). */
 #define VAD_PROF_SLOTS 32
 int vad_prof_enable(int on);
 int vad_prof_reset(void);

@@ -7,6 +7,9 @@ import torch
 
 hip = importlib.import_module("video-anomaly-detection_amd.hip")
 
+#: arithmetic mode (VAD_PREC_*) the helpers pack and launch with; tests that cover the split mode set it around a case
+PRECISION = 0
+
 
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
@@ -39,7 +42,7 @@ def pack_conv3x3(w, b, bn=None):
     else:
         wp = np.empty(l.vad_pack_conv3x3_floats(cout, cin), np.float32)
         bo = np.empty(cout, np.float32)
-        hip.check(l.vad_pack_conv3x3(w.ctypes.data, b.ctypes.data, bnp, cout, cin, wp.ctypes.data, bo.ctypes.data))
+        hip.check(l.vad_pack_conv3x3(w.ctypes.data, b.ctypes.data, bnp, cout, cin, PRECISION, wp.ctypes.data, bo.ctypes.data))
     return dev(wp), dev(bo)
 
 
@@ -50,7 +53,7 @@ def pack_convt(w, b, bn=None):
     keep, bnp = _bn_ptrs(bn)
     wp = np.empty(l.vad_pack_convt2x2_floats(cin, cout), np.float32)
     bo = np.empty(cout, np.float32)
-    hip.check(l.vad_pack_convt2x2(w.ctypes.data, b.ctypes.data, bnp, cin, cout, wp.ctypes.data, bo.ctypes.data))
+    hip.check(l.vad_pack_convt2x2(w.ctypes.data, b.ctypes.data, bnp, cin, cout, PRECISION, wp.ctypes.data, bo.ctypes.data))
     return dev(wp), dev(bo)
 
 
@@ -72,7 +75,7 @@ def conv3x3(x_nchw, w, b, bn=None, act=0, pool=False):
     else:
         xin = nhwc(x_nchw)
         hip.check(l.vad_conv3x3(xin.data_ptr(), 0, wp.data_ptr(), bo.data_ptr(), out.data_ptr(), 0, n, h, wd, cin,
-                                cout, act, int(pool), stream()))
+                                cout, act, int(pool), PRECISION, stream()))
     torch.cuda.synchronize()
     return to_nchw(out)
 
@@ -85,7 +88,7 @@ def convt2x2(x_nchw, w, b, bn=None, act=0):
     xin = nhwc(x_nchw)
     out = torch.full((n, 2 * h, 2 * wd, cout), float("nan"), device="cuda")
     hip.check(l.vad_convt2x2(xin.data_ptr(), 0, wp.data_ptr(), bo.data_ptr(), out.data_ptr(), 0, n, h, wd, cin, cout,
-                             act, stream()))
+                             act, PRECISION, stream()))
     torch.cuda.synchronize()
     return to_nchw(out)
 
@@ -118,7 +121,7 @@ def convlstm_step(x, h, c, w, b):
     hout = torch.full((n, hh, ww, hid), float("nan"), device="cuda")
     cout = torch.full((n, hh, ww, hid), float("nan"), device="cuda")
     hip.check(l.vad_convlstm_step(xin.data_ptr(), 0, hip.ptr(hin), 0, hip.ptr(cin_), wp.data_ptr(), bo.data_ptr(),
-                                  hout.data_ptr(), 0, cout.data_ptr(), n, hh, ww, cx, hid, stream()))
+                                  hout.data_ptr(), 0, cout.data_ptr(), n, hh, ww, cx, hid, PRECISION, stream()))
     torch.cuda.synchronize()
     return to_nchw(hout), to_nchw(cout)
 
@@ -132,6 +135,6 @@ def conv3x3_c3_fused(x_nchw, w0, b0, bn0, w1, b1, bn1):
     xin = dev(x_nchw)
     out = torch.full((n, h // 2, wd // 2, 32), float("nan"), device="cuda")
     hip.check(l.vad_conv3x3_c3_fused(xin.data_ptr(), wp0.data_ptr(), bo0.data_ptr(), wp1.data_ptr(), bo1.data_ptr(),
-                                     out.data_ptr(), n, h, wd, stream()))
+                                     out.data_ptr(), n, h, wd, PRECISION, stream()))
     torch.cuda.synchronize()
     return to_nchw(out)

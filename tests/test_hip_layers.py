@@ -80,14 +80,13 @@ def test_conv3x3_no_bn_and_frame_strides():
                                               (32, 32, 9, 13, 2), (32, 64, 3, 5, 0), (128, 128, 2, 2, 1)])
 @pytest.mark.parametrize("precision", [0, 1])
 def test_convt2x2(vad, cin, cout, h, w, act, precision):
-    """precision 1 = split-fp16 operands (weights packed AND kernels launched under vad_set_precision(1))."""
+    """precision 1 = split-fp16 operands (weights packed AND kernels launched with precision = VAD_PREC_SPLIT)."""
     import hip_helpers as H
-    l = vad.hip.lib()
-    assert l.vad_set_precision(precision) == 0
+    H.PRECISION = precision
     try:
         _check_convt2x2(H, cin, cout, h, w, act)
     finally:
-        l.vad_set_precision(0)
+        H.PRECISION = 0
 
 
 def _check_convt2x2(H, cin, cout, h, w, act):
@@ -166,8 +165,8 @@ def test_bad_arguments_are_rejected():
     import hip_helpers as H
     l = H.hip.lib()
     t = torch.zeros(16, device="cuda")
-    assert l.vad_conv3x3(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 1, 4, 4, 24, 32, 0, 0, None) == -1
+    assert l.vad_conv3x3(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 1, 4, 4, 24, 32, 0, 0, 0, None) == -1
     assert b"multiples of 32" in l.vad_last_error()
-    assert l.vad_conv3x3(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 1, 5, 4, 32, 32, 0, 1, None) == -1
+    assert l.vad_conv3x3(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 1, 5, 4, 32, 32, 0, 1, 0, None) == -1
     assert l.vad_img_score(t.data_ptr(), 1, 30, 32, 256, t.data_ptr(), t.data_ptr(), 64, 1, t.data_ptr(), None, None, None, None) == -1
     assert l.vad_img_score(t.data_ptr(), 1, 32, 32, 256, t.data_ptr(), t.data_ptr(), 64, 1, t.data_ptr(), None, None, None, None) == -3

@@ -253,42 +253,106 @@ def test_trained_model_precision_gate(vad, golden):
 
 
 def test_split_precision_mode_holds_parity(vad, golden):
-    """Opt-in split-fp16 arithmetic (3 x fp16 MFMA, fp32 accumulate; vad_set_precision): every score gate of the exact
-    path — reference golden vectors on random weights, the trained-model gate, the ConvLSTM video model — within 1e-5
-    relative, i.e. 10x inside north_star's 1e-4 bar."""
-    try:
-        g = golden("img_l256_64.npz")
-        m, _ = _img_model(vad, 256, int(g["wseed"]))
-        m.precision = "split"
-        x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), 3, 64, 64)).cuda()
-        with torch.no_grad():
-            out = m.score_all(x)
-        assert rel_err(out["scores"].cpu().numpy(), g["scores"]) < SCORE_RTOL
-        assert max_abs(out["recon"].cpu().numpy(), g["recon"]) < ACT_ATOL
-        t = golden("img_trained_l64.npz")
-        mt = vad.ConvAutoencoder(in_channels=3, latent_dim=64)
-        mt.load_state_dict({k[2:]: torch.from_numpy(t[k]) for k in t.files if k.startswith("w.")}, strict=True)
-        mt = mt.cuda().eval()
-        mt.precision = "split"
-        with torch.no_grad():
-            s = mt.get_reconstruction_error(torch.from_numpy(t["test_u8"]).cuda()).cpu().numpy()
-        assert rel_err(s, t["scores"]) < SCORE_RTOL
-        assert np.array_equal(np.argsort(s), np.argsort(t["scores"]))
-        v = golden("vid_default_64.npz")
-        mv, _ = _vid_model(vad, 128, 128, 2, int(v["wseed"]))
-        mv.precision = "split"
-        xv = torch.from_numpy(vad.synth.clips(int(v["xseed"]), 0, int(v["b"]), int(v["t"]), 3, 64, 64)).cuda()
-        with torch.no_grad():
-            ov = mv.score_all(xv)
-        assert rel_err(ov["frame"].cpu().numpy(), v["frame"]) < SCORE_RTOL
-        assert max_abs(ov["recon"].cpu().numpy(), v["recon"]) < ACT_ATOL
-        # and the exact path is still what a default model uses afterwards
-        m2, _ = _img_model(vad, 256, int(g["wseed"]))
-        with torch.no_grad():
-            s2 = m2.get_reconstruction_error(x)
-        assert vad.hip.lib().vad_get_precision() == 0 and rel_err(s2.cpu().numpy(), g["scores"]) < SCORE_RTOL
-    finally:
-        vad.hip.lib().vad_set_precision(0)
+    """Opt-in split-fp16 arithmetic (3 x fp16 MFMA, fp32 accumulate; `model.precision = "split"` -> VAD_PREC_SPLIT in
+    every call): every score gate of the exact path — reference golden vectors on random weights, the trained-model gate,
+    the ConvLSTM video model — within 1e-5 relative, i.e. 10x inside north_star's 1e-4 bar."""
+    g = golden("img_l256_64.npz")
+    m, _ = _img_model(vad, 256, int(g["wseed"]))
+    m.precision = "split"
+    x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), 3, 64, 64)).cuda()
+    with torch.no_grad():
+        out = m.score_all(x)
+    assert rel_err(out["scores"].cpu().numpy(), g["scores"]) < SCORE_RTOL
+    assert max_abs(out["recon"].cpu().numpy(), g["recon"]) < ACT_ATOL
+    t = golden("img_trained_l64.npz")
+    mt = vad.ConvAutoencoder(in_channels=3, latent_dim=64)
+    mt.load_state_dict({k[2:]: torch.from_numpy(t[k]) for k in t.files if k.startswith("w.")}, strict=True)
+    mt = mt.cuda().eval()
+    mt.precision = "split"
+    with torch.no_grad():
+        s = mt.get_reconstruction_error(torch.from_numpy(t["test_u8"]).cuda()).cpu().numpy()
+    assert rel_err(s, t["scores"]) < SCORE_RTOL
+    assert np.array_equal(np.argsort(s), np.argsort(t["scores"]))
+    v = golden("vid_default_64.npz")
+    mv, _ = _vid_model(vad, 128, 128, 2, int(v["wseed"]))
+    mv.precision = "split"
+    xv = torch.from_numpy(vad.synth.clips(int(v["xseed"]), 0, int(v["b"]), int(v["t"]), 3, 64, 64)).cuda()
+    with torch.no_grad():
+        ov = mv.score_all(xv)
+    assert rel_err(ov["frame"].cpu().numpy(), v["frame"]) < SCORE_RTOL
+    assert max_abs(ov["recon"].cpu().numpy(), v["recon"]) < ACT_ATOL
+    # the mode belongs to the model: a default model scored afterwards (and the first one flipped back) is exact again
+    m2, _ = _img_model(vad, 256, int(g["wseed"]))
+    with torch.no_grad():
+        s2 = m2.get_reconstruction_error(x)
+        m.precision = "fp32"
+        s3 = m.get_reconstruction_error(x)
+    assert rel_err(s2.cpu().numpy(), g["scores"]) < SCORE_RTOL and torch.equal(s2, s3)
+
+
+def test_two_threads_with_different_precision_do_not_interfere(vad):
+    """SURVEY.md section 8(b) threading contract (the reference's UI calls one global model from worker threads,
+    main.py:50,274): an exact-fp32 model and a split-fp16 model scored CONCURRENTLY from two Python threads on two
+    streams give, every time, bit-for-bit what each gives alone.  With the arithmetic mode as process state (ABI 1) the
+    two raced: a blob packed for one mode was launched under the other."""
+    import threading
+    ma, _ = _img_model(vad, 64, 3)
+    mb, _ = _img_model(vad, 64, 3)
+    mb.precision = "split"
+    va, _ = _vid_model(vad, 64, 64, 2, 5)
+    va.precision = "split"
+    x = vad.scoring.synth_frames_device(9, 0, 24, 64, 64)
+    xc = vad.scoring.synth_frames_device(10, 0, 24, 32, 32).view(4, 6, 3, 32, 32)
+    with torch.no_grad():
+        want = {"a": ma.get_reconstruction_error(x), "b": mb.get_reconstruction_error(x), "v": va.score_seq_and_frames(xc)["frame"]}
+    assert not torch.equal(want["a"], want["b"])                    # the two modes do differ in the last bits
+    torch.cuda.synchronize()
+    rounds, errors, start = 40, [], threading.Barrier(3)
+
+    def worker(tag, fn):
+        try:
+            stream = torch.cuda.Stream()
+            start.wait()
+            with torch.no_grad(), torch.cuda.stream(stream):
+                for i in range(rounds):
+                    got = fn()
+                    stream.synchronize()
+                    if not torch.equal(got, want[tag]):
+                        errors.append(f"{tag}: round {i} differs from the single-threaded result")
+                        return
+        except Exception as e:                                      # noqa: BLE001 - reported by the main thread
+            errors.append(f"{tag}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=("a", lambda: ma.get_reconstruction_error(x))),
+               threading.Thread(target=worker, args=("b", lambda: mb.get_reconstruction_error(x))),
+               threading.Thread(target=worker, args=("v", lambda: va.score_seq_and_frames(xc)["frame"]))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads) and not errors, errors
+
+
+def test_blob_launched_under_the_wrong_precision_is_rejected_on_the_device(vad):
+    """ABI 2 safety net: the packed blob's header carries the mode it was packed for; a launch that names another mode
+    returns NaN scores (checked by the finalising kernel on the device), never a plausible wrong number."""
+    l = vad.hip.lib()
+    m, _ = _img_model(vad, 64, 5)
+    x = vad.scoring.synth_frames_device(1, 0, 2, 64, 64)
+    packed = m._packed(x.device)                                    # packed for fp32
+    need = l.vad_img_workspace_bytes(2, 64, 64, 64)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    scores = torch.zeros(2, device="cuda")
+    s = vad.hip.current_stream()
+    args = (2, 64, 64, 64, packed.data_ptr(), ws.data_ptr(), need, 2, scores.data_ptr(), None, None, None, s)
+    assert l.vad_img_score_x(x.data_ptr(), 0, vad.hip.PREC_SPLIT, *args) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(scores).all()
+    assert l.vad_img_score_x(x.data_ptr(), 0, vad.hip.PREC_FP32, *args) == 0
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert torch.equal(scores, m.get_reconstruction_error(x))
+    assert l.vad_img_score_x(x.data_ptr(), 0, 5, *args) == -1 and b"precision" in l.vad_last_error()
 
 
 def test_uint8_ingest_is_bit_identical(vad):
@@ -445,11 +509,12 @@ def test_c_abi_reports_errors_before_launching(vad):
     tb = l.vad_vid_train_workspace_bytes(1, 2, 32, 32, *cfg)
     tws = torch.empty(tb, dtype=torch.uint8, device="cuda")
     assert l.vad_vid_train_fwd_bwd(clips.data_ptr(), 1, 2, 32, 32, *cfg, flat.data_ptr(), grad.data_ptr(), None, tws.data_ptr(), tb - 1,
-                                   loss.data_ptr(), None, s) == ERR_WS
+                                   0, loss.data_ptr(), None, s) == ERR_WS
     assert l.vad_vid_train_fwd_bwd(clips.data_ptr(), 1, 2, 24, 32, *cfg, flat.data_ptr(), grad.data_ptr(), None, tws.data_ptr(), tb,
-                                   loss.data_ptr(), None, s) == ERR_ARG and b"multiples of 16" in l.vad_last_error()
+                                   0, loss.data_ptr(), None, s) == ERR_ARG and b"multiples of 16" in l.vad_last_error()
+    assert l.vad_vid_train_fwd_bwd(clips.data_ptr(), 1, 2, 32, 32, *cfg, flat.data_ptr(), grad.data_ptr(), None, tws.data_ptr(), tb,
+                                   9, loss.data_ptr(), None, s) == ERR_ARG and b"precision" in l.vad_last_error()
     assert l.vad_adam_step(flat.data_ptr(), grad.data_ptr(), flat.data_ptr(), flat.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1.0, s) == ERR_ARG   # step >= 1
-    assert l.vad_set_precision(7) == ERR_ARG and l.vad_get_precision() == 0
 
 
 # ------------------------------------------------------------------------------------------------ configs[3]: frame stream

@@ -188,15 +188,10 @@ def test_lstm_gates_forward_backward(vad, nb, hw, hid, first):
 def test_conv3x3_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
     """precision 1: the device packers emit the split-fp16 operand form and the forward / data-gradient convolutions run
     on it (the weight gradient is fp32 in both modes)."""
-    l = vad.hip.lib()
-    assert l.vad_set_precision(precision) == 0
-    try:
-        _check_conv3x3_gradients(vad, n, h, w, cin, cout)
-    finally:
-        l.vad_set_precision(0)
+    _check_conv3x3_gradients(vad, n, h, w, cin, cout, precision)
 
 
-def _check_conv3x3_gradients(vad, n, h, w, cin, cout):
+def _check_conv3x3_gradients(vad, n, h, w, cin, cout, precision):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin + cout + h)
     a = rng.standard_normal((n, cin, h, w)).astype(np.float32)
@@ -215,13 +210,13 @@ def _check_conv3x3_gradients(vad, n, h, w, cin, cout):
     wd = H.dev(wt)
     fwd = _ws(l.vad_pack_conv3x3_floats(cout, cin))
     dgr = _ws(l.vad_pack_conv3x3_floats(cin, cout))
-    vad.hip.check(l.vad_train_pack_conv3x3(wd.data_ptr(), cout, cin, fwd.data_ptr(), dgr.data_ptr(), H.stream()))
+    vad.hip.check(l.vad_train_pack_conv3x3(wd.data_ptr(), cout, cin, fwd.data_ptr(), dgr.data_ptr(), precision, H.stream()))
     zero_in, zero_out = torch.zeros(cin, device="cuda"), torch.zeros(cout, device="cuda")
     da = torch.full((n, h, w, cin), float("nan"), device="cuda")
-    vad.hip.check(l.vad_conv3x3(gd.data_ptr(), 0, dgr.data_ptr(), zero_in.data_ptr(), da.data_ptr(), 0, n, h, w, cout, cin, 0, 0, H.stream()))
+    vad.hip.check(l.vad_conv3x3(gd.data_ptr(), 0, dgr.data_ptr(), zero_in.data_ptr(), da.data_ptr(), 0, n, h, w, cout, cin, 0, 0, precision, H.stream()))
     _close(H.to_nchw(da), at.grad.numpy(), 1e-4, "dA")
     out = torch.full((n, h, w, cout), float("nan"), device="cuda")
-    vad.hip.check(l.vad_conv3x3(ad.data_ptr(), 0, fwd.data_ptr(), zero_out.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 0, 0, H.stream()))
+    vad.hip.check(l.vad_conv3x3(ad.data_ptr(), 0, fwd.data_ptr(), zero_out.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 0, 0, precision, H.stream()))
     _close(H.to_nchw(out), F.conv2d(torch.from_numpy(a), torch.from_numpy(wt), padding=1).numpy(), 2e-5, "forward with device pack")
 
 
@@ -229,15 +224,10 @@ def _check_conv3x3_gradients(vad, n, h, w, cin, cout):
                                             (4, 28, 28, 64, 32), (4, 7, 7, 32, 128), (2, 5, 3, 128, 64)])
 @pytest.mark.parametrize("precision", [0, 1])
 def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
-    l = vad.hip.lib()
-    assert l.vad_set_precision(precision) == 0
-    try:
-        _check_convt2x2_gradients(vad, n, h, w, cin, cout)
-    finally:
-        l.vad_set_precision(0)
+    _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision)
 
 
-def _check_convt2x2_gradients(vad, n, h, w, cin, cout):
+def _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin * 3 + cout + h)
     a = rng.standard_normal((n, cin, h, w)).astype(np.float32)
@@ -256,13 +246,13 @@ def _check_convt2x2_gradients(vad, n, h, w, cin, cout):
     wd = H.dev(wt)
     fwd = _ws(l.vad_pack_convt2x2_floats(cin, cout))
     dgr = _ws(l.vad_pack_conv1x1_floats(cin, 4 * cout))
-    vad.hip.check(l.vad_train_pack_convt2x2(wd.data_ptr(), cin, cout, fwd.data_ptr(), dgr.data_ptr(), H.stream()))
+    vad.hip.check(l.vad_train_pack_convt2x2(wd.data_ptr(), cin, cout, fwd.data_ptr(), dgr.data_ptr(), precision, H.stream()))
     zero_in, zero_out = torch.zeros(cin, device="cuda"), torch.zeros(cout, device="cuda")
     da = torch.full((n, h, w, cin), float("nan"), device="cuda")
     vad.hip.check(l.vad_conv1x1(g_s2d.data_ptr(), dgr.data_ptr(), zero_in.data_ptr(), da.data_ptr(), n * h * w, 4 * cout, cin, H.stream()))
     _close(H.to_nchw(da), at.grad.numpy(), 1e-4, "dA")
     out = torch.full((n, 2 * h, 2 * w, cout), float("nan"), device="cuda")
-    vad.hip.check(l.vad_convt2x2(ad.data_ptr(), 0, fwd.data_ptr(), zero_out.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 0, H.stream()))
+    vad.hip.check(l.vad_convt2x2(ad.data_ptr(), 0, fwd.data_ptr(), zero_out.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 0, precision, H.stream()))
     _close(H.to_nchw(out), F.conv_transpose2d(torch.from_numpy(a), torch.from_numpy(wt), stride=2).numpy(), 2e-5, "forward with device pack")
 
 
@@ -363,7 +353,7 @@ def test_image_last_layer_conv_tanh_backward(vad, n, h, w, given_drecon):
     ad, xd, wd, bd = H.nhwc(a), H.dev(x), H.dev(wt), H.dev(b)
     fwd = _ws(l.vad_pack_conv3x3_to3_floats(32))
     dgr = torch.zeros(l.vad_pack_conv3x3_c3_floats(32), device="cuda")
-    vad.hip.check(l.vad_train_pack_conv3x3_to3(wd.data_ptr(), 32, fwd.data_ptr(), dgr.data_ptr(), H.stream()))
+    vad.hip.check(l.vad_train_pack_conv3x3_to3(wd.data_ptr(), 32, fwd.data_ptr(), dgr.data_ptr(), precision, H.stream()))
     recon = torch.full((n, 3, h, w), float("nan"), device="cuda")
     parts = _ws(n * l.vad_score_partials(0, h, w))
     vad.hip.check(l.vad_conv3x3_to3_score(ad.data_ptr(), fwd.data_ptr(), bd.data_ptr(), xd.data_ptr(), parts.data_ptr(), recon.data_ptr(), None,

@@ -345,7 +345,6 @@ def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, la
         worst = max(worst, err)
         assert err < bound, f"grad {k}: {err:.3e} of max |g| {scale:.3e} from the decision-conditioned float64 gradient " \
                            f"(decisions differing from float64: {[(s, n_) for s, n_, _, _ in report if n_]})"
-    assert vad.hip.lib().vad_get_precision() == 0                  # the trainer leaves the process-wide switch as found
     print(f"[{precision},{latent},{layers},{b}x{t},{hw}] worst gradient deviation {worst:.2e}; differing decisions {[(s, n_, f'{mg:.1e}') for s, n_, mg, _ in report if n_]}")
 
 

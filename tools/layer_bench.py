@@ -23,7 +23,7 @@ IMAGE_LAYERS = [  # name, kind, h, cin, cout, pool
 ]
 
 
-def run(kind, n, h, w, cin, cout, pool, iters, warm=3):
+def run(kind, n, h, w, cin, cout, pool, iters, warm=3, prec=0):
     l = hip.lib()
     g = torch.Generator(device="cuda").manual_seed(1)
     s = hip.current_stream()
@@ -38,19 +38,19 @@ def run(kind, n, h, w, cin, cout, pool, iters, warm=3):
         x = rnd(n, 3, h, w); w0 = rnd(28 * 32) * 0.2; b0 = rnd(32); w1 = rnd(9 * 32 * 32) * 0.05; b1 = rnd(32)
         out = torch.empty(n, h // 2, w // 2, 32, device="cuda")
         fn = lambda: l.vad_conv3x3_c3_fused(x.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
-                                            out.data_ptr(), n, h, w, s)
+                                            out.data_ptr(), n, h, w, prec, s)
         flop = 2.0 * n * h * w * (27 * 32 + 9 * 32 * 32)
         byts = 4.0 * (x.numel() + out.numel())
     elif kind == "conv3x3":
         x = rnd(n, h, w, cin); wt = rnd(9 * cin * cout) * 0.05; b = rnd(cout)
         out = torch.empty(n, h // (2 if pool else 1), w // (2 if pool else 1), cout, device="cuda")
-        fn = lambda: l.vad_conv3x3(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 1, pool, s)
+        fn = lambda: l.vad_conv3x3(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 1, pool, prec, s)
         flop = 2.0 * n * h * w * 9 * cin * cout
         byts = 4.0 * (x.numel() + out.numel())
     elif kind == "convt":
         x = rnd(n, h, w, cin); wt = rnd(4 * cin * cout) * 0.05; b = rnd(cout)
         out = torch.empty(n, 2 * h, 2 * w, cout, device="cuda")
-        fn = lambda: l.vad_convt2x2(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 2, s)
+        fn = lambda: l.vad_convt2x2(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 2, prec, s)
         flop = 2.0 * n * h * w * 4 * cin * cout
         byts = 4.0 * (x.numel() + out.numel())
     elif kind == "lstm":
@@ -59,7 +59,7 @@ def run(kind, n, h, w, cin, cout, pool, iters, warm=3):
         wt = rnd(9 * (cin + hid) * 4 * hid) * 0.02; b = rnd(4 * hid)
         ho = torch.empty(n, h, w, hid, device="cuda"); co = torch.empty(n, h, w, hid, device="cuda")
         fn = lambda: l.vad_convlstm_step(x.data_ptr(), 0, hp.data_ptr(), 0, cp.data_ptr(), wt.data_ptr(), b.data_ptr(),
-                                         ho.data_ptr(), 0, co.data_ptr(), n, h, w, cin, hid, s)
+                                         ho.data_ptr(), 0, co.data_ptr(), n, h, w, cin, hid, prec, s)
         flop = 2.0 * n * h * w * 9 * (cin + hid) * 4 * hid
         byts = 4.0 * (x.numel() + 4 * ho.numel())
     elif kind == "tail":
@@ -109,8 +109,6 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.variant >= 0:
         hip.lib().vad_debug_set_conv_variant(a.variant)
-    if a.precision:
-        hip.lib().vad_set_precision(a.precision)
     dbg = None
     if a.stamps:
         import ctypes
@@ -120,12 +118,12 @@ if __name__ == "__main__":
     if a.kind == "image":
         tot = 0.0
         for name, kind, h, cin, cout, pool in IMAGE_LAYERS:
-            ms, tf, gbs = run(kind, a.n, h, h, cin, cout, pool, a.iters)
+            ms, tf, gbs = run(kind, a.n, h, h, cin, cout, pool, a.iters, prec=a.precision)
             tot += ms
             print(f"{name:8s} {kind:8s} {ms * 1e3 / a.n:8.2f} us/frame  {tf:7.2f} TFLOP/s  {gbs:8.1f} GB/s")
         print(f"total {tot * 1e3 / a.n:.2f} us/frame -> {a.n / tot * 1e3:.0f} frames/s")
     else:
-        ms, tf, gbs = run(a.kind, a.n, a.h, a.w or a.h, a.cin, a.cout, a.pool, a.iters)
+        ms, tf, gbs = run(a.kind, a.n, a.h, a.w or a.h, a.cin, a.cout, a.pool, a.iters, prec=a.precision)
         print(f"{a.kind} n={a.n} {a.h}x{a.w or a.h} {a.cin}->{a.cout} pool={a.pool}: {ms:.4f} ms  {tf:.2f} TFLOP/s  {gbs:.1f} GB/s")
         if dbg is not None:
             d = dbg.cpu().numpy().reshape(-1, 12)

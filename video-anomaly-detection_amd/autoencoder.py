@@ -84,11 +84,19 @@ class _HipScorer:
     def __init__(self):
         self.key = None
         self.packed = None
+        self.mode = hip.PREC_FP32
         self.ws = None
 
     @staticmethod
     def state_key(module: nn.Module):
-        return tuple((t.data_ptr(), t._version, str(t.device)) for t in module.state_dict(keep_vars=True).values())
+        """(storage, version counter, device) of every state tensor.  In-place edits through `.data` / custom kernels do
+        not bump the counter (call `invalidate_packed()` after those); inference-mode tensors have no counter at all."""
+        def version(t):
+            try:
+                return t._version
+            except RuntimeError:          # tensors created under torch.inference_mode() do not track versions
+                return -1
+        return tuple((t.data_ptr(), version(t), str(t.device)) for t in module.state_dict(keep_vars=True).values())
 
     @staticmethod
     def float_params(module: nn.Module):
@@ -99,17 +107,6 @@ class _HipScorer:
                 continue
             out.append(np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy()))
         return out
-
-    @staticmethod
-    def set_precision(name: str) -> int:
-        """Select the library's arithmetic mode for the calls that follow (process-wide switch, see vad_hip.h)."""
-        modes = {"fp32": 0, "split": 1}
-        if name not in modes:
-            raise hip.VadError(f"precision must be one of {sorted(modes)}, got {name!r}")
-        l = hip.lib()
-        if l.vad_get_precision() != modes[name]:
-            hip.check(l.vad_set_precision(modes[name]), "vad_set_precision")
-        return modes[name]
 
     def workspace(self, nbytes: int, device) -> torch.Tensor:
         if self.ws is None or self.ws.numel() < nbytes or self.ws.device != device:
@@ -124,7 +121,7 @@ class ConvAutoencoder(nn.Module):
     #: several work-groups per resident slot
     chunk = 128
     #: "fp32" = exact fp32 MFMA (default, the parity path); "split" = 3 x fp16 MFMA with fp32 accumulate (opt-in,
-    #: 22-bit products; see include/vad_hip.h vad_set_precision)
+    #: 22-bit products; see include/vad_hip.h VAD_PREC_SPLIT).  Per model: the mode travels with every call as an argument
     precision = "fp32"
 
     def __init__(self, in_channels: int = 3, latent_dim: int = 256):
@@ -142,7 +139,7 @@ class ConvAutoencoder(nn.Module):
 
     def _packed(self, device) -> torch.Tensor:
         l = hip.lib()
-        mode = _HipScorer.set_precision(self.precision)
+        mode = hip.precision_mode(self.precision)
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_img_packed_floats(self.in_channels, self.latent_dim)
@@ -153,10 +150,22 @@ class ConvAutoencoder(nn.Module):
             params = _HipScorer.float_params(self)
             blob = np.empty(n, dtype=np.float32)
             hip.check(l.vad_img_pack(hip.pointer_array(params), len(params), self.in_channels,
-                                     self.latent_dim, blob.ctypes.data), "vad_img_pack")
+                                     self.latent_dim, mode, blob.ctypes.data), "vad_img_pack")
             self._hip.packed = torch.from_numpy(blob).to(device)
             self._hip.key = key
+            self._hip.mode = mode        # the mode this blob was packed for: passed to every launch that reads it
         return self._hip.packed
+
+    def invalidate_packed(self) -> None:
+        """Drop the packed-weight cache.  Needed only after edits the cache key cannot see: writes through `p.data`
+        (`p.data.copy_()`, EMA swaps), custom kernels writing into parameter storage.  `load_state_dict`, in-place ops on
+        the parameters and optimiser steps are detected by themselves; `train()` / `eval()` drop the cache too."""
+        self._hip.key = None
+
+    def train(self, mode: bool = True):
+        if mode != self.training:         # entering / leaving training: re-pack on the next scoring call
+            self._hip.key = None
+        return super().train(mode)
 
     def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False):
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,H,W,3]: normalised inside the kernels (row f-3)
@@ -190,7 +199,7 @@ class ConvAutoencoder(nn.Module):
         if latent:
             out["latent"] = torch.empty(b, self.latent_dim, h // 16, w // 16, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(l.vad_img_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, b, h, w,
+            hip.check(l.vad_img_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, h, w,
                                         self.latent_dim, packed.data_ptr(), ws.data_ptr(),
                                         ws.numel(), chunk, hip.ptr(out.get("scores")), hip.ptr(out.get("errmap")),
                                         hip.ptr(out.get("recon")), hip.ptr(out.get("latent")), hip.current_stream()),

@@ -18,6 +18,7 @@
 // (models/autoencoder.py:38-79,103-139; models/video_autoencoder.py:191-215), ConvLSTMCell
 // (models/video_autoencoder.py:54-85), nn.ConvTranspose2d(k2,s2)+BN+ReLU
 // (models/autoencoder.py:104-131; models/video_autoencoder.py:244-256).
+#include <atomic>
 #include <type_traits>
 #include "vad_common.h"
 
@@ -255,25 +256,29 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
 #include "conv_pkernel.h"
 #include "convt_pkernel.h"
 
-unsigned long long* g_vad_dbg = nullptr;
+// Developer A/B switches (vad_debug_*): written only by an explicit debug call, read once per launch; the library
+// itself never writes them, and the arithmetic mode is NOT among them (it is an argument of every entry point).
+static std::atomic<unsigned long long*> g_vad_dbg{nullptr};
 extern "C" int vad_debug_set_stamp_buffer(void* p) { g_vad_dbg = (unsigned long long*)p; return VAD_OK; }
-extern int g_vad_precision;   // pack.cpp: the weights were packed for this mode
-int g_vad_conv_variant = 1;   // 0: one tile per work-group, 1: persistent + register prefetch (default)
-int g_vad_conv_stagger = 0;
-int g_vad_conv64 = 0;
-extern "C" int vad_debug_set_conv_variant(int v) {
-    g_vad_conv_variant = v & 1; g_vad_conv_stagger = (v >> 1) & 1; g_vad_conv64 = (v >> 2) & 1;
-    return VAD_OK;
-}
+static std::atomic<int> g_vad_conv_bits{1};   // bit 0: 1 = persistent + register prefetch (default), 0 = one tile per work-group;
+                                              // bit 1: price the weight traffic (split kernels); bit 2: alternative cout-64 tiling
+extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 7; return VAD_OK; }
+struct ConvKnobs {
+    int variant, stagger, conv64;
+    ConvKnobs() { const int b = g_vad_conv_bits.load(std::memory_order_relaxed); variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; }
+};
+#define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, who ": precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision)
 
 template <typename K>
 static unsigned persistent_grid(K kernel, unsigned nblocks, int max_per_cu = 2) {
     int per_cu = 0, dev = 0;
-    static int ncu = 0;
+    static std::atomic<int> ncu_cached{0};
+    int ncu = ncu_cached.load(std::memory_order_relaxed);
     if (!ncu) {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
+        ncu_cached = ncu;
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     // Use EVERY resident slot the hardware offers: with fewer work-groups than slots the dispatcher packs some CUs
@@ -293,30 +298,34 @@ static unsigned persistent_grid_for(const Conv3P& p, unsigned cap) {
     return per_frame * fgroups;
 }
 
+// `variant`: 1 = persistent kernel, 0 = one tile per work-group (exact fp32 only); grid caps are per instantiation and
+// written once with the same value by whichever thread gets there first.
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT>
-static void launch_conv3_act(const Conv3P& p, hipStream_t s) {
-    if (g_vad_precision == 1) {   // split-fp16 operands (persistent kernel only)
-        static unsigned grid_cap1 = 0;
-        if (!grid_cap1) grid_cap1 = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>, ~0u);
+static void launch_conv3_act(const Conv3P& p, hipStream_t s, int precision, int variant, const ConvKnobs& kn) {
+    if (precision == VAD_PREC_SPLIT) {   // split-fp16 operands (persistent kernel only)
+        static std::atomic<unsigned> grid_cap1{0};
+        unsigned cap = grid_cap1.load(std::memory_order_relaxed);
+        if (!cap) grid_cap1 = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>, ~0u);
         Conv3P q = p;
         q.dbg = g_vad_dbg;
-        q.stagger = g_vad_conv_stagger;   // debug (variant bit 1): zero-sized weight descriptor = price the weight traffic
-        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>), dim3(persistent_grid_for(p, grid_cap1)), dim3(256), 0, s, q);
+        q.stagger = kn.stagger;   // debug (variant bit 1): zero-sized weight descriptor = price the weight traffic
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
         return;
     }
-    if (g_vad_conv_variant == 0) {
+    if (variant == 0) {
         hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(p.nblocks), dim3(256), 0, s, p);
     } else {
-        static unsigned grid_cap = 0;   // per instantiation
-        if (!grid_cap) grid_cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>, ~0u);
+        static std::atomic<unsigned> grid_cap{0};
+        unsigned cap = grid_cap.load(std::memory_order_relaxed);
+        if (!cap) grid_cap = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>, ~0u);
         Conv3P q = p;
         q.dbg = g_vad_dbg;
-        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(persistent_grid_for(p, grid_cap)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
     }
 }
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE>
-static int launch_conv3(Conv3P& p, int n, int act, hipStream_t s) {
+static int launch_conv3(Conv3P& p, int n, int act, hipStream_t s, int precision, int variant, const ConvKnobs& kn) {
     constexpr int TH = 2 * MT * WM;
     p.tiles_x = (p.w_ + 15) / 16;
     p.tiles_y = (p.h + TH - 1) / TH;
@@ -329,17 +338,19 @@ static int launch_conv3(Conv3P& p, int n, int act, hipStream_t s) {
     const long long chmax = p.cin > p.cout ? p.cin : p.cout;
     VAD_REQUIRE((long long)p.h * p.w_ * chmax * 4 < (1ll << 31) && 9ll * p.cin * p.cout * 4 < (1ll << 31),
                 "conv3x3: frame %dx%dx%lld or weights %dx%d too large for 32-bit offsets", p.h, p.w_, chmax, p.cin, p.cout);
-    if (MODE == MODE_LSTM || act == VAD_ACT_NONE) launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_NONE>(p, s);
-    else if (act == VAD_ACT_LEAKY) launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_LEAKY>(p, s);
-    else launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_RELU>(p, s);
+    if (MODE == MODE_LSTM || act == VAD_ACT_NONE) launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_NONE>(p, s, precision, variant, kn);
+    else if (act == VAD_ACT_LEAKY) launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_LEAKY>(p, s, precision, variant, kn);
+    else launch_conv3_act<CK, MT, NT, WM, WN, MODE, VAD_ACT_RELU>(p, s, precision, variant, kn);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
 
 extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, const float* bias,
                            float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
-                           int act, int pool, void* stream) {
+                           int act, int pool, int precision, void* stream) {
     VAD_REQUIRE(in && w && bias && out, "conv3x3: null pointer");
+    VAD_REQUIRE_PREC("conv3x3");
+    const ConvKnobs kn;
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "conv3x3: bad shape n=%d h=%d w=%d", n, h, wd);
     VAD_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
                 "conv3x3: cin=%d cout=%d must be positive multiples of 32", cin, cout);
@@ -353,48 +364,44 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
     p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
     p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.hid = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (g_vad_precision == 1) {
+#define L3(CK, MT, NT, WM, WN, MODE) launch_conv3<CK, MT, NT, WM, WN, MODE>(p, n, act, s, precision, kn.variant, kn)
+    if (precision == VAD_PREC_SPLIT) {
         // split-fp16 operands double the accumulators (main + cross terms): keep one N-tile per wave
-        if (cout % 128 == 0 && !g_vad_conv64)   // one B fragment per 4 M-tiles: halves the weight traffic through L1
-            return pool ? launch_conv3<32, 4, 1, 1, 4, MODE_POOL>(p, n, act, s)
-                        : launch_conv3<32, 4, 1, 1, 4, MODE_PLAIN>(p, n, act, s);
+        if (cout % 128 == 0 && !kn.conv64)   // one B fragment per 4 M-tiles: halves the weight traffic through L1
+            return pool ? L3(32, 4, 1, 1, 4, MODE_POOL) : L3(32, 4, 1, 1, 4, MODE_PLAIN);
         if (cout % 64 == 0)
-            return pool ? launch_conv3<32, 2, 1, 2, 2, MODE_POOL>(p, n, act, s)
-                        : launch_conv3<32, 2, 1, 2, 2, MODE_PLAIN>(p, n, act, s);
-        return pool ? launch_conv3<32, 2, 1, 4, 1, MODE_POOL>(p, n, act, s)
-                    : launch_conv3<32, 2, 1, 4, 1, MODE_PLAIN>(p, n, act, s);
+            return pool ? L3(32, 2, 1, 2, 2, MODE_POOL) : L3(32, 2, 1, 2, 2, MODE_PLAIN);
+        return pool ? L3(32, 2, 1, 4, 1, MODE_POOL) : L3(32, 2, 1, 4, 1, MODE_PLAIN);
     }
     if (cout % 128 == 0) {
         // Small grids (the per-step ConvLSTM gate convolutions of the training path: 16x16 maps, a few dozen frames): the
         // 8-row tile yields 8 work-groups per 16x16x512 frame, too few to fill 256 CUs twice; a 4-row tile doubles them
         // (same K order, identical results).  Measured at 32 clips: 24 -> see DESIGN.md section 9.
         const long long nb8 = (long long)n * ((wd + 15) / 16) * ((h + 7) / 8) * (cout / 128);
-        if (!pool && nb8 < 768) return launch_conv3<32, 1, 2, 2, 2, MODE_PLAIN>(p, n, act, s);
-        return pool ? launch_conv3<32, 2, 2, 2, 2, MODE_POOL>(p, n, act, s)
-                    : launch_conv3<32, 2, 2, 2, 2, MODE_PLAIN>(p, n, act, s);
+        if (!pool && nb8 < 768) return L3(32, 1, 2, 2, 2, MODE_PLAIN);
+        return pool ? L3(32, 2, 2, 2, 2, MODE_POOL) : L3(32, 2, 2, 2, 2, MODE_PLAIN);
     } else if (cout % 64 == 0) {
-        if (g_vad_conv64)
-            return pool ? launch_conv3<32, 2, 1, 2, 2, MODE_POOL>(p, n, act, s)
-                        : launch_conv3<32, 2, 1, 2, 2, MODE_PLAIN>(p, n, act, s);
-        return pool ? launch_conv3<32, 2, 2, 4, 1, MODE_POOL>(p, n, act, s)
-                    : launch_conv3<32, 2, 2, 4, 1, MODE_PLAIN>(p, n, act, s);
+        if (kn.conv64) return pool ? L3(32, 2, 1, 2, 2, MODE_POOL) : L3(32, 2, 1, 2, 2, MODE_PLAIN);
+        return pool ? L3(32, 2, 2, 4, 1, MODE_POOL) : L3(32, 2, 2, 4, 1, MODE_PLAIN);
     } else {
-        return pool ? launch_conv3<32, 2, 1, 4, 1, MODE_POOL>(p, n, act, s)
-                    : launch_conv3<32, 2, 1, 4, 1, MODE_PLAIN>(p, n, act, s);
+        return pool ? L3(32, 2, 1, 4, 1, MODE_POOL) : L3(32, 2, 1, 4, 1, MODE_PLAIN);
     }
+#undef L3
 }
 
 // Fused enc1: Conv2d(3->32)+BN+LeakyReLU -> Conv2d(32->32)+BN+LeakyReLU -> MaxPool2d(2,2)
 // (reference models/autoencoder.py:38-46) in one launch; x is NCHW [N,3,H,W], out NHWC [N,H/2,W/2,32].
 extern "C" int vad_conv3x3_c3_fused(const float* x, const float* w0, const float* b0, const float* w1,
-                                    const float* b1, float* out, int n, int h, int wd, void* stream) {
-    return vad_conv3x3_c3_fused_fmt(x, VAD_X_F32_NCHW, w0, b0, w1, b1, out, n, h, wd, stream);
+                                    const float* b1, float* out, int n, int h, int wd, int precision, void* stream) {
+    return vad_conv3x3_c3_fused_fmt(x, VAD_X_F32_NCHW, w0, b0, w1, b1, out, n, h, wd, precision, stream);
 }
 
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1,
-                             const float* b1, float* out, int n, int h, int wd, void* stream) {
+                             const float* b1, float* out, int n, int h, int wd, int precision, void* stream) {
     VAD_REQUIRE(x && w0 && b0 && w1 && b1 && out, "conv3x3_c3_fused: null pointer");
-    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || (fmt == VAD_X_U8_NHWC && (g_vad_conv_variant != 0 || g_vad_precision == 1)),
+    VAD_REQUIRE_PREC("conv3x3_c3_fused");
+    const ConvKnobs kn;
+    VAD_REQUIRE(fmt == VAD_X_F32_NCHW || (fmt == VAD_X_U8_NHWC && (kn.variant != 0 || precision == VAD_PREC_SPLIT)),
                 "conv3x3_c3_fused: input format %d unsupported (uint8 input needs the persistent kernel)", fmt);
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && h % 2 == 0 && wd % 2 == 0, "conv3x3_c3_fused: bad shape %dx%d", h, wd);
     Conv3P p{};
@@ -408,20 +415,22 @@ int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const floa
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3_fused: grid too large");
     p.nblocks = (unsigned)nb;
     p.n = n;
-    if (g_vad_precision == 1) {
-        static unsigned grid_cap1 = 0;
-        if (!grid_cap1) grid_cap1 = persistent_grid(conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1, 1>, ~0u);
+    if (precision == VAD_PREC_SPLIT) {
+        static std::atomic<unsigned> grid_cap1{0};
+        unsigned cap = grid_cap1.load(std::memory_order_relaxed);
+        if (!cap) grid_cap1 = cap = persistent_grid(conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1, 1>, ~0u);
         p.dbg = g_vad_dbg;
-        hipLaunchKernelGGL((conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1, 1>), dim3(persistent_grid_for(p, grid_cap1)), dim3(256), 0,
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1, 1>), dim3(persistent_grid_for(p, cap)), dim3(256), 0,
                            (hipStream_t)stream, p);
-    } else if (g_vad_conv_variant == 0) {
+    } else if (kn.variant == 0) {
         hipLaunchKernelGGL((conv3x3_mfma_kernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>), dim3((unsigned)nb), dim3(256), 0,
                            (hipStream_t)stream, p);
     } else {
-        static unsigned grid_cap = 0;
-        if (!grid_cap) grid_cap = persistent_grid(conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>, ~0u, g_vad_conv64 ? 3 : 2);
+        static std::atomic<unsigned> grid_cap{0};
+        unsigned cap = grid_cap.load(std::memory_order_relaxed);
+        if (!cap) grid_cap = cap = persistent_grid(conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>, ~0u);
         p.dbg = g_vad_dbg;
-        hipLaunchKernelGGL((conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>), dim3(persistent_grid_for(p, grid_cap)), dim3(256), 0,
+        hipLaunchKernelGGL((conv3x3_mfma_pkernel<32, 2, 1, 4, 1, MODE_POOL, VAD_ACT_LEAKY, 1>), dim3(persistent_grid_for(p, cap)), dim3(256), 0,
                            (hipStream_t)stream, p);
     }
     VAD_LAUNCH_CHECK();
@@ -430,8 +439,9 @@ int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const floa
 
 extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_prev, long long h_prev_fs, const float* c_prev,
                                  const float* w, const float* bias, float* h_out, long long h_out_fs,
-                                 float* c_out, int n, int h, int wd, int cin_x, int hid, void* stream) {
+                                 float* c_out, int n, int h, int wd, int cin_x, int hid, int precision, void* stream) {
     VAD_REQUIRE(x && w && bias && h_out && c_out, "convlstm_step: null pointer");
+    VAD_REQUIRE_PREC("convlstm_step");
     VAD_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), "convlstm_step: h_prev and c_prev must both be given or both NULL");
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "convlstm_step: bad shape");
     VAD_REQUIRE(cin_x % 32 == 0 && hid % 64 == 0 && cin_x > 0 && hid > 0,
@@ -444,12 +454,9 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
     p.c_prev = c_prev; p.c_out = c_out;
     p.h = h; p.w_ = wd; p.cin = cin_x + hid; p.cout = 4 * hid; p.hid = hid;
     // the persistent kernel shares one set of staging offsets between x and h: needs cin_x == hid
-    VAD_REQUIRE(!(g_vad_precision == 1 && cin_x != hid), "convlstm_step: split precision needs cin_x == hid (got %d, %d)", cin_x, hid);
-    const int saved = g_vad_conv_variant;
-    if (cin_x != hid) g_vad_conv_variant = 0;
-    const int rc = launch_conv3<32, 1, 4, 2, 2, MODE_LSTM>(p, n, VAD_ACT_NONE, (hipStream_t)stream);
-    g_vad_conv_variant = saved;
-    return rc;
+    VAD_REQUIRE(!(precision == VAD_PREC_SPLIT && cin_x != hid), "convlstm_step: split precision needs cin_x == hid (got %d, %d)", cin_x, hid);
+    const ConvKnobs kn;
+    return launch_conv3<32, 1, 4, 2, 2, MODE_LSTM>(p, n, VAD_ACT_NONE, (hipStream_t)stream, precision, cin_x != hid ? 0 : kn.variant, kn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -665,17 +672,19 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
     VAD_REQUIRE(!pool || (h % 2 == 0 && wd % 2 == 0), "conv3x3_c3: pooling needs even H,W");
     VAD_REQUIRE(act == VAD_ACT_LEAKY || act == VAD_ACT_RELU || act == VAD_ACT_NONE, "conv3x3_c3: bad act");
     hipStream_t s = (hipStream_t)stream;
+    const ConvKnobs kn;
     // persistent kernel (tiles of 32 rows x 16 columns) for the pooled form; the un-pooled form (training forward) writes
     // 8.4 MB per 256x256 frame and is faster with many small work-groups in flight (measured 4.0 vs 6.5 us/frame)
-    if (g_vad_conv_variant != 0 && pool) {
+    if (kn.variant != 0 && pool) {
         ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 31) / 32, 0, fmt == VAD_X_U8_NHWC};
         const long long nb = (long long)n * p.tiles_x * p.tiles_y;
         VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");
         p.nblocks = (unsigned)nb;
 #define C3P_LAUNCH(POOL, ACT)                                                                              \
     {                                                                                                      \
-        static unsigned cap = 0;                                                                           \
-        if (!cap) cap = persistent_grid(conv3x3_c3_pkernel<POOL, ACT>, ~0u);                               \
+        static std::atomic<unsigned> cap_{0};                                                              \
+        unsigned cap = cap_.load(std::memory_order_relaxed);                                               \
+        if (!cap) cap_ = cap = persistent_grid(conv3x3_c3_pkernel<POOL, ACT>, ~0u);                        \
         hipLaunchKernelGGL((conv3x3_c3_pkernel<POOL, ACT>), dim3(p.nblocks < cap ? p.nblocks : cap), dim3(256), 0, s, p); \
     }
         if (pool) {
@@ -851,8 +860,10 @@ static int launch_convt(ConvTP& p, int act, hipStream_t s) {
 
 extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, const float* bias,
                             float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
-                            int act, void* stream) {
+                            int act, int precision, void* stream) {
     VAD_REQUIRE(in && w && bias && out, "convt2x2: null pointer");
+    VAD_REQUIRE_PREC("convt2x2");
+    const ConvKnobs kn;
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "convt2x2: bad shape");
     VAD_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
                 "convt2x2: cin=%d cout=%d must be positive multiples of 32", cin, cout);
@@ -862,14 +873,14 @@ extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, co
     p.w = w; p.bias = bias; p.out = out;
     p.out_fs = out_fs ? out_fs : (long long)4 * h * wd * cout;
     p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.npix = (long long)n * h * wd;
-    if (g_vad_conv_variant == 0 && g_vad_precision == 0) return launch_convt<1>(p, act, (hipStream_t)stream);
+    if (kn.variant == 0 && precision == VAD_PREC_FP32) return launch_convt<1>(p, act, (hipStream_t)stream);
     // wave-persistent LDS-free kernel (convt_pkernel.h): 32-bit offsets inside one frame
     VAD_REQUIRE(4ll * h * wd * cout * 4 < (1ll << 31) && (long long)h * wd * cin * 4 < (1ll << 31) && 4ll * cin * cout * 4 < (1ll << 31),
                 "convt2x2: frame %dx%d (cin %d, cout %d) too large for 32-bit offsets", h, wd, cin, cout);
     ConvTP2 q{};
     q.in = p.in; q.in_fs = p.in_fs; q.w = w; q.bias = bias; q.out = out; q.out_fs = p.out_fs;
     q.n = n; q.h = h; q.w_ = wd; q.cin = cin; q.cout = cout;
-    const int prec = g_vad_precision == 1;           // split-fp16 operands: two accumulator sets, so half the columns per wave
+    const int prec = precision == VAD_PREC_SPLIT;    // split-fp16 operands: two accumulator sets, so half the columns per wave
     // wave tile 2 x 4 (exact) measured best of {2x4, 1x4, 2x2, 1x2}: dec4.0 2.18 / 2.47 / 2.28 / 2.78 us per frame
     const int mt = 2, nt = prec ? 2 : 4;
     q.tiles_x = (wd + 15) / 16; q.tiles_y = (h + 2 * mt - 1) / (2 * mt);
@@ -880,8 +891,9 @@ extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, co
     const unsigned want = (unsigned)((items + 3) / 4);
 #define CT_LAUNCH_(A, MT_, NT_, P)                                                                           \
     {                                                                                                        \
-        static unsigned cap = 0;                                                                             \
-        if (!cap) cap = persistent_grid(convt2x2_pkernel<MT_, NT_, A, P>, ~0u);                              \
+        static std::atomic<unsigned> cap_{0};                                                                \
+        unsigned cap = cap_.load(std::memory_order_relaxed);                                                 \
+        if (!cap) cap_ = cap = persistent_grid(convt2x2_pkernel<MT_, NT_, A, P>, ~0u);                       \
         hipLaunchKernelGGL((convt2x2_pkernel<MT_, NT_, A, P>), dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, q); \
     }
 #define CT_LAUNCH(A)                                                                                         \

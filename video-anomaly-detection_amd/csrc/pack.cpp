@@ -41,13 +41,8 @@ static void bn_scale_shift(const float* bias, const float* const* bn, int cout,
     }
 }
 
-int g_vad_precision = 0;   // 0: exact fp32 MFMA; 1: split-fp16 (3 x fp16 MFMA, fp32 accumulate) for the 3x3 and transposed convolutions
-extern "C" int vad_set_precision(int mode) {
-    REQ(mode == 0 || mode == 1, "set_precision: mode must be 0 (fp32) or 1 (split fp16)");
-    g_vad_precision = mode;
-    return VAD_OK;
-}
-extern "C" int vad_get_precision(void) { return g_vad_precision; }
+// The arithmetic mode is an ARGUMENT of every packer and launcher (ABI 2): there is no process-wide switch.
+#define REQ_PREC(who) REQ(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, who ": precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision)
 
 extern "C" size_t vad_pack_conv3x3_floats(int cout, int cin) { return (size_t)9 * ((cin + 7) / 8) * cout * 8; }
 
@@ -69,13 +64,15 @@ static void pack_conv3x3_split(const float* w, const std::vector<double>& s, int
 }
 
 extern "C" int vad_pack_conv3x3(const float* w, const float* bias, const float* const* bn,
-                                int cout, int cin, float* out, float* bias_out) {
+                                int cout, int cin, int precision, float* out, float* bias_out) {
     REQ(w && out && bias_out && cout > 0 && cin > 0, "pack_conv3x3: bad arguments");
+    REQ_PREC("pack_conv3x3");
+    REQ(precision != VAD_PREC_SPLIT || cin % 16 == 0, "pack_conv3x3: split precision needs cin %% 16 == 0 (got %d)", cin);
     std::vector<double> s;
     bn_scale_shift(bias, bn, cout, s, bias_out);
     const int c8n = (cin + 7) / 8;
     memset(out, 0, vad_pack_conv3x3_floats(cout, cin) * sizeof(float));
-    if (g_vad_precision == 1 && cin % 16 == 0) {
+    if (precision == VAD_PREC_SPLIT) {
         pack_conv3x3_split(w, s, cout, cin, out);
         return VAD_OK;
     }
@@ -114,11 +111,13 @@ extern "C" int vad_pack_conv3x3_c3(const float* w, const float* bias, const floa
 extern "C" size_t vad_pack_convt2x2_floats(int cin, int cout) { return (size_t)4 * (cin / 8) * cout * 8; }
 
 extern "C" int vad_pack_convt2x2(const float* w, const float* bias, const float* const* bn,
-                                 int cin, int cout, float* out, float* bias_out) {
+                                 int cin, int cout, int precision, float* out, float* bias_out) {
     REQ(w && out && bias_out && cout > 0 && cin > 0 && cin % 8 == 0, "pack_convt2x2: bad arguments");
+    REQ_PREC("pack_convt2x2");
+    REQ(precision != VAD_PREC_SPLIT || cin % 16 == 0, "pack_convt2x2: split precision needs cin %% 16 == 0 (got %d)", cin);
     std::vector<double> s;
     bn_scale_shift(bias, bn, cout, s, bias_out);
-    if (g_vad_precision == 1 && cin % 16 == 0) {   // split-fp16 operands: [q][cin/16][cout][half h][8 x hi | 8 x lo]
+    if (precision == VAD_PREC_SPLIT) {   // split-fp16 operands: [q][cin/16][cout][half h][8 x hi | 8 x lo]
         _Float16* o = (_Float16*)out;
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co)
@@ -166,10 +165,27 @@ extern "C" int vad_pack_conv3x3_to3(const float* w, int cin, float* out) {
 // --------------------------------------------------------------------------- image autoencoder
 static size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
+// Every model blob starts with a 4-word header {magic, tag, dim0, dim1} (uint32 bit patterns in the float array): the tag
+// names the model kind and the arithmetic mode the operands were packed for.  The score entry points take the mode as an
+// argument; the kernel that finalises the scores compares it with the tag ON THE DEVICE and writes NaN scores on a
+// mismatch, so a blob launched under the wrong mode cannot pass as a result.
+static void put_header(float* out, int kind, int precision, int d0, int d1) {
+    const unsigned h[4] = {VAD_BLOB_MAGIC, vad_blob_tag(kind, precision), (unsigned)d0, (unsigned)d1};
+    memcpy(out, h, sizeof h);
+}
+
+extern "C" int vad_blob_precision(const float* packed_host) {
+    if (!packed_host) return vad_fail(VAD_ERR_ARG, "blob_precision: null pointer");
+    unsigned h[2];
+    memcpy(h, packed_host, sizeof h);
+    if (h[0] != VAD_BLOB_MAGIC || (h[1] >> 16) != VAD_ABI_VERSION) return vad_fail(VAD_ERR_ARG, "blob_precision: not a packed model blob of ABI %d", VAD_ABI_VERSION);
+    return (int)((h[1] >> 8) & 0xff);
+}
+
 ImgLayout img_layout(int latent) {
     ImgLayout L{};
     const int ch[5] = {3, 32, 64, 128, latent};
-    size_t off = 0;
+    size_t off = VAD_BLOB_HEADER_FLOATS;
     int li = 0;
     auto add = [&](int kind, int cin, int cout, size_t wfloats) {
         LayerSlot& s = L.layer[li++];
@@ -198,14 +214,16 @@ extern "C" size_t vad_img_packed_floats(int in_ch, int latent) {
     return img_layout(latent).total;
 }
 
-extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int latent, float* out) {
+extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int latent, int precision, float* out) {
     REQ(P && out, "img_pack: null pointer");
+    REQ_PREC("img_pack");
     REQ(in_ch == 3, "img_pack: in_channels=%d unsupported (every reference call site uses 3)", in_ch);
     REQ(latent > 0 && latent % 32 == 0, "img_pack: latent_dim=%d must be a positive multiple of 32", latent);
     REQ(nparams == VAD_IMG_NPARAMS, "img_pack: expected %d parameter tensors, got %d", VAD_IMG_NPARAMS, nparams);
     for (int i = 0; i < nparams; ++i) REQ(P[i], "img_pack: parameter %d is NULL", i);
     const ImgLayout L = img_layout(latent);
     memset(out, 0, L.total * sizeof(float));
+    put_header(out, VAD_BLOB_IMG, precision, latent, 0);
     int pi = 0, rc = VAD_OK;
     for (int li = 0; li < L.nlayers && rc == VAD_OK; ++li) {
         const LayerSlot& s = L.layer[li];
@@ -218,8 +236,8 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
         }
         const float* bn[4] = {P[pi + 2], P[pi + 3], P[pi + 4], P[pi + 5]};
         if (s.kind == LK_CONV_C3) rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b);
-        else if (s.kind == LK_CONV) rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, out + s.w, out + s.b);
-        else rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, out + s.w, out + s.b);
+        else if (s.kind == LK_CONV) rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, precision, out + s.w, out + s.b);
+        else rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, precision, out + s.w, out + s.b);
         pi += 6;
     }
     if (rc == VAD_OK && pi != nparams) return vad_fail(VAD_ERR_ARG, "img_pack: consumed %d of %d parameters", pi, nparams);
@@ -229,7 +247,7 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
 // --------------------------------------------------------------------------- video autoencoder
 VidLayout vid_layout(int latent, int hid, int layers) {
     VidLayout L{};
-    size_t off = 0;
+    size_t off = VAD_BLOB_HEADER_FLOATS;
     int li = 0;
     auto add = [&](int kind, int cin, int cout, size_t wfloats) {
         LayerSlot& s = L.layer[li++];
@@ -270,8 +288,9 @@ extern "C" size_t vad_vid_packed_floats(int latent, int hid, int layers) {
     return vid_layout(latent, hid, layers).total;
 }
 
-extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int hid, int layers, float* out) {
+extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int hid, int layers, int precision, float* out) {
     REQ(P && out, "vid_pack: null pointer");
+    REQ_PREC("vid_pack");
     int rc = vid_dims_ok(latent, hid, layers);
     if (rc != VAD_OK) return rc;
     const VidLayout L = vid_layout(latent, hid, layers);
@@ -279,6 +298,7 @@ extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int 
         vad_vid_nparams(layers, L.has_proj), nparams);
     for (int i = 0; i < nparams; ++i) REQ(P[i], "vid_pack: parameter %d is NULL", i);
     memset(out, 0, L.total * sizeof(float));
+    put_header(out, VAD_BLOB_VID, precision, latent, hid | (layers << 16));
     int pi = 0;
     for (int li = 0; li < L.nlayers && rc == VAD_OK; ++li) {
         const LayerSlot& s = L.layer[li];
@@ -288,10 +308,10 @@ extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int 
         case LK_CONV_C3: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
             rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b); pi += 6; break;
         case LK_CONV: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
-            rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, out + s.w, out + s.b); pi += 6; break;
+            rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 6; break;
         case LK_CONVT: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
-            rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, out + s.w, out + s.b); pi += 6; break;
-        case LK_LSTM: rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break;
+            rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, precision, out + s.w, out + s.b); pi += 6; break;
+        case LK_LSTM: rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 2; break;
         case LK_PROJ: rc = vad_pack_conv1x1(w, b, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break;
         case LK_TAIL_CONVT:
             memcpy(out + s.w, w, (size_t)32 * 12 * sizeof(float));

@@ -255,15 +255,19 @@ __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
 
 // One 64-lane block per clip (t frames): lane l adds partials l, l+64, ... in order, then the
 // wave butterfly; the result depends only on (frame data, tile grid), never on batch or rank.
+// hdr / want: header of the packed model blob and the tag the launch was made for (vad_layout.h); a blob packed for
+// another arithmetic mode or model kind turns every score into NaN instead of a plausible-looking number.
 __global__ __launch_bounds__(64) void score_finalize_kernel(const float* partials, int nparts, float denom,
-                                                            float* frame_scores, float* seq_scores, int t) {
+                                                            float* frame_scores, float* seq_scores, int t,
+                                                            const unsigned* hdr, unsigned want) {
     const int clip = blockIdx.x, lane = threadIdx.x;
+    const float poison = (hdr && hdr[1] != want) ? __builtin_nanf("") : 0.f;
     float seq = 0.f;
     for (int f = 0; f < t; ++f) {
         const float* pp = partials + ((size_t)clip * t + f) * nparts;
         float s = 0.f;
         for (int i = lane; i < nparts; i += 64) s += pp[i];
-        s = wave_sum(s) / denom;
+        s = wave_sum(s) / denom + poison;
         if (lane == 0 && frame_scores) frame_scores[(size_t)clip * t + f] = s;
         seq += s;
     }
@@ -320,11 +324,16 @@ int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float
 
 extern "C" int vad_score_finalize(const float* partials, int nparts, int n, int h2, int w2,
                                   float* frame_scores, float* seq_scores, int t, void* stream) {
+    return vad_score_finalize_tagged(partials, nparts, n, h2, w2, frame_scores, seq_scores, t, nullptr, 0u, stream);
+}
+
+int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, float* frame_scores,
+                              float* seq_scores, int t, const unsigned* hdr, unsigned want_tag, void* stream) {
     VAD_REQUIRE(partials && nparts > 0 && n > 0 && t > 0 && n % t == 0, "score_finalize: bad arguments");
     VAD_REQUIRE(frame_scores || seq_scores, "score_finalize: no output requested");
     const float denom = 3.0f * (float)h2 * (float)w2;
     hipLaunchKernelGGL(score_finalize_kernel, dim3(n / t), dim3(64), 0, (hipStream_t)stream,
-                       partials, nparts, denom, frame_scores, seq_scores, t);
+                       partials, nparts, denom, frame_scores, seq_scores, t, hdr, want_tag);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

@@ -1026,18 +1026,20 @@ extern "C" int vad_adam_step(float* p, const float* g, float* m, float* v, long 
     return VAD_OK;
 }
 
-extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream) {
+extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv3x3: bad arguments");
-    const int split = vad_get_precision() == 1;       // the packed layout follows the arithmetic mode, like the host packers
+    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "train_pack_conv3x3: precision=%d must be 0 (fp32) or 1 (split fp16)", precision);
+    const int split = precision == VAD_PREC_SPLIT;    // the packed layout follows the arithmetic mode, like the host packers
     VAD_REQUIRE(!split || (cin % 16 == 0 && (!dgrad || cout % 16 == 0)), "train_pack_conv3x3: split precision needs channel counts in multiples of 16");
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(9ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad, split);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
 
-extern "C" int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, void* stream) {
+extern "C" int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_iohw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || (4 * cout) % 8 == 0), "train_pack_convt2x2: bad arguments");
-    const int split = vad_get_precision() == 1;
+    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "train_pack_convt2x2: precision=%d must be 0 (fp32) or 1 (split fp16)", precision);
+    const int split = precision == VAD_PREC_SPLIT;
     VAD_REQUIRE(!split || cin % 16 == 0, "train_pack_convt2x2: split precision needs cin in multiples of 16");
     hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad, split);
     VAD_LAUNCH_CHECK();

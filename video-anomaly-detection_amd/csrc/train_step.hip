@@ -219,9 +219,10 @@ extern "C" int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent
 
 extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent, int hid, int layers,
                                      const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
-                                     float* loss, float* recon, void* stream) {
+                                     int precision, float* loss, float* recon, void* stream) {
     VAD_REQUIRE(x && params && grads && workspace && loss, "vid_train_fwd_bwd: null pointer");
-    // Arithmetic mode (vad_set_precision): 0 = exact fp32 everywhere (the parity path); 1 = the 3x3 and transposed
+    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "vid_train_fwd_bwd: precision=%d must be 0 (fp32) or 1 (split fp16)", precision);
+    // Arithmetic mode (argument `precision`): 0 = exact fp32 everywhere (the parity path); 1 = the 3x3 and transposed
     // convolutions (forward and data gradients) take split-fp16 operands (22-bit products, fp32 accumulate), everything
     // else - first layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam - stays fp32.
     Plan p;
@@ -242,11 +243,11 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     // ---- operand packing of the current parameters
     TRY(vad_train_pack_conv3x3_c3(P + p.e_w[0], 32, ws + p.pk_e[0], s));
     for (int k = 1; k < 4; ++k)
-        TRY(vad_train_pack_conv3x3(P + p.e_w[k], p.encC[k + 1], p.encC[k], ws + p.pk_e[k], ws + p.pk_e_dg[k], s));
+        TRY(vad_train_pack_conv3x3(P + p.e_w[k], p.encC[k + 1], p.encC[k], ws + p.pk_e[k], ws + p.pk_e_dg[k], precision, s));
     for (int l = 0; l < NL; ++l)
-        TRY(vad_train_pack_conv3x3(P + p.l_w[l], 4 * Hd, p.lstm_cin(l) + Hd, ws + p.pk_l[l], ws + p.pk_l_dg[l], s));
+        TRY(vad_train_pack_conv3x3(P + p.l_w[l], 4 * Hd, p.lstm_cin(l) + Hd, ws + p.pk_l[l], ws + p.pk_l_dg[l], precision, s));
     for (int j = 0; j < 3; ++j)
-        TRY(vad_train_pack_convt2x2(P + p.d_w[j], p.decC[j], p.decC[j + 1], ws + p.pk_d[j], ws + p.pk_d_dg[j], s));
+        TRY(vad_train_pack_convt2x2(P + p.d_w[j], p.decC[j], p.decC[j + 1], ws + p.pk_d[j], ws + p.pk_d_dg[j], precision, s));
     if (p.proj) TRY(vad_train_pack_conv1x1(P + p.pj_w, L, Hd, ws + p.pk_pj, ws + p.pk_pj_dg, s));
 
     // ================================================================================== forward
@@ -255,7 +256,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         float* y = ws + p.y[k];
         if (k == 0) TRY(vad_conv3x3_c3(x, ws + p.pk_e[0], P + p.e_b[0], y, N, hk, wk, co, VAD_ACT_NONE, 0, s));
-        else TRY(vad_conv3x3(ws + p.a[k - 1], 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, s));
+        else TRY(vad_conv3x3(ws + p.a[k - 1], 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, s));
         float* rs = running ? running + p.e_rs[k] : nullptr;
         TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
         if (k < 3)
@@ -272,7 +273,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         for (int tt = 0; tt < T; ++tt) {
             float* zt = ws + p.z[l] + (size_t)tt * B * hw * 4 * Hd;
             float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
-            TRY(vad_conv3x3(ws + p.cat[l] + tt * slab, 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, s));
+            TRY(vad_conv3x3(ws + p.cat[l] + tt * slab, 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, precision, s));
             float* h1 = tt + 1 < T ? ws + p.cat[l] + (tt + 1) * slab + cx : nullptr;
             float* h2; long long h2_fs; int h2_ps;
             if (l + 1 < NL) { h2 = ws + p.cat[l + 1] + (size_t)tt * B * hw * 2 * Hd; h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
@@ -291,7 +292,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
         const float* in = j == 0 ? dec_in : ws + p.r[j - 1];
         float* u = ws + p.u[j];
-        TRY(vad_convt2x2(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, s));
+        TRY(vad_convt2x2(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, precision, s));
         float* rs = running ? running + p.d_rs[j] : nullptr;
         TRY(vad_bn_stats(u, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
         TRY(vad_bn_act_pool_fwd(u, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], ws + p.r[j], 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
@@ -340,7 +341,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
             const float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
             TRY(vad_lstm_gates_bwd(ws + p.z[l] + (size_t)tt * B * hw * 4 * Hd, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
                                    dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s));
-            TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, ws + p.dcat[l] + tt * slab, 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, s));
+            TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, ws + p.dcat[l] + tt * slab, 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, precision, s));
         }
         // weight / bias gradients of the cell's convolution over all steps at once (frames = T*B)
         TRY(vad_conv_wgrad(ws + p.cat[l], ws + p.dzl[l], G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, s));
@@ -361,7 +362,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
             TRY(vad_conv_c3_wgrad(x, g2, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
         } else {
             TRY(vad_conv_wgrad(ws + p.a[k - 1], g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, s));
-            TRY(vad_conv3x3(g2, 0, ws + p.pk_e_dg[k], zeros, g0, 0, N, hk, wk, co, ci, VAD_ACT_NONE, 0, s));
+            TRY(vad_conv3x3(g2, 0, ws + p.pk_e_dg[k], zeros, g0, 0, N, hk, wk, co, ci, VAD_ACT_NONE, 0, precision, s));
         }
     }
     return VAD_OK;

@@ -4,19 +4,24 @@
 // Launch order follows ConvAutoencoder.forward / get_reconstruction_error
 // (reference models/autoencoder.py:181-221) and VideoAutoencoder.forward /
 // get_reconstruction_error (reference models/video_autoencoder.py:329-384).
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include "vad_common.h"
 #include "vad_layout.h"
 
 // ------------------------------------------------------------------------------ profiling
+// The record list and the event pool are shared by every thread that scores while profiling is on: one mutex guards
+// them, and a scope keeps its OWN end event (another thread may append records between its two ends).
 namespace {
 struct ProfRec { int slot; hipEvent_t a, b; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
 std::vector<ProfRec> g_recs;      // records since the last reset
 std::vector<hipEvent_t> g_pool;   // recycled events
 size_t g_pool_used = 0;
 
-hipEvent_t prof_event() {
+hipEvent_t prof_event() {         // g_prof_mu held
     if (g_pool_used == g_pool.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
@@ -26,23 +31,33 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
-VadProfScope::VadProfScope(int slot_, hipStream_t stream_) : slot(-1), stream(stream_) {
-    if (!g_prof_on) return;
-    hipEvent_t a = prof_event(), b = prof_event();
-    if (!a || !b) return;
+VadProfScope::VadProfScope(int slot_, hipStream_t stream_) : slot(-1), stream(stream_), end(nullptr) {
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    hipEvent_t a, b;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        a = prof_event(); b = prof_event();
+        if (!a || !b) return;
+        g_recs.push_back({slot_, a, b});
+    }
     slot = slot_;
-    g_recs.push_back({slot_, a, b});
+    end = b;
     (void)hipEventRecord(a, stream);
 }
 VadProfScope::~VadProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_recs.back().b, stream);
+    if (slot >= 0) (void)hipEventRecord(end, stream);
 }
 
 extern "C" int vad_prof_enable(int on) { g_prof_on = on != 0; return VAD_OK; }
-extern "C" int vad_prof_reset(void) { g_recs.clear(); g_pool_used = 0; return VAD_OK; }
+extern "C" int vad_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_recs.clear(); g_pool_used = 0;
+    return VAD_OK;
+}
 extern "C" int vad_prof_read(float* ms, int* launches) {
     VAD_REQUIRE(ms && launches, "prof_read: null pointer");
     for (int i = 0; i < VAD_PROF_SLOTS; ++i) { ms[i] = 0.f; launches[i] = 0; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (const ProfRec& r : g_recs) {
         VAD_HIP_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
@@ -65,8 +80,9 @@ extern "C" const char* vad_prof_slot_name(int model, int slot) {
 
 #define TRY(call) do { int rc_ = (call); if (rc_ != VAD_OK) return rc_; } while (0)
 
-int g_vad_tail_group = 0;   // frames per dec4.0 -> tail sub-group (0 = the whole launch group)
+static std::atomic<int> g_vad_tail_group{0};   // debug: frames per dec4.0 -> tail sub-group (0 = the whole launch group)
 extern "C" int vad_debug_set_tail_group(int frames) { g_vad_tail_group = frames; return VAD_OK; }
+#define REQ_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, who ": precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision)
 
 static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -87,14 +103,15 @@ extern "C" size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent) {
 extern "C" int vad_img_score(const float* x, long long b, int h, int w, int latent, const float* packed,
                              void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
                              float* recon, float* latent_out, void* stream) {
-    return vad_img_score_x(x, VAD_X_F32_NCHW, b, h, w, latent, packed, ws, ws_bytes, chunk, scores, errmap, recon,
+    return vad_img_score_x(x, VAD_X_F32_NCHW, VAD_PREC_FP32, b, h, w, latent, packed, ws, ws_bytes, chunk, scores, errmap, recon,
                            latent_out, stream);
 }
 
-extern "C" int vad_img_score_x(const void* xv, int x_format, long long b, int h, int w, int latent, const float* packed,
-                               void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
+extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long long b, int h, int w, int latent,
+                               const float* packed, void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
                                float* recon, float* latent_out, void* stream) {
     VAD_REQUIRE(xv && packed && ws, "img_score: null pointer");
+    REQ_PREC("img_score");
     VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "img_score: unknown input format %d", x_format);
     const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
     const char* x = (const char*)xv;
@@ -125,13 +142,13 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, long long b, int h,
         const char* xin = x + (size_t)f0 * 3 * h * w * xelem;
         int hh = h, ww = w;
         // encoder: 4 x [conv-BN-LeakyReLU, conv-BN-LeakyReLU-MaxPool] (models/autoencoder.py:38-79)
-        { VadProfScope ps(1, s); TRY(vad_conv3x3_c3_fused_fmt(xin, x_format, W_(0), B_(0), W_(1), B_(1), B, n, hh, ww, s)); }
+        { VadProfScope ps(1, s); TRY(vad_conv3x3_c3_fused_fmt(xin, x_format, W_(0), B_(0), W_(1), B_(1), B, n, hh, ww, precision, s)); }
         for (int blk = 1; blk < 4; ++blk) {
             hh /= 2; ww /= 2;
             { VadProfScope ps(2 * blk, s);
-              TRY(vad_conv3x3(B, 0, W_(2 * blk), B_(2 * blk), A, 0, n, hh, ww, ch[blk], ch[blk + 1], VAD_ACT_LEAKY, 0, s)); }
+              TRY(vad_conv3x3(B, 0, W_(2 * blk), B_(2 * blk), A, 0, n, hh, ww, ch[blk], ch[blk + 1], VAD_ACT_LEAKY, 0, precision, s)); }
             { VadProfScope ps(2 * blk + 1, s);
-              TRY(vad_conv3x3(A, 0, W_(2 * blk + 1), B_(2 * blk + 1), B, 0, n, hh, ww, ch[blk + 1], ch[blk + 1], VAD_ACT_LEAKY, 1, s)); }
+              TRY(vad_conv3x3(A, 0, W_(2 * blk + 1), B_(2 * blk + 1), B, 0, n, hh, ww, ch[blk + 1], ch[blk + 1], VAD_ACT_LEAKY, 1, precision, s)); }
         }
         hh /= 2; ww /= 2;   // B = latent code [n, H/16, W/16, latent]
         if (latent_out) {
@@ -142,20 +159,21 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, long long b, int h,
         // decoder: 3 x [convT-BN-ReLU, conv-BN-ReLU] + [convT-BN-ReLU, conv-Tanh] (models/autoencoder.py:103-139)
         for (int blk = 0; blk < 3; ++blk) {
             { VadProfScope ps(8 + 2 * blk, s);
-              TRY(vad_convt2x2(B, 0, W_(8 + 2 * blk), B_(8 + 2 * blk), A, 0, n, hh, ww, dch[blk], dch[blk + 1], VAD_ACT_RELU, s)); }
+              TRY(vad_convt2x2(B, 0, W_(8 + 2 * blk), B_(8 + 2 * blk), A, 0, n, hh, ww, dch[blk], dch[blk + 1], VAD_ACT_RELU, precision, s)); }
             hh *= 2; ww *= 2;
             { VadProfScope ps(9 + 2 * blk, s);
-              TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, s)); }
+              TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, precision, s)); }
         }
         // dec4.0 (convT 32->32, writes 8.4 MB per 256x256 frame) and the scoring tail that reads it back can run in
         // sub-groups (vad_debug_set_tail_group) so that map stays in the 256 MiB Infinity Cache; measured on MI355X
         // this does NOT pay (15.2 k frames/s whole group vs 14.9 k at 16 frames), so the default is the whole group.
         const size_t in_f = (size_t)hh * ww * 32;
-        const int sub = g_vad_tail_group > 0 ? g_vad_tail_group : n;
+        const int tg = g_vad_tail_group.load(std::memory_order_relaxed);
+        const int sub = tg > 0 ? tg : n;
         for (int f1 = 0; f1 < n; f1 += sub) {
             const int m = (n - f1 < sub) ? (n - f1) : sub;
             { VadProfScope ps(14, s);
-              TRY(vad_convt2x2(B + (size_t)f1 * in_f, 0, W_(14), B_(14), A, 0, m, hh, ww, 32, 32, VAD_ACT_RELU, s)); }
+              TRY(vad_convt2x2(B + (size_t)f1 * in_f, 0, W_(14), B_(14), A, 0, m, hh, ww, 32, 32, VAD_ACT_RELU, precision, s)); }
             { VadProfScope ps(15, s);
               const size_t fo = (size_t)(f0 + f1);
               TRY(vad_conv3x3_to3_score_fmt(A, W_(15), B_(15), xin + (size_t)f1 * 3 * h * w * xelem, x_format, parts + (size_t)f1 * nparts,
@@ -164,7 +182,8 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, long long b, int h,
         }
         if (scores) {
             VadProfScope ps(16, s);
-            TRY(vad_score_finalize(parts, nparts, n, h, w, scores + f0, nullptr, 1, s));
+            TRY(vad_score_finalize_tagged(parts, nparts, n, h, w, scores + f0, nullptr, 1, (const unsigned*)packed,
+                                          vad_blob_tag(VAD_BLOB_IMG, precision), s));
         }
     }
 #undef W_
@@ -198,10 +217,11 @@ VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent, int hid, int la
 }
 
 // clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
-int vid_run(const void* xv, int x_format, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
+int vid_run(const void* xv, int x_format, int precision, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
             const float* packed, void* ws, size_t ws_bytes, int chunk, float* seq_scores, float* frame_scores,
             float* errmap, float* recon, hipStream_t s, const char* who) {
     VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "%s: unknown input format %d", who, x_format);
+    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "%s: precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", who, precision);
     const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
     const char* x = (const char*)xv;
     const VidWs Z = vid_ws(chunk, t, cs, h, w, latent, hid, layers);
@@ -234,9 +254,9 @@ int vid_run(const void* xv, int x_format, long long nclips, int t, int cs, int h
         // VideoEncoder: 4 x conv-BN-LeakyReLU-MaxPool on the flattened frames
         // (models/video_autoencoder.py:191-215, :222-228)
         { VadProfScope ps(0, s); TRY(vad_conv3x3_c3_fmt(xin, x_format, W_(0), B_(0), A, nf, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
-        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, s)); }
-        { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, s)); }
-        { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, s)); }
+        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, precision, s)); }
+        { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, precision, s)); }
+        { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, precision, s)); }
         // ConvLSTM: layers outer, time inner, zero initial state (models/video_autoencoder.py:144-166)
         for (int l = 0; l < layers; ++l) {
             const float* xin_l = (l == 0) ? E : HS[(l - 1) & 1];
@@ -250,7 +270,7 @@ int vid_run(const void* xv, int x_format, long long nclips, int t, int cs, int h
                                       ti ? hs + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
                                       ti ? C : nullptr, W_(4 + l), B_(4 + l),
                                       hs + (size_t)ti * fs_hid, (long long)t * fs_hid, C,
-                                      nc, h16, w16, cin_x, hid, s));
+                                      nc, h16, w16, cin_x, hid, precision, s));
             }
         }
         const float* dec_in = HS[(layers - 1) & 1];
@@ -262,9 +282,9 @@ int vid_run(const void* xv, int x_format, long long nclips, int t, int cs, int h
             ++li;
         }
         // VideoDecoder: 3 x convT-BN-ReLU + convT-Tanh (models/video_autoencoder.py:242-261)
-        { VadProfScope ps(6, s); TRY(vad_convt2x2(dec_in, 0, W_(li), B_(li), A, 0, n, h16, w16, latent, 128, VAD_ACT_RELU, s)); }
-        { VadProfScope ps(7, s); TRY(vad_convt2x2(A, 0, W_(li + 1), B_(li + 1), Bf, 0, n, h / 8, w / 8, 128, 64, VAD_ACT_RELU, s)); }
-        { VadProfScope ps(8, s); TRY(vad_convt2x2(Bf, 0, W_(li + 2), B_(li + 2), A, 0, n, h / 4, w / 4, 64, 32, VAD_ACT_RELU, s)); }
+        { VadProfScope ps(6, s); TRY(vad_convt2x2(dec_in, 0, W_(li), B_(li), A, 0, n, h16, w16, latent, 128, VAD_ACT_RELU, precision, s)); }
+        { VadProfScope ps(7, s); TRY(vad_convt2x2(A, 0, W_(li + 1), B_(li + 1), Bf, 0, n, h / 8, w / 8, 128, 64, VAD_ACT_RELU, precision, s)); }
+        { VadProfScope ps(8, s); TRY(vad_convt2x2(Bf, 0, W_(li + 2), B_(li + 2), A, 0, n, h / 4, w / 4, 64, 32, VAD_ACT_RELU, precision, s)); }
         { VadProfScope ps(9, s);
           TRY(vad_convt2x2_to3_score_fmt(A, W_(li + 3), B_(li + 3), xin, x_format, parts,
                                      recon ? recon + (size_t)c0 * t * 3 * h * w : nullptr,
@@ -272,8 +292,9 @@ int vid_run(const void* xv, int x_format, long long nclips, int t, int cs, int h
                                      t, cs, s)); }
         if (seq_scores || frame_scores) {
             VadProfScope ps(10, s);
-            TRY(vad_score_finalize(parts, nparts, n, h, w, frame_scores ? frame_scores + (size_t)c0 * t : nullptr,
-                                   seq_scores ? seq_scores + c0 : nullptr, t, s));
+            TRY(vad_score_finalize_tagged(parts, nparts, n, h, w, frame_scores ? frame_scores + (size_t)c0 * t : nullptr,
+                                          seq_scores ? seq_scores + c0 : nullptr, t, (const unsigned*)packed,
+                                          vad_blob_tag(VAD_BLOB_VID, precision), s));
         }
     }
 #undef W_
@@ -291,11 +312,11 @@ extern "C" size_t vad_vid_workspace_bytes(int chunk, int t, int h, int w, int la
 extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
                              const float* packed, void* ws, size_t ws_bytes, int chunk,
                              float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
-    return vad_vid_score_x(x, VAD_X_F32_NCHW, b, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores,
+    return vad_vid_score_x(x, VAD_X_F32_NCHW, VAD_PREC_FP32, b, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores,
                            frame_scores, errmap, recon, stream);
 }
 
-extern "C" int vad_vid_score_x(const void* x, int x_format, long long b, int t, int h, int w, int latent, int hid, int layers,
+extern "C" int vad_vid_score_x(const void* x, int x_format, int precision, long long b, int t, int h, int w, int latent, int hid, int layers,
                                const float* packed, void* ws, size_t ws_bytes, int chunk,
                                float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
     VAD_REQUIRE(x && packed && ws, "vid_score: null pointer");
@@ -304,7 +325,7 @@ extern "C" int vad_vid_score_x(const void* x, int x_format, long long b, int t, 
                 "vid_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
     if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;   // message already set
     VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score: no output requested");
-    return vid_run(x, x_format, b, t, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap,
+    return vid_run(x, x_format, precision, b, t, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap,
                    recon, (hipStream_t)stream, "vid_score");
 }
 
@@ -323,11 +344,11 @@ extern "C" int vad_vid_score_windows(const float* frames, long long nframes, int
                                      int latent, int hid, int layers, const float* packed, void* ws, size_t ws_bytes,
                                      int chunk, float* seq_scores, float* frame_scores, float* errmap, float* recon,
                                      void* stream) {
-    return vad_vid_score_windows_x(frames, VAD_X_F32_NCHW, nframes, t, stride, h, w, latent, hid, layers, packed, ws, ws_bytes,
+    return vad_vid_score_windows_x(frames, VAD_X_F32_NCHW, VAD_PREC_FP32, nframes, t, stride, h, w, latent, hid, layers, packed, ws, ws_bytes,
                                    chunk, seq_scores, frame_scores, errmap, recon, stream);
 }
 
-extern "C" int vad_vid_score_windows_x(const void* frames, int x_format, long long nframes, int t, int stride, int h, int w,
+extern "C" int vad_vid_score_windows_x(const void* frames, int x_format, int precision, long long nframes, int t, int stride, int h, int w,
                                        int latent, int hid, int layers, const float* packed, void* ws, size_t ws_bytes,
                                        int chunk, float* seq_scores, float* frame_scores, float* errmap, float* recon,
                                        void* stream) {
@@ -337,6 +358,6 @@ extern "C" int vad_vid_score_windows_x(const void* frames, int x_format, long lo
     VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0, "vid_score_windows: H=%d W=%d must be positive multiples of 16", h, w);
     if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;
     VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score_windows: no output requested");
-    return vid_run(frames, x_format, vad_vid_num_windows(nframes, t, stride), t, stride, h, w, latent, hid, layers, packed, ws,
+    return vid_run(frames, x_format, precision, vad_vid_num_windows(nframes, t, stride), t, stride, h, w, latent, hid, layers, packed, ws,
                    ws_bytes, chunk, seq_scores, frame_scores, errmap, recon, (hipStream_t)stream, "vid_score_windows");
 }

@@ -81,7 +81,10 @@ __device__ __forceinline__ float vad_norm_u8(unsigned v) {
 int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias, float* out, int n, int h, int wd,
                        int cout, int act, int pool, void* stream);
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1, const float* b1,
-                             float* out, int n, int h, int wd, void* stream);
+                             float* out, int n, int h, int wd, int precision, void* stream);
+// vad_score_finalize + the device-side blob check: when hdr != NULL and hdr[1] != want_tag every score becomes NaN
+int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, float* frame_scores,
+                              float* seq_scores, int t, const unsigned* hdr, unsigned want_tag, void* stream);
 int vad_conv3x3_to3_score_fmt(const float* in, const float* w_packed, const float* bias3, const void* x, int fmt,
                               float* partials, float* recon, float* errmap, int n, int h2, int w2, int cin, void* stream);
 int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float* bias3, const void* x, int fmt,
@@ -92,6 +95,7 @@ int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float
 struct VadProfScope {
     int slot;
     hipStream_t stream;
+    hipEvent_t end;
     VadProfScope(int slot, hipStream_t stream);
     ~VadProfScope();
 };

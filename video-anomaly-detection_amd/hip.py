@@ -17,9 +17,11 @@ REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
 SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
-HEADERS = ["vad_common.h", "vad_layout.h"]
 
 VAD_OK = 0
+ABI_VERSION = 2
+PREC_FP32, PREC_SPLIT = 0, 1
+PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT}
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 X_F32_NCHW, X_U8_NHWC = 0, 1
 PROF_SLOTS = 32
@@ -34,17 +36,33 @@ class VadError(RuntimeError):
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile libvad_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile libvad_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per source, compiled
+    in parallel and re-used while it is newer than its source and every header, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + [CSRC / h for h in HEADERS] + [REPO_DIR / "include" / "vad_hip.h"]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return LIB_PATH
+    hdrs = sorted(CSRC.glob("*.h")) + [REPO_DIR / "include" / "vad_hip.h"]
+    hdr_time = max(h.stat().st_mtime for h in hdrs)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           f"-I{REPO_DIR / 'include'}", f"-I{CSRC}", "-o", str(LIB_PATH)] + [str(s) for s in srcs]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    objdir = PKG_DIR / "build"
+    objdir.mkdir(exist_ok=True)
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", f"-I{REPO_DIR / 'include'}", f"-I{CSRC}"]
+
+    def compile_one(src: Path) -> Path:
+        obj = objdir / (src.name + ".o")
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_time):
+            cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    if force or not LIB_PATH.exists() or any(LIB_PATH.stat().st_mtime < o.stat().st_mtime for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", str(LIB_PATH)] + [str(o) for o in objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return LIB_PATH
 
 
@@ -60,21 +78,21 @@ SIGNATURES = {
     "vad_abi_version": (_i, []),
     "vad_last_error": (C.c_char_p, []),
     "vad_pack_conv3x3_floats": (_sz, [_i, _i]),
-    "vad_pack_conv3x3": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vad_pack_conv3x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "vad_pack_conv3x3_c3_floats": (_sz, [_i]),
     "vad_pack_conv3x3_c3": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "vad_pack_convt2x2_floats": (_sz, [_i, _i]),
-    "vad_pack_convt2x2": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vad_pack_convt2x2": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "vad_pack_conv1x1_floats": (_sz, [_i, _i]),
     "vad_pack_conv1x1": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "vad_pack_conv3x3_to3_floats": (_sz, [_i]),
     "vad_pack_conv3x3_to3": (_i, [_vp, _i, _vp]),
     "vad_conv3x3_c3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "vad_conv3x3_c3_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "vad_conv3x3": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "vad_convt2x2": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_conv3x3_c3_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_conv3x3": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_convt2x2": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_conv1x1": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
-    "vad_convlstm_step": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vad_convlstm_step": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_score_partials": (_i, [_i, _i, _i]),
     "vad_conv3x3_to3_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_convt2x2_to3_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -100,8 +118,8 @@ SIGNATURES = {
     "vad_convt_to3_mse_ws_floats": (_sz, [_i, _i, _i]),
     "vad_convt_to3_mse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "vad_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp]),
-    "vad_train_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "vad_train_pack_convt2x2": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "vad_train_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
+    "vad_train_pack_convt2x2": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
     "vad_train_pack_conv3x3_c3": (_i, [_vp, _i, _vp, _vp]),
     "vad_train_pack_conv1x1": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "vad_train_pack_conv3x3_to3": (_i, [_vp, _i, _vp, _vp, _vp]),
@@ -114,28 +132,27 @@ SIGNATURES = {
     "vad_debug_train_decisions_used": (_sz, []),
     "vad_debug_set_train_stop": (_i, [_i]),
     "vad_vid_train_debug_layout": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i]),
-    "vad_vid_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "vad_vid_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "vad_img_train_nparams": (_sz, [_i]),
     "vad_img_train_nstats": (_sz, [_i]),
     "vad_img_train_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "vad_img_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _f, _i, _vp, _vp, _vp]),
+    "vad_img_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _f, _i, _i, _vp, _vp, _vp]),
     "vad_synth_frames": (_i, [_vp, C.c_ulonglong, _ll, _ll, _i, _i, _i, _i, _vp]),
     "vad_img_packed_floats": (_sz, [_i, _i]),
-    "vad_img_pack": (_i, [_vp, _i, _i, _i, _vp]),
+    "vad_img_pack": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "vad_blob_precision": (_i, [_vp]),
     "vad_img_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "vad_img_score": (_i, [_vp, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_nparams": (_i, [_i, _i]),
     "vad_vid_packed_floats": (_sz, [_i, _i, _i]),
-    "vad_vid_pack": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "vad_vid_pack": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "vad_vid_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
-    "vad_set_precision": (_i, [_i]),
-    "vad_get_precision": (_i, []),
     "vad_debug_set_conv_variant": (_i, [_i]),
     "vad_debug_set_tail_group": (_i, [_i]),
-    "vad_img_score_x": (_i, [_vp, _i, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
-    "vad_vid_score_x": (_i, [_vp, _i, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
-    "vad_vid_score_windows_x": (_i, [_vp, _i, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_img_score_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_vid_score_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_vid_score_windows_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_num_windows": (_ll, [_ll, _i, _i]),
     "vad_vid_windows_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "vad_vid_score_windows": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -159,10 +176,17 @@ def lib() -> C.CDLL:
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(l, name)
                 fn.restype, fn.argtypes = res, args
-            if l.vad_abi_version() != 1:
+            if l.vad_abi_version() != ABI_VERSION:
                 raise VadError("libvad_hip.so ABI version mismatch")
             _lib = l
         return _lib
+
+
+def precision_mode(name: str) -> int:
+    """'fp32' / 'split' -> VAD_PREC_*: the arithmetic mode is an argument of every packer and launcher (ABI 2)."""
+    if name not in PRECISIONS:
+        raise VadError(f"precision must be one of {sorted(PRECISIONS)}, got {name!r}")
+    return PRECISIONS[name]
 
 
 def check(rc: int, what: str = "") -> None:

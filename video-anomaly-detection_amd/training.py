@@ -24,6 +24,19 @@ from . import hip
 from .video_autoencoder import VideoAutoencoder
 
 
+def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> None:
+    """Overwrite `flat` on every rank with rank `src`'s copy (same gloo host-copy route as `allreduce_sum_`)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+
+
 def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
     """Sum `flat` over the ranks of `group`, in place; returns the world size (1 when no process group is initialised).
     Backend "nccl" is RCCL on ROCm: one collective over the flat gradient buffer on the device.  With gloo (the CPU tests,
@@ -81,6 +94,22 @@ class _FlatTrainer:
         self.steps = 0
         self._ws: Optional[torch.Tensor] = None
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # Data-parallel replicas must start equal (DistributedDataParallel broadcasts rank 0's module at construction;
+        # the reference's train_video.py sets no seed, so independently constructed ranks would otherwise diverge silently).
+        broadcast_(self.flat, 0, process_group)
+        broadcast_(self.running, 0, process_group)
+
+    def _check_aliasing(self) -> None:
+        """The parameters must still be views of the flat buffers: `model.to()`, `.half()`, `.float()` or assigning
+        `p.data` re-allocates them, after which the kernels would update storage the module no longer reads."""
+        off = 0
+        for p in self.model.parameters():
+            if p.data_ptr() != self.flat.data_ptr() + 4 * off or p.dtype != torch.float32:
+                raise hip.VadError("a parameter no longer aliases the trainer's flat buffer (model.to()/.half()/.float() or a "
+                                   "p.data assignment after the trainer was built): build a new trainer from the module")
+            off += p.numel()
+        if self.bns and self.bns[0].running_mean.data_ptr() != self.running.data_ptr():
+            raise hip.VadError("a BatchNorm buffer no longer aliases the trainer's flat buffer: build a new trainer from the module")
 
     @staticmethod
     def _check_model(model, cls, name):
@@ -164,6 +193,7 @@ class _FlatTrainer:
     def step(self, batch: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's batch; with a process group the gradients are summed over ranks with ONE
         all-reduce of the flat buffer and averaged inside the optimiser kernel (DistributedDataParallel semantics)."""
+        self._check_aliasing()
         loss, _ = self.forward_backward(batch)
         world = allreduce_sum_(self.grad, self.group)
         self.optimizer_step(1.0 / world)
@@ -204,16 +234,9 @@ class VideoTrainer(_FlatTrainer):
         out = torch.empty_like(x) if recon else None
         l = hip.lib()
         with torch.cuda.device(self.device):
-            mode, before = (1 if self.precision == "split" else 0), l.vad_get_precision()
-            if before != mode:
-                hip.check(l.vad_set_precision(mode), "vad_set_precision")
-            try:
-                hip.check(l.vad_vid_train_fwd_bwd(x.data_ptr(), b, t, h, w, *self.cfg, self.flat.data_ptr(), self.grad.data_ptr(),
-                                                  self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._loss.data_ptr(),
-                                                  hip.ptr(out), hip.current_stream()), "vad_vid_train_fwd_bwd")
-            finally:
-                if before != mode:           # the switch is process-wide: leave it as found
-                    l.vad_set_precision(before)
+            hip.check(l.vad_vid_train_fwd_bwd(x.data_ptr(), b, t, h, w, *self.cfg, self.flat.data_ptr(), self.grad.data_ptr(),
+                                              self.running.data_ptr(), ws.data_ptr(), ws.numel(), hip.precision_mode(self.precision),
+                                              self._loss.data_ptr(), hip.ptr(out), hip.current_stream()), "vad_vid_train_fwd_bwd")
         self._after_forward_backward("train_step")
         return self._loss[0].clone(), out
 
@@ -251,17 +274,10 @@ class ImageTrainer(_FlatTrainer):
         ws = self._ensure_ws(nbytes)
         out = torch.empty_like(x) if recon else None
         with torch.cuda.device(self.device):
-            mode, before = (1 if self.precision == "split" else 0), l.vad_get_precision()
-            if before != mode:
-                hip.check(l.vad_set_precision(mode), "vad_set_precision")
-            try:
-                hip.check(l.vad_img_train_fwd_bwd(x.data_ptr(), b, h, w, self.latent, self.flat.data_ptr(), self.grad.data_ptr(),
-                                                  self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._KINDS[self.loss],
-                                                  self.ssim_weight, self.window_size, self._loss.data_ptr(), hip.ptr(out),
-                                                  hip.current_stream()), "vad_img_train_fwd_bwd")
-            finally:
-                if before != mode:
-                    l.vad_set_precision(before)
+            hip.check(l.vad_img_train_fwd_bwd(x.data_ptr(), b, h, w, self.latent, self.flat.data_ptr(), self.grad.data_ptr(),
+                                              self.running.data_ptr(), ws.data_ptr(), ws.numel(), self._KINDS[self.loss],
+                                              self.ssim_weight, self.window_size, hip.precision_mode(self.precision),
+                                              self._loss.data_ptr(), hip.ptr(out), hip.current_stream()), "vad_img_train_fwd_bwd")
         self._after_forward_backward("train_step_img")
         return self._loss[0].clone(), out
 

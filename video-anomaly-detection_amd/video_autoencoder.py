@@ -151,7 +151,7 @@ class VideoAutoencoder(nn.Module):
 
     def _packed(self, device) -> torch.Tensor:
         l = hip.lib()
-        mode = _HipScorer.set_precision(self.precision)
+        mode = hip.precision_mode(self.precision)
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
@@ -164,10 +164,20 @@ class VideoAutoencoder(nn.Module):
             params = _HipScorer.float_params(self)
             blob = np.empty(n, dtype=np.float32)
             hip.check(l.vad_vid_pack(hip.pointer_array(params), len(params), self.latent_dim,
-                                     self.lstm_hidden_dim, self.lstm_num_layers, blob.ctypes.data), "vad_vid_pack")
+                                     self.lstm_hidden_dim, self.lstm_num_layers, mode, blob.ctypes.data), "vad_vid_pack")
             self._hip.packed = torch.from_numpy(blob).to(device)
             self._hip.key = key
+            self._hip.mode = mode
         return self._hip.packed
+
+    def invalidate_packed(self) -> None:
+        """Drop the packed-weight cache (see ConvAutoencoder.invalidate_packed)."""
+        self._hip.key = None
+
+    def train(self, mode: bool = True):
+        if mode != self.training:
+            self._hip.key = None
+        return super().train(mode)
 
     def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False):
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,T,H,W,3]: normalised inside the kernels (row f-3)
@@ -202,7 +212,7 @@ class VideoAutoencoder(nn.Module):
         if recon:
             out["recon"] = torch.empty(b, t, 3, h, w, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(l.vad_vid_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, b, t, h, w, *dims,
+            hip.check(l.vad_vid_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, t, h, w, *dims,
                                         packed.data_ptr(), ws.data_ptr(), ws.numel(),
                                       chunk, hip.ptr(out.get("seq")), hip.ptr(out.get("frame")),
                                       hip.ptr(out.get("errmap")), hip.ptr(out.get("recon")), hip.current_stream()),
@@ -282,7 +292,7 @@ class VideoAutoencoder(nn.Module):
         if recon:
             out["recon"] = torch.empty(nw, t, 3, h, w, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(l.vad_vid_score_windows_x(frames.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, f, t,
+            hip.check(l.vad_vid_score_windows_x(frames.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, f, t,
                                                 int(stride), h, w, *dims, packed.data_ptr(),
                                               ws.data_ptr(), ws.numel(), chunk, out["seq"].data_ptr(),
                                               out["frame"].data_ptr(), hip.ptr(out.get("errmap")),
