@@ -54,3 +54,15 @@ def rel_err(a, b):
 
 def max_abs(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+def auroc_slack(labels, ref_scores, rtol):
+    """Largest AUROC change that score errors of `rtol` (relative) can cause: every (anomalous, normal) pair whose
+    reference scores are closer than 2*rtol may swap order or tie.  With 64 scores inside one per-cent of each other some
+    pairs differ by a single float32 ulp, so an exact AUROC match is not implied by matching scores; everything beyond these
+    few pairs is."""
+    labels = np.asarray(labels).astype(bool)
+    s = np.asarray(ref_scores, dtype=np.float64)
+    pos, neg = s[labels], s[~labels]
+    close = np.abs(pos[:, None] - neg[None, :]) <= 2 * rtol * np.maximum(np.abs(pos[:, None]), np.abs(neg[None, :]))
+    return float(close.sum()) / (len(pos) * len(neg)), int(close.sum())

@@ -353,7 +353,7 @@ def test_image_last_layer_conv_tanh_backward(vad, n, h, w, given_drecon):
     ad, xd, wd, bd = H.nhwc(a), H.dev(x), H.dev(wt), H.dev(b)
     fwd = _ws(l.vad_pack_conv3x3_to3_floats(32))
     dgr = torch.zeros(l.vad_pack_conv3x3_c3_floats(32), device="cuda")
-    vad.hip.check(l.vad_train_pack_conv3x3_to3(wd.data_ptr(), 32, fwd.data_ptr(), dgr.data_ptr(), precision, H.stream()))
+    vad.hip.check(l.vad_train_pack_conv3x3_to3(wd.data_ptr(), 32, fwd.data_ptr(), dgr.data_ptr(), H.stream()))
     recon = torch.full((n, 3, h, w), float("nan"), device="cuda")
     parts = _ws(n * l.vad_score_partials(0, h, w))
     vad.hip.check(l.vad_conv3x3_to3_score(ad.data_ptr(), fwd.data_ptr(), bd.data_ptr(), xd.data_ptr(), parts.data_ptr(), recon.data_ptr(), None,

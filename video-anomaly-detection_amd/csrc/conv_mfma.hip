@@ -212,13 +212,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
                 if (y < p.h && x < p.w_) {
                     const size_t pix = (size_t)y * p.w_ + x;
                     const float cp = p.c_prev ? p.c_prev[(size_t)n * cfs + pix * p.hid + hc] : 0.f;
-                    const float gi = vad_sigmoid(acc[mt][0][r]);
-                    const float gf = vad_sigmoid(acc[mt][1][r]);
-                    const float gg = vad_tanh(acc[mt][2][r]);
-                    const float go = vad_sigmoid(acc[mt][3][r]);
-                    const float cn = gf * cp + gi * gg;
+                    float cn, hn;
+                    vad_lstm_cell(acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r], cp, cn, hn);
                     p.c_out[(size_t)n * cfs + pix * p.hid + hc] = cn;
-                    p.out[(size_t)n * p.out_fs + pix * p.hid + hc] = go * vad_tanh(cn);
+                    p.out[(size_t)n * p.out_fs + pix * p.hid + hc] = hn;
                 }
             }
         }
@@ -254,6 +251,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
 }
 
 #include "conv_pkernel.h"
+#include "conv_small.h"
 #include "convt_pkernel.h"
 
 // Developer A/B switches (vad_debug_*): written only by an explicit debug call, read once per launch; the library
@@ -261,11 +259,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
 static std::atomic<unsigned long long*> g_vad_dbg{nullptr};
 extern "C" int vad_debug_set_stamp_buffer(void* p) { g_vad_dbg = (unsigned long long*)p; return VAD_OK; }
 static std::atomic<int> g_vad_conv_bits{1};   // bit 0: 1 = persistent + register prefetch (default), 0 = one tile per work-group;
-                                              // bit 1: price the weight traffic (split kernels); bit 2: alternative cout-64 tiling
-extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 7; return VAD_OK; }
+                                              // bit 1: price the weight traffic (split kernels); bit 2: alternative cout-64 tiling;
+                                              // bit 3: never use the small-grid (16x16x4) ConvLSTM kernel
+extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 15; return VAD_OK; }
 struct ConvKnobs {
-    int variant, stagger, conv64;
-    ConvKnobs() { const int b = g_vad_conv_bits.load(std::memory_order_relaxed); variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; }
+    int variant, stagger, conv64, no_small;
+    ConvKnobs() {
+        const int b = g_vad_conv_bits.load(std::memory_order_relaxed);
+        variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; no_small = (b >> 3) & 1;
+    }
 };
 #define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, who ": precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision)
 
@@ -456,6 +458,20 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
     // the persistent kernel shares one set of staging offsets between x and h: needs cin_x == hid
     VAD_REQUIRE(!(precision == VAD_PREC_SPLIT && cin_x != hid), "convlstm_step: split precision needs cin_x == hid (got %d, %d)", cin_x, hid);
     const ConvKnobs kn;
+    // Small grids (the reference's own batch sizes: 4 clips, or 1 window): the 32x32x2 tiling yields 8 work-groups per clip of
+    // a 16x16 map, each a 123 us serial K loop; below one work-group per CU the 16x16x4 form (4x the waves, a quarter of the
+    // latency, bit-identical results: conv_small.h) wins - 133 -> ~35 us per step at B <= 8.
+    const long long nb_big = (long long)n * ((wd + 15) / 16) * ((h + 3) / 4) * (hid / 64);
+    if (precision == VAD_PREC_FP32 && kn.variant != 0 && !kn.no_small && nb_big < 256) {
+        p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 1) / 2; p.cblocks = hid / 32;
+        const long long nb = (long long)n * p.tiles_x * p.tiles_y * p.cblocks;
+        p.nblocks = (unsigned)nb; p.n = n;
+        VAD_REQUIRE((long long)h * wd * (cin_x > hid ? cin_x : hid) * 4 < (1ll << 31) && 9ll * p.cin * p.cout * 4 < (1ll << 31),
+                    "convlstm_step: frame or weights too large for 32-bit offsets");
+        hipLaunchKernelGGL(convlstm_small_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
     return launch_conv3<32, 1, 4, 2, 2, MODE_LSTM>(p, n, VAD_ACT_NONE, (hipStream_t)stream, precision, cin_x != hid ? 0 : kn.variant, kn);
 }
 

@@ -527,13 +527,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                     const unsigned vo = ok ? eoff[0] : VAD_OOB;                 // gate 0's channel == hidden channel
                     const unsigned so = dy * erow + dx * ecol;
                     const float cp = vad_bload1(rc_in, vo, so);                  // zero-sized descriptor -> 0 (initial state)
-                    const float gi = vad_sigmoid(acc[mt][0][r]);
-                    const float gf = vad_sigmoid(acc[mt][1][r]);
-                    const float gg = vad_tanh(acc[mt][2][r]);
-                    const float go = vad_sigmoid(acc[mt][3][r]);
-                    const float cn = gf * cp + gi * gg;
+                    float cn, hn;
+                    vad_lstm_cell(acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r], cp, cn, hn);
                     vad_bstore1(cn, rc_out, vo, so);
-                    vad_bstore1(go * vad_tanh(cn), rh_out, vo, so);
+                    vad_bstore1(hn, rh_out, vo, so);
                 }
             }
         } else {

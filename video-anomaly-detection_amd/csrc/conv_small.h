@@ -1,0 +1,141 @@
+// Small-grid form of the ConvLSTM gate convolution (included by conv_mfma.hip after conv_pkernel.h).
+//
+// The reference's own callers use small batches: 4 clips per batch in evaluate_video.py:416 / train_video.py:306, ONE
+// window per forward in generate_video_output (evaluate_video.py:344).  A ConvLSTM step on a 16x16 map is then a GEMM of
+// M = B*256 pixels, N = 512 gate columns, K = 2304, and the time of a step is not throughput but the serial K loop of ONE
+// wave: the 32x32x2 kernel gives a wave a 32-pixel x 128-column tile = 4,608 dependent-per-accumulator MFMAs of 64 cycles
+// (123 us at 2.4 GHz) however few work-groups there are (8 per clip: 32 of 256 CUs busy at B = 4).
+//
+// This kernel cuts the wave tile to 16 pixels x 64 columns (4 gates x 16 hidden channels) on v_mfma_f32_16x16x4_f32
+// (32 cycles, same FLOP/cycle): 2,304 MFMAs of 32 cycles per wave = 31 us per step, and 4x the waves (128 per clip).
+//
+// Bit-identical to conv3x3_mfma_pkernel's LSTM mode, not merely close: both MFMAs are k-ordered fp32 fmaf chains, and the
+// k order is reproduced exactly - per 32-channel chunk: tap-major, then 8-channel groups, and inside a group the
+// 32x32x2 kernel's order ch0,ch4,ch1,ch5 | ch2,ch6,ch3,ch7 (its lane halves hold channels j and 4+j of step j) becomes two
+// 16x16x4 instructions whose four k lanes hold (ch0,ch4,ch1,ch5) and (ch2,ch6,ch3,ch7).  Same bias-initialised
+// accumulator, same gate functions: a clip scored alone equals the same clip inside a batch of 64 (tests assert
+// torch.equal), which is what keeps sharded and chunked scoring exact.
+//
+// Operands: A = NHWC tile with 1-pixel halo in LDS (2 rows x 16 columns + halo, pixel stride 36 floats, next chunk
+// prefetched into registers); B = the packed weights [tap][cin/8][cout][8] straight from L2 (a lane reads 16 B of its
+// column's 8-channel group and uses 2 of the 4 values per instruction pair).  M-tile = 2 rows x 8 columns in pooling-window
+// order, so a lane's 4 accumulator registers are a 2x2 pixel block.  Exact fp32 only.
+#pragma once
+
+#define MFMA16X4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// 4 waves = 2 M-tiles (left / right 8 columns of a 2 x 16 pixel tile) x 2 blocks of 16 hidden channels
+__global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
+    constexpr int CK = 32, LH = 4, LW = 18, PS = CK + 4, NPIX = LH * LW, TOT = NPIX * (CK / 4), NPF = (TOT + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, kq = lane >> 4;
+    const int H = p.h, W = p.w_, hid = p.hid;
+
+    unsigned L = vad_xcd_remap(blockIdx.x, p.nblocks);
+    const int cb = L % p.cblocks; L /= p.cblocks;
+    const int x0 = (L % p.tiles_x) * 16; L /= p.tiles_x;
+    const int y0 = (L % p.tiles_y) * 2;
+    const int n = L / p.tiles_y;
+
+    // A operand: M index li -> pooling-window order inside the wave's 2 x 8 pixel M-tile
+    const int arow = (li >> 1) & 1, acol = 8 * wm + 2 * (li >> 2) + (li & 1);
+    const int abase = (arow * LW + acol) * PS + 4 * (kq & 1);
+    const bool hi_pair = (kq >> 1) != 0;              // k lanes 2,3 take elements 1 and 3 of the 4-channel read, lanes 0,1 take 0 and 2
+
+    // B operand / bias: gate g, hidden channel hc -> column g*hid + hc
+    const int hc = (cb * 2 + wn) * 16 + li;
+    const unsigned wstep = (unsigned)p.cout * 32u;                 // bytes per (tap, 8-channel group) slab
+    const unsigned wtap = (unsigned)(p.cin / 8) * wstep;           // bytes per tap
+    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 9u * wtap);
+    unsigned wl[4];
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co = g * hid + hc;
+        wl[g] = (unsigned)co * 32u + 16u * (kq & 1);
+        const float bv = p.bias[co];
+        acc[g] = f32x4{bv, bv, bv, bv};
+    }
+
+    const int nch_a = p.cin_a / CK;
+    const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
+
+    // staging: slot i of this thread = float4 number tid + 256 i of the halo tile (pixel-major, 8 quads per pixel)
+    f32x4 pf[NPF];
+    auto issue = [&](int ch) {
+        const bool a = ch < nch_a;
+        const float* src = a ? p.in + (size_t)n * p.in_fs : p.in2 + (size_t)n * p.in2_fs;
+        const int pstride = a ? p.cin_a : p.cin - p.cin_a;
+        const int coff = (a ? ch : ch - nch_a) * CK;
+        const __amdgpu_buffer_rsrc_t r = vad_rsrc(src, (unsigned)(H * W) * (unsigned)pstride * 4u);
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + 256 * i, pix = idx >> 3, c4 = idx & 7;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            const bool ok = idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            pf[i] = vad_bload4(r, ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, pstride) + coff + c4 * 4) * 4u : VAD_OOB, 0);
+        }
+    };
+    issue(0);
+
+    f32x4 b[2][4];
+#define SLOAD_B(buf, chunk, step)                                                                                     \
+    {                                                                                                                 \
+        const unsigned woff_ = (unsigned)((step) >> 2) * wtap + (unsigned)((chunk) * 4 + ((step) & 3)) * wstep;       \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) b[buf][g] = vad_bload4(rw, wl[g], woff_);                       \
+    }
+    SLOAD_B(0, 0, 0);
+
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();                               // every wave is done reading the previous chunk
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < TOT) *(f32x4*)&tile[(idx >> 3) * PS + (idx & 7) * 4] = pf[i];
+        }
+        __syncthreads();
+        if (ch + 1 < nch) issue(ch + 1);               // in flight during the 36 steps below
+
+        f32x4 a[2];
+        a[0] = *(const f32x4*)&tile[abase];
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {                 // (tap, 8-channel group) steps: same order as the 32x32x2 kernel
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < 36) {
+                const int tap = (s + 1) >> 2;
+                a[nxt] = *(const f32x4*)&tile[abase + ((tap / 3) * LW + tap % 3) * PS + ((s + 1) & 3) * 8];
+                SLOAD_B(nxt, ch, s + 1);
+            } else if (ch + 1 < nch) {
+                SLOAD_B(nxt, ch + 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // keep the prefetch above this step's MFMAs
+            const float a0 = hi_pair ? a[cur][1] : a[cur][0], a1 = hi_pair ? a[cur][3] : a[cur][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a0, hi_pair ? b[cur][g][1] : b[cur][g][0], acc[g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a1, hi_pair ? b[cur][g][3] : b[cur][g][2], acc[g]);
+        }
+    }
+#undef SLOAD_B
+
+    // epilogue: registers r = 2x2 pixel block (dy = r>>1, dx = r&1) of window kq; gates of hidden channel hc in this lane
+    const size_t cfs = (size_t)H * W * hid;
+    const float* cprev = p.c_prev ? p.c_prev + (size_t)n * cfs : nullptr;
+    float* cout_ = p.c_out + (size_t)n * cfs;
+    float* hout = p.out + (size_t)n * p.out_fs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+        if (y < H && x < W) {
+            const size_t o = ((size_t)y * W + x) * hid + hc;
+            float cn, hn;
+            vad_lstm_cell(acc[0][r], acc[1][r], acc[2][r], acc[3][r], cprev ? cprev[o] : 0.f, cn, hn);
+            cout_[o] = cn;
+            hout[o] = hn;
+        }
+    }
+}

@@ -43,7 +43,15 @@ __device__ __forceinline__ float vad_act(float v, int act) {
 // Gate non-linearities of the ConvLSTM epilogue on the hardware transcendental unit (v_exp_f32 / v_rcp_f32,
 // ~1 ulp each): 4-5 instructions instead of the ~40 of libm's expf/tanhf, absolute error ~1e-7.
 __device__ __forceinline__ float vad_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
-__device__ __forceinline__ float vad_tanh(float v) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f); }
+__device__ __forceinline__ float vad_tanh(float v) { return __builtin_fmaf(-2.0f, __frcp_rn(__expf(2.0f * v) + 1.0f), 1.0f); }
+// ConvLSTMCell state update (reference models/video_autoencoder.py:76-83) from the four gate pre-activations.  The
+// contractions are spelled out so that every kernel that fuses it (32x32x2 persistent / one-tile forms, 16x16x4 small-grid
+// form) rounds identically: c' = fma(sigmoid(f), c, sigmoid(i)*tanh(g)), h' = sigmoid(o) * tanh(c').
+__device__ __forceinline__ void vad_lstm_cell(float zi, float zf, float zg, float zo, float c_prev, float& c_next, float& h_next) {
+    const float ig = vad_sigmoid(zi) * vad_tanh(zg);
+    c_next = __builtin_fmaf(vad_sigmoid(zf), c_prev, ig);
+    h_next = vad_sigmoid(zo) * vad_tanh(c_next);
+}
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
