@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the secondary split-precision measurement")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (row f-1)")
+    ap.add_argument("--no-wavefront", action="store_true", help="video: ConvLSTM layers strictly one after the other (A/B of the small-batch wavefront)")
+    ap.add_argument("--conv-variant", type=int, default=-1, help="vad_debug_set_conv_variant bits (A/B; 9 = never the small-grid ConvLSTM kernel)")
     ap.add_argument("--tail-group", type=int, default=0, help="frames per dec4.0 -> tail sub-group (0 = auto)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use GPU 0")
@@ -111,6 +113,10 @@ def main():
     scale = (hw * hw) / 65536.0
     if args.tail_group:
         lib.vad_debug_set_tail_group(args.tail_group)
+    if args.no_wavefront:
+        lib.vad_debug_set_lstm_wavefront(0)
+    if args.conv_variant >= 0:
+        lib.vad_debug_set_conv_variant(args.conv_variant)
 
     def synth_load(module, seed):
         shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}

@@ -302,7 +302,8 @@ size_t vad_vid_packed_floats(int latent, int hid, int layers);
 int vad_vid_pack(const float* const* params, int nparams, int latent, int hid, int layers, int precision, float* packed_host);
 size_t vad_vid_workspace_bytes(int chunk_clips, int t, int h, int w, int latent, int hid, int layers);
 /* x [B,T,3,H,W].  Outputs (any may be NULL): seq_scores [B]; frame_scores [B,T];
- * errmap [B,T,H,W]; recon [B,T,3,H,W]. */
+ * errmap [B,T,H,W]; recon [B,T,3,H,W].  Asynchronous on `stream`; launch groups smaller than one work-group per CU run the
+ * ConvLSTM layers as a wavefront on library-owned helper streams that fork from and join `stream` (vad_debug_set_lstm_wavefront). */
 int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
                   const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips,
                   float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
@@ -311,6 +312,10 @@ int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, 
  * results are bit-identical): 0 = one tile per work-group, 1 = persistent work-groups with register prefetch of the next
  * stage (default). */
 int vad_debug_set_conv_variant(int variant);
+/* 0 = run the ConvLSTM layers strictly one after the other on the caller's stream; 1 (default) = small launch groups run
+ * them as a wavefront: layer l step t on a library-owned helper stream as soon as layer l-1 step t is done (fork / join by
+ * events on `stream`; the helper streams are created once per thread and device on the first such call).  Same results. */
+int vad_debug_set_lstm_wavefront(int on);
 /* Frames per dec4.0 -> scoring-tail sub-group inside vad_img_score (0 = whole launch group). */
 int vad_debug_set_tail_group(int frames);
 

@@ -40,6 +40,12 @@ struct Conv3P {
 };
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// K order inside an 8-channel group, shared by every exact-fp32 3x3 kernel so that they stay bit-identical to each other:
+// a 32x32x2 step j multiplies channels (j, 4+j) (its two lane halves), and the steps run in the order j = 0, 2, 1, 3, i.e.
+// channels 0,4,2,6 | 1,5,3,7.  That is the one order both this instruction AND v_mfma_f32_16x16x4_f32 can feed with plain
+// contiguous reads: the 16x16x4 kernel's four k lanes read the adjacent channel pairs (0,1) (4,5) (2,3) (6,7) and issue
+// (0,4,2,6) then (1,5,3,7) (conv_small.h) - no per-lane element selects, no duplicated weight bytes through L1.
+#define VAD_KORDER(jj) (((jj) == 1) ? 2 : ((jj) == 2) ? 1 : (jj))
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
@@ -188,12 +194,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
             // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks each load to its first use)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = VAD_KORDER(jj);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = MFMA32(a[cur][mt][j], b[cur][nt][j], acc[mt][nt]);
+            }
         }
     }
 #undef LOAD_A

@@ -486,12 +486,14 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                     else if (ch + 1 < nch) { LOAD_B(bnxt, ch + 1, s + PB - NS); }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = VAD_KORDER(jj);       // channels j and 4+j of the 8-group; see VAD_KORDER
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
                                 acc[mt][nt] = MFMA32(a[cur][mt][j], b[bcur][nt][j], acc[mt][nt]);
+                    }
                 }
             }
             STAMP(5);

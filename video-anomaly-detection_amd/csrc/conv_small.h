@@ -10,16 +10,18 @@
 // (32 cycles, same FLOP/cycle): 2,304 MFMAs of 32 cycles per wave = 31 us per step, and 4x the waves (128 per clip).
 //
 // Bit-identical to conv3x3_mfma_pkernel's LSTM mode, not merely close: both MFMAs are k-ordered fp32 fmaf chains, and the
-// k order is reproduced exactly - per 32-channel chunk: tap-major, then 8-channel groups, and inside a group the
-// 32x32x2 kernel's order ch0,ch4,ch1,ch5 | ch2,ch6,ch3,ch7 (its lane halves hold channels j and 4+j of step j) becomes two
-// 16x16x4 instructions whose four k lanes hold (ch0,ch4,ch1,ch5) and (ch2,ch6,ch3,ch7).  Same bias-initialised
-// accumulator, same gate functions: a clip scored alone equals the same clip inside a batch of 64 (tests assert
-// torch.equal), which is what keeps sharded and chunked scoring exact.
+// k order is reproduced exactly - per 32-channel chunk: tap-major, then 8-channel groups, and inside a group channels
+// 0,4,2,6,1,5,3,7 (VAD_KORDER in conv_mfma.hip): the 32x32x2 kernels run their steps j = 0,2,1,3 over channel pairs (j, 4+j);
+// here k lane kq reads the ADJACENT channels (c, c+1), c = (0,4,2,6)[kq], and two 16x16x4 instructions take the first and the
+// second of each pair.  Same bias-initialised accumulator, same gate functions: a clip scored alone equals the same clip
+// inside a batch of 64 (tests assert torch.equal), which is what keeps sharded and chunked scoring exact.
 //
 // Operands: A = NHWC tile with 1-pixel halo in LDS (2 rows x 16 columns + halo, pixel stride 36 floats, next chunk
-// prefetched into registers); B = the packed weights [tap][cin/8][cout][8] straight from L2 (a lane reads 16 B of its
-// column's 8-channel group and uses 2 of the 4 values per instruction pair).  M-tile = 2 rows x 8 columns in pooling-window
-// order, so a lane's 4 accumulator registers are a 2x2 pixel block.  Exact fp32 only.
+// prefetched into registers), one ds_read_b64 per lane and step; B = the packed weights [tap][cin/8][cout][8] straight from
+// L2, one 8-byte load per lane, gate and step: a wave reads 512 contiguous bytes, every byte once (16-byte loads with a
+// per-lane element pick moved 2x the bytes through the 64 B/clk vector L1 and made it, not the matrix pipe, the limit:
+// 64 us per launch instead of ~35).  M-tile = 2 rows x 8 columns in pooling-window order, so a lane's 4 accumulator
+// registers are a 2x2 pixel block.  Exact fp32 only.
 #pragma once
 
 #define MFMA16X4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -34,16 +36,18 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
     const int li = lane & 15, kq = lane >> 4;
     const int H = p.h, W = p.w_, hid = p.hid;
 
+    // column block slowest inside a frame: the work-groups an XCD runs (consecutive logical ids) then read the SAME quarter of
+    // the 4.7 MB gate weights, which fits its 4 MB L2; the first reader of a line pays the Infinity-Cache trip, the rest hit
     unsigned L = vad_xcd_remap(blockIdx.x, p.nblocks);
-    const int cb = L % p.cblocks; L /= p.cblocks;
     const int x0 = (L % p.tiles_x) * 16; L /= p.tiles_x;
-    const int y0 = (L % p.tiles_y) * 2;
-    const int n = L / p.tiles_y;
+    const int y0 = (L % p.tiles_y) * 2; L /= p.tiles_y;
+    const int cb = L % p.cblocks;
+    const int n = L / p.cblocks;
 
     // A operand: M index li -> pooling-window order inside the wave's 2 x 8 pixel M-tile
     const int arow = (li >> 1) & 1, acol = 8 * wm + 2 * (li >> 2) + (li & 1);
-    const int abase = (arow * LW + acol) * PS + 4 * (kq & 1);
-    const bool hi_pair = (kq >> 1) != 0;              // k lanes 2,3 take elements 1 and 3 of the 4-channel read, lanes 0,1 take 0 and 2
+    const int kc = ((kq & 1) << 2) | (kq & 2);        // first channel of this k lane's pair: (0,4,2,6)[kq]
+    const int abase = (arow * LW + acol) * PS + kc;
 
     // B operand / bias: gate g, hidden channel hc -> column g*hid + hc
     const int hc = (cb * 2 + wn) * 16 + li;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co = g * hid + hc;
-        wl[g] = (unsigned)co * 32u + 16u * (kq & 1);
+        wl[g] = (unsigned)co * 32u + 4u * (unsigned)kc;
         const float bv = p.bias[co];
         acc[g] = f32x4{bv, bv, bv, bv};
     }
@@ -82,13 +86,19 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
     };
     issue(0);
 
-    f32x4 b[2][4];
+    // B fragments run PB steps ahead in a ring of NB register sets: a step is only 8 MFMAs x 32 cycles, and a weight line that
+    // misses L2 comes back from the Infinity Cache in ~550 cycles (one step ahead left ~300 cycles exposed per step: 73 us
+    // per launch instead of the 31 us of its MFMAs)
+    constexpr int PB = 3, NB = 4;
+    static_assert(36 % NB == 0, "ring position must be the same in every chunk");
+    f32x2 b[NB][4];
 #define SLOAD_B(buf, chunk, step)                                                                                     \
     {                                                                                                                 \
         const unsigned woff_ = (unsigned)((step) >> 2) * wtap + (unsigned)((chunk) * 4 + ((step) & 3)) * wstep;       \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) b[buf][g] = vad_bload4(rw, wl[g], woff_);                       \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) b[buf][g] = vad_bload2(rw, wl[g], woff_);                       \
     }
-    SLOAD_B(0, 0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < PB; ++s0) SLOAD_B(s0, 0, s0);
 
     for (int ch = 0; ch < nch; ++ch) {
         __syncthreads();                               // every wave is done reading the previous chunk
@@ -100,24 +110,23 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
         __syncthreads();
         if (ch + 1 < nch) issue(ch + 1);               // in flight during the 36 steps below
 
-        f32x4 a[2];
-        a[0] = *(const f32x4*)&tile[abase];
+        f32x2 a[2];
+        a[0] = *(const f32x2*)&tile[abase];
 #pragma unroll
         for (int s = 0; s < 36; ++s) {                 // (tap, 8-channel group) steps: same order as the 32x32x2 kernel
             const int cur = s & 1, nxt = cur ^ 1;
+            const int bcur = s % NB, bnxt = (s + PB) % NB;
             if (s + 1 < 36) {
                 const int tap = (s + 1) >> 2;
-                a[nxt] = *(const f32x4*)&tile[abase + ((tap / 3) * LW + tap % 3) * PS + ((s + 1) & 3) * 8];
-                SLOAD_B(nxt, ch, s + 1);
-            } else if (ch + 1 < nch) {
-                SLOAD_B(nxt, ch + 1, 0);
+                a[nxt] = *(const f32x2*)&tile[abase + ((tap / 3) * LW + tap % 3) * PS + ((s + 1) & 3) * 8];
             }
+            if (s + PB < 36) { SLOAD_B(bnxt, ch, s + PB); }
+            else if (ch + 1 < nch) { SLOAD_B(bnxt, ch + 1, s + PB - 36); }
             __builtin_amdgcn_sched_barrier(0);         // keep the prefetch above this step's MFMAs
-            const float a0 = hi_pair ? a[cur][1] : a[cur][0], a1 = hi_pair ? a[cur][3] : a[cur][2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a0, hi_pair ? b[cur][g][1] : b[cur][g][0], acc[g]);
+            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a[cur][0], b[bcur][g][0], acc[g]);      // channels 0,4,2,6
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a1, hi_pair ? b[cur][g][3] : b[cur][g][2], acc[g]);
+            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a[cur][1], b[bcur][g][1], acc[g]);      // channels 1,5,3,7
         }
     }
 #undef SLOAD_B

@@ -212,9 +212,43 @@ VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent, int hid, int la
     z.cst = up256(sizeof(float) * (size_t)chunk * p16 * hid);
     z.proj = (hid != latent) ? up256(sizeof(float) * n * p16 * latent) : 0;
     z.parts = up256(sizeof(float) * n * (size_t)vad_score_partials(1, h, w));
-    z.total = 2 * z.act + z.enc + (layers > 1 ? 2 : 1) * z.hseq + z.cst + z.proj + z.parts;
+    z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst) + z.proj + z.parts;   // h sequence + cell state per layer
     return z;
 }
+
+// Helper streams for the ConvLSTM layer wavefront (small batches): layer l runs on side stream l-1 and step t of layer l
+// waits only for step t of layer l-1, so layer 1 step t overlaps layer 0 step t+1 (the reference's loop is strictly
+// layers-outer, models/video_autoencoder.py:153-160; the data dependences allow the diagonal order).  Created once per
+// thread and device on the first small-batch call; fork / join through events on the caller's stream, so the call stays
+// asynchronous and capturable into a hipGraph (after one eager call has created the streams).
+struct VadSideStreams {
+    int dev = -1, n = 0;
+    hipStream_t st[7] = {};
+    hipEvent_t done[8] = {};      // done[l]: layer l finished its latest step
+    hipEvent_t fork = nullptr;
+};
+static thread_local VadSideStreams t_side;
+
+static int side_streams(int layers, VadSideStreams** out) {
+    int dev = 0;
+    VAD_HIP_TRY(hipGetDevice(&dev));
+    VadSideStreams& S = t_side;
+    if (S.dev != dev) {            // first use on this device by this thread (streams of another device are left to the runtime)
+        S = VadSideStreams{};
+        S.dev = dev;
+        VAD_HIP_TRY(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+        for (int l = 0; l < 8; ++l) VAD_HIP_TRY(hipEventCreateWithFlags(&S.done[l], hipEventDisableTiming));
+    }
+    while (S.n < layers - 1) {
+        VAD_HIP_TRY(hipStreamCreateWithFlags(&S.st[S.n], hipStreamNonBlocking));
+        ++S.n;
+    }
+    *out = &S;
+    return VAD_OK;
+}
+
+static std::atomic<int> g_vad_lstm_wavefront{1};   // debug: 0 = always the sequential layers-outer order
+extern "C" int vad_debug_set_lstm_wavefront(int on) { g_vad_lstm_wavefront = on != 0; return VAD_OK; }
 
 // clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
 int vid_run(const void* xv, int x_format, int precision, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
@@ -232,11 +266,10 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
     float* A = (float*)base; base += Z.act;
     float* Bf = (float*)base; base += Z.act;
     float* E = (float*)base; base += Z.enc;
-    float* HS[2];
-    HS[0] = (float*)base; base += Z.hseq;
-    HS[1] = HS[0];
-    if (layers > 1) { HS[1] = (float*)base; base += Z.hseq; }
-    float* C = (float*)base; base += Z.cst;
+    float* HS[8];
+    float* CS[8];
+    for (int l = 0; l < layers; ++l) { HS[l] = (float*)base; base += Z.hseq; }
+    for (int l = 0; l < layers; ++l) { CS[l] = (float*)base; base += Z.cst; }
     float* P = nullptr;
     if (L.has_proj) { P = (float*)base; base += Z.proj; }
     float* parts = (float*)base;
@@ -257,23 +290,40 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, precision, s)); }
         { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, precision, s)); }
         { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, precision, s)); }
-        // ConvLSTM: layers outer, time inner, zero initial state (models/video_autoencoder.py:144-166)
-        for (int l = 0; l < layers; ++l) {
-            const float* xin_l = (l == 0) ? E : HS[(l - 1) & 1];
+        // ConvLSTM, zero initial state (models/video_autoencoder.py:144-166).  Step (l, t) needs (l, t-1) and (l-1, t) only.
+        auto lstm_step = [&](int l, int ti, hipStream_t st) -> int {
+            const float* xin_l = (l == 0) ? E : HS[l - 1];
             const long long fs_in = (l == 0) ? fs_lat : fs_hid;
             const long long clip_in = (l == 0) ? (long long)cs * fs_lat : (long long)t * fs_hid;   // layer 0 reads the shared features
-            const int cin_x = (l == 0) ? latent : hid;
-            float* hs = HS[l & 1];
-            for (int ti = 0; ti < t; ++ti) {
-                VadProfScope ps(4, s);
-                TRY(vad_convlstm_step(xin_l + (size_t)ti * fs_in, clip_in,
-                                      ti ? hs + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
-                                      ti ? C : nullptr, W_(4 + l), B_(4 + l),
-                                      hs + (size_t)ti * fs_hid, (long long)t * fs_hid, C,
-                                      nc, h16, w16, cin_x, hid, precision, s));
-            }
+            VadProfScope ps(4, st);
+            return vad_convlstm_step(xin_l + (size_t)ti * fs_in, clip_in,
+                                     ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
+                                     ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l),
+                                     HS[l] + (size_t)ti * fs_hid, (long long)t * fs_hid, CS[l],
+                                     nc, h16, w16, (l == 0) ? latent : hid, hid, precision, st);
+        };
+        // Large launch groups fill the chip with one step: layers outer, time inner on the caller's stream (the reference's
+        // order).  Small ones (the reference's batch sizes; a step is then one wave's serial K loop on a fraction of the
+        // CUs) run the layers as a wavefront on helper streams.
+        const long long lstm_groups = (long long)nc * ((w16 + 15) / 16) * ((h16 + 3) / 4) * (hid / 64);
+        if (layers > 1 && lstm_groups < 256 && g_vad_lstm_wavefront.load(std::memory_order_relaxed)) {
+            VadSideStreams* S = nullptr;
+            TRY(side_streams(layers, &S));
+            VAD_HIP_TRY(hipEventRecord(S->fork, s));                          // the encoder's output is ready
+            for (int l = 1; l < layers; ++l) VAD_HIP_TRY(hipStreamWaitEvent(S->st[l - 1], S->fork, 0));
+            for (int ti = 0; ti < t; ++ti)
+                for (int l = 0; l < layers; ++l) {
+                    hipStream_t st = l ? S->st[l - 1] : s;
+                    if (l) VAD_HIP_TRY(hipStreamWaitEvent(st, S->done[l - 1], 0));     // (l-1, ti) finished
+                    TRY(lstm_step(l, ti, st));
+                    if (l + 1 < layers || ti + 1 == t) VAD_HIP_TRY(hipEventRecord(S->done[l], st));
+                }
+            for (int l = 1; l < layers; ++l) VAD_HIP_TRY(hipStreamWaitEvent(s, S->done[l], 0));   // join
+        } else {
+            for (int l = 0; l < layers; ++l)
+                for (int ti = 0; ti < t; ++ti) TRY(lstm_step(l, ti, s));
         }
-        const float* dec_in = HS[(layers - 1) & 1];
+        const float* dec_in = HS[layers - 1];
         int li = 4 + layers;
         if (L.has_proj) {   // models/video_autoencoder.py:346-349
             VadProfScope ps(5, s);

@@ -150,6 +150,7 @@ SIGNATURES = {
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_debug_set_conv_variant": (_i, [_i]),
     "vad_debug_set_tail_group": (_i, [_i]),
+    "vad_debug_set_lstm_wavefront": (_i, [_i]),
     "vad_img_score_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_score_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_score_windows_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
