@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the secondary split-precision measurement")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (row f-1)")
+    ap.add_argument("--graph", action="store_true", help="capture the step's scoring call into a hipGraph once and replay it every step (1 GPU, image / video)")
     ap.add_argument("--no-wavefront", action="store_true", help="video: ConvLSTM layers strictly one after the other (A/B of the small-batch wavefront)")
     ap.add_argument("--conv-variant", type=int, default=-1, help="vad_debug_set_conv_variant bits (A/B; 9 = never the small-grid ConvLSTM kernel)")
     ap.add_argument("--tail-group", type=int, default=0, help="frames per dec4.0 -> tail sub-group (0 = auto)")
@@ -184,6 +185,16 @@ def main():
 
     model.precision = args.precision
     n_items = per_gpu * world
+    if args.graph:
+        if world != 1 or args.workload == "dense":
+            raise SystemExit("--graph: 1 GPU, image or video workload")
+        with torch.no_grad():
+            captured = model.capture(x, scores=True) if args.workload == "image" else model.capture(x, seq=False, frame=True)
+        key = "scores" if args.workload == "image" else "frame"
+
+        def score_block(first, count):                     # noqa: F811 - one graph launch instead of the launch sequence
+            return captured.replay()[key]
+        workload += "; the call is captured into a hipGraph once and replayed (vad_graph_*)"
 
     def step():
         with torch.no_grad():
@@ -347,7 +358,7 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
     m = m.to(dev)
     x = vad.scoring.synth_frames_device(0xC0FFEE + 4, 0, clips * t, hw, hw, 3, dev).view(clips, t, 3, hw, hw)
     out = {"unit": "frames/s trained", "clips": clips, "t": t, "dtype": "f32"}
-    for precision in ("fp32", "split"):          # both start from the same weights: a fresh trainer re-reads the module
+    for precision in ("fp32", "split", "bf16"):  # all start from the same weights: a fresh trainer re-reads the module
         state = {k: v.detach().clone() for k, v in m.state_dict().items()}
         tr = vad.VideoTrainer(m, precision=precision)
         first = None
@@ -364,9 +375,12 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
         if precision == "fp32":
             out.update(res)
             out["workspace_GiB"] = round(tr._ws.numel() / 2**30, 2)
-        else:
+        elif precision == "split":
             out["split_precision"] = dict(res, arithmetic="3x3 / transposed convolutions (forward + data gradients) on split-fp16 operands, "
                                                           "everything else fp32")
+        else:
+            out["bf16_precision"] = dict(res, arithmetic="BASELINE configs[4] dtype: 3x3 / transposed convolutions (forward + data gradients) on bf16 "
+                                                         "operands with fp32 accumulation; master weights, BatchNorm, loss, weight gradients, Adam fp32")
         m.load_state_dict(state)
         del tr
     del m, x

@@ -36,6 +36,11 @@ extern "C" {
  *      fp32.  Needs |activation| < 65504.  Opt-in; gated by the same golden-vector and trained-model tests. */
 #define VAD_PREC_FP32 0
 #define VAD_PREC_SPLIT 1
+/*   VAD_PREC_BF16  bf16 operands (round to nearest even), one v_mfma_f32_32x32x16_bf16 per 16 channels, fp32 accumulate -
+ *      TRAINING ONLY (BASELINE.json configs[4] names bf16): accepted by vad_conv3x3, vad_convt2x2, vad_train_pack_* and the
+ *      vad_*_train_fwd_bwd entry points; master weights, BatchNorm, statistics, loss, weight gradients and Adam stay fp32.
+ *      8 significant bits: the scoring entry points and host packers reject it (scores would miss the 1e-4 bar by 60x). */
+#define VAD_PREC_BF16 2
 
 int vad_abi_version(void);
 const char* vad_last_error(void);   /* per thread */
@@ -236,8 +241,9 @@ int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, f
 /* ------------------------------------------------------------------ whole training step (row f-1)
  * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim,
  * lstm_num_layers) (both dims multiples of 32, hidden <= 256; `proj` is the 1x1 conv when they differ): train-mode forward (batch-statistics BatchNorm, running stats updated when `running`
- * is given), nn.MSELoss, and the full backward.  precision VAD_PREC_FP32: exact fp32; VAD_PREC_SPLIT: the 3x3 and
- * transposed convolutions (forward + data gradients) use the split-fp16 operands, the rest stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
+ * is given), nn.MSELoss, and the full backward.  precision VAD_PREC_FP32: exact fp32; VAD_PREC_SPLIT / VAD_PREC_BF16: the 3x3
+ * and transposed convolutions (forward + data gradients) use split-fp16 / bf16 operands with fp32 accumulation, the rest
+ * (first and last layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam, master weights) stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
  * floats, torch layouts in named_parameters() order (see csrc/train_step.hip); running: vad_vid_train_nstats floats,
  * {running_mean, running_var} per BatchNorm in module order.  x [B,T,3,H,W]; loss: device float[1];
  * recon (nullable) [B,T,3,H,W].  Every gradient is overwritten (no accumulation), so there is no zero_grad.
@@ -350,6 +356,18 @@ size_t vad_vid_windows_workspace_bytes(int chunk_windows, int t, int stride, int
 int vad_vid_score_windows(const float* frames, long long nframes, int t, int stride, int h, int w, int latent, int hid,
                           int layers, const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_windows,
                           float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
+
+/* ------------------------------------------------------------------ hipGraph capture / replay of a scoring call
+ * vad_graph_begin(stream); <one vad_img_score* / vad_vid_score* call on `stream`>; vad_graph_end(stream, &exec) captures
+ * the call's launch sequence (kernels, and the fork / join with the library's helper streams) into an instantiated
+ * hipGraph; vad_graph_launch(exec, stream) replays it asynchronously with the SAME device pointers (keep input, output and
+ * workspace buffers alive and write new frames into the same input buffer).  Run the call once eagerly first: the first
+ * call of a thread creates helper streams and queries occupancy, which must not happen inside a capture.  Per-layer timing
+ * is skipped while capturing.  Results are bit-identical to the eager call. */
+int vad_graph_begin(void* stream);
+int vad_graph_end(void* stream, void** exec_out);
+int vad_graph_launch(void* exec, void* stream);
+int vad_graph_destroy(void* exec);
 
 /* ------------------------------------------------------------------ per-layer timing
  * When enabled, the model-level calls bracket every layer launch with hipEvents on `stream`.

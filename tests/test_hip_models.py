@@ -335,6 +335,37 @@ def test_two_threads_with_different_precision_do_not_interfere(vad):
     assert not any(th.is_alive() for th in threads) and not errors, errors
 
 
+def test_captured_graph_replays_bit_identically(vad):
+    """hipGraph capture / replay of one scoring call (vad_graph_*, `model.capture`) at the reference's call sizes: batch 16
+    images (evaluate.py:240), 4 clips x 16 frames (evaluate_video.py:416: the small-grid ConvLSTM kernel and the two-stream
+    layer wavefront inside the capture), one window (evaluate_video.py:344).  A replay on NEW frames equals the eager call
+    on those frames, bit for bit, every time."""
+    mi, _ = _img_model(vad, 64, 3)
+    xa, xb = vad.scoring.synth_frames_device(9, 0, 16, 64, 64), vad.scoring.synth_frames_device(9, 100, 16, 64, 64)
+    with torch.no_grad():
+        g = mi.capture(xa, scores=True, errmap=True)
+        ea, eb = mi.score_all(xa), mi.score_all(xb)
+        n0 = vad.hip.calls["img_score"]
+        for _ in range(3):
+            ob = g.replay(xb)
+            assert torch.equal(ob["scores"], eb["scores"]) and torch.equal(ob["errmap"], eb["errmap"])
+        oa = g.replay(xa)
+        assert torch.equal(oa["scores"], ea["scores"]) and not torch.equal(ea["scores"], eb["scores"])
+        assert vad.hip.calls["img_score"] == n0 and vad.hip.calls["graph_replay"] >= 4      # no eager launch behind a replay
+    mv, _ = _vid_model(vad, 128, 128, 2, 5)
+    for b, t in ((4, 16), (1, 16)):
+        ca = vad.scoring.synth_frames_device(11, 0, b * t, 32, 32).view(b, t, 3, 32, 32)
+        cb = vad.scoring.synth_frames_device(11, 500, b * t, 32, 32).view(b, t, 3, 32, 32)
+        with torch.no_grad():
+            gv = mv.capture(ca, seq=True, frame=True, recon=True)
+            want = mv.score_all(cb)
+            for _ in range(3):
+                got = gv.replay(cb)
+                for k in ("seq", "frame", "recon"):
+                    assert torch.equal(got[k], want[k]), (b, t, k)
+    torch.cuda.synchronize()
+
+
 def test_blob_launched_under_the_wrong_precision_is_rejected_on_the_device(vad):
     """ABI 2 safety net: the packed blob's header carries the mode it was packed for; a launch that names another mode
     returns NaN scores (checked by the finalising kernel on the device), never a plausible wrong number."""

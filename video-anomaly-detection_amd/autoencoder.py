@@ -140,6 +140,8 @@ class ConvAutoencoder(nn.Module):
     def _packed(self, device) -> torch.Tensor:
         l = hip.lib()
         mode = hip.precision_mode(self.precision)
+        if mode == hip.PREC_BF16:
+            raise hip.VadError("precision 'bf16' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32' or 'split'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_img_packed_floats(self.in_channels, self.latent_dim)
@@ -167,7 +169,22 @@ class ConvAutoencoder(nn.Module):
             self._hip.key = None
         return super().train(mode)
 
-    def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False):
+    def capture(self, x: torch.Tensor, scores=True, errmap=False, recon=False, latent=False) -> "hip.CapturedCall":
+        """Capture ONE scoring call on a batch shaped like `x` into a hipGraph (include/vad_hip.h vad_graph_*) and return
+        the replayable call: `g = model.capture(x); out = g.replay(new_x)` copies `new_x` into the captured input buffer and
+        relaunches the whole layer sequence as one graph launch; `out` is the dict of captured output tensors (overwritten by
+        every replay), bit-identical to the eager call.  Meant for the reference's call sizes (batch 16, evaluate.py:240),
+        where the 16 launches of a call are short.  The graph reads the weights as packed NOW: capture again after
+        changing parameters."""
+        if not self._use_hip():
+            raise hip.VadError("capture is an inference entry point: call under eval() and torch.no_grad()")
+        want = dict(scores=scores, errmap=errmap, recon=recon, latent=latent)
+        xs = x.clone()
+        eager = self._run_hip(xs, **want)                 # packs weights, sizes the workspace, creates helper state
+        out = {k: torch.empty_like(v) for k, v in eager.items()}
+        return hip.CapturedCall(lambda: self._run_hip(xs, out=out, **want), xs, out, keep=(self._hip.packed, self._hip.ws))
+
+    def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False, out=None):
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,H,W,3]: normalised inside the kernels (row f-3)
         if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != 3:
             raise hip.VadError(f"expected float input [B,3,H,W] or uint8 input [B,H,W,3], got {x.dtype} {tuple(x.shape)}")
@@ -189,15 +206,16 @@ class ConvAutoencoder(nn.Module):
         if nbytes == 0:
             raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
         ws = self._hip.workspace(nbytes, dev)
-        out = {}
-        if scores:
-            out["scores"] = torch.empty(b, dtype=torch.float32, device=dev)
-        if errmap:
-            out["errmap"] = torch.empty(b, 1, h, w, dtype=torch.float32, device=dev)
-        if recon:
-            out["recon"] = torch.empty(b, 3, h, w, dtype=torch.float32, device=dev)
-        if latent:
-            out["latent"] = torch.empty(b, self.latent_dim, h // 16, w // 16, dtype=torch.float32, device=dev)
+        if out is None:                                   # (a captured call hands in its own output tensors)
+            out = {}
+            if scores:
+                out["scores"] = torch.empty(b, dtype=torch.float32, device=dev)
+            if errmap:
+                out["errmap"] = torch.empty(b, 1, h, w, dtype=torch.float32, device=dev)
+            if recon:
+                out["recon"] = torch.empty(b, 3, h, w, dtype=torch.float32, device=dev)
+            if latent:
+                out["latent"] = torch.empty(b, self.latent_dim, h // 16, w // 16, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             hip.check(l.vad_img_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, h, w,
                                         self.latent_dim, packed.data_ptr(), ws.data_ptr(),

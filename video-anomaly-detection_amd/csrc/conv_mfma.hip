@@ -277,7 +277,7 @@ struct ConvKnobs {
         variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; no_small = (b >> 3) & 1;
     }
 };
-#define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, who ": precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision)
+#define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT || precision == VAD_PREC_BF16, who ": precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1) or VAD_PREC_BF16 (2)", precision)
 
 template <typename K>
 static unsigned persistent_grid(K kernel, unsigned nblocks, int max_per_cu = 2) {
@@ -321,6 +321,17 @@ static void launch_conv3_act(const Conv3P& p, hipStream_t s, int precision, int 
         q.stagger = kn.stagger;   // debug (variant bit 1): zero-sized weight descriptor = price the weight traffic
         hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
         return;
+    }
+    if constexpr (MODE != MODE_LSTM) {   // bf16 operands (training convolutions; the ConvLSTM step is not offered in bf16)
+        if (precision == VAD_PREC_BF16) {
+            static std::atomic<unsigned> grid_cap2{0};
+            unsigned cap = grid_cap2.load(std::memory_order_relaxed);
+            if (!cap) grid_cap2 = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 2>, ~0u);
+            Conv3P q = p;
+            q.dbg = g_vad_dbg;
+            hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 2>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
+            return;
+        }
     }
     if (variant == 0) {
         hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(p.nblocks), dim3(256), 0, s, p);
@@ -375,8 +386,8 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
     p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.hid = 0;
     hipStream_t s = (hipStream_t)stream;
 #define L3(CK, MT, NT, WM, WN, MODE) launch_conv3<CK, MT, NT, WM, WN, MODE>(p, n, act, s, precision, kn.variant, kn)
-    if (precision == VAD_PREC_SPLIT) {
-        // split-fp16 operands double the accumulators (main + cross terms): keep one N-tile per wave
+    if (precision != VAD_PREC_FP32) {
+        // split-fp16 operands double the accumulators (main + cross terms): keep one N-tile per wave (bf16 shares the tilings)
         if (cout % 128 == 0 && !kn.conv64)   // one B fragment per 4 M-tiles: halves the weight traffic through L1
             return pool ? L3(32, 4, 1, 1, 4, MODE_POOL) : L3(32, 4, 1, 1, 4, MODE_PLAIN);
         if (cout % 64 == 0)
@@ -409,7 +420,7 @@ extern "C" int vad_conv3x3_c3_fused(const float* x, const float* w0, const float
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1,
                              const float* b1, float* out, int n, int h, int wd, int precision, void* stream) {
     VAD_REQUIRE(x && w0 && b0 && w1 && b1 && out, "conv3x3_c3_fused: null pointer");
-    VAD_REQUIRE_PREC("conv3x3_c3_fused");
+    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "conv3x3_c3_fused: precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision);
     const ConvKnobs kn;
     VAD_REQUIRE(fmt == VAD_X_F32_NCHW || (fmt == VAD_X_U8_NHWC && (kn.variant != 0 || precision == VAD_PREC_SPLIT)),
                 "conv3x3_c3_fused: input format %d unsupported (uint8 input needs the persistent kernel)", fmt);
@@ -451,7 +462,7 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
                                  const float* w, const float* bias, float* h_out, long long h_out_fs,
                                  float* c_out, int n, int h, int wd, int cin_x, int hid, int precision, void* stream) {
     VAD_REQUIRE(x && w && bias && h_out && c_out, "convlstm_step: null pointer");
-    VAD_REQUIRE_PREC("convlstm_step");
+    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "convlstm_step: precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision);
     VAD_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), "convlstm_step: h_prev and c_prev must both be given or both NULL");
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "convlstm_step: bad shape");
     VAD_REQUIRE(cin_x % 32 == 0 && hid % 64 == 0 && cin_x > 0 && hid > 0,
@@ -904,7 +915,7 @@ extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, co
     ConvTP2 q{};
     q.in = p.in; q.in_fs = p.in_fs; q.w = w; q.bias = bias; q.out = out; q.out_fs = p.out_fs;
     q.n = n; q.h = h; q.w_ = wd; q.cin = cin; q.cout = cout;
-    const int prec = precision == VAD_PREC_SPLIT;    // split-fp16 operands: two accumulator sets, so half the columns per wave
+    const int prec = precision;                      // split-fp16 operands: two accumulator sets, so half the columns per wave (bf16 shares the tiling)
     // wave tile 2 x 4 (exact) measured best of {2x4, 1x4, 2x2, 1x2}: dec4.0 2.18 / 2.47 / 2.28 / 2.78 us per frame
     const int mt = 2, nt = prec ? 2 : 4;
     q.tiles_x = (wd + 15) / 16; q.tiles_y = (h + 2 * mt - 1) / (2 * mt);
@@ -922,7 +933,8 @@ extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, co
     }
 #define CT_LAUNCH(A)                                                                                         \
     {                                                                                                        \
-        if (prec) CT_LAUNCH_(A, 2, 2, 1)                                                                     \
+        if (prec == VAD_PREC_SPLIT) CT_LAUNCH_(A, 2, 2, 1)                                                   \
+        else if (prec == VAD_PREC_BF16) CT_LAUNCH_(A, 2, 2, 2)                                               \
         else CT_LAUNCH_(A, 2, 4, 0)                                                                          \
     }
     if (act == VAD_ACT_RELU) CT_LAUNCH(VAD_ACT_RELU)

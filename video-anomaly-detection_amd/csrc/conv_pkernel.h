@@ -55,12 +55,39 @@ __device__ __forceinline__ void vad_split(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
-// store one activation (channel ch of the pixel whose tile float offset is pixoff): fp32, or its (hi, lo) fp16 pair
+// PREC 2 (training only): bf16 operands, ONE v_mfma_f32_32x32x16_bf16 per step, fp32 accumulate.  It rides on the
+// split-fp16 data path: the same [8 x hi | 8 x lo] 16-bit slots per 8-channel block, with hi = the bf16 bit pattern of v
+// (round to nearest even) and the lo slots unused, so staging, fragment loads and the packed-weight layout are shared and
+// only the conversion and the MFMA differ.  8 significant bits: no score-parity claim, gated by the loss-curve test.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMAB16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+template <int PREC>
+__device__ __forceinline__ void vad_split_p(float v, _Float16& hi, _Float16& lo) {
+    if constexpr (PREC == 2) {
+        hi = __builtin_bit_cast(_Float16, (__bf16)v);
+        lo = (_Float16)0.f;
+    } else {
+        vad_split(v, hi, lo);
+    }
+}
+// one k-step of 16 channels for one (M-tile, N-tile) pair
+template <int PREC>
+__device__ __forceinline__ void vad_mma16(f32x16& acc, f32x16& corr, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
+    if constexpr (PREC == 2) {
+        acc = MFMAB16(ah, bh, acc);
+    } else {
+        acc = MFMA16(ah, bh, acc);
+        corr = MFMA16(ah, bl, corr);
+        corr = MFMA16(al, bh, corr);
+    }
+}
+
+// store one activation (channel ch of the pixel whose tile float offset is pixoff): fp32, or its (hi, lo) 16-bit pair
 template <int PREC>
 __device__ __forceinline__ void tile_put_t(float* tile, int pixoff_plus_ch, int ch, float v) {
     if constexpr (PREC) {
         _Float16 hi, lo;
-        vad_split(v, hi, lo);
+        vad_split_p<PREC>(v, hi, lo);
         _Float16* blk = (_Float16*)&tile[pixoff_plus_ch - ch + (ch >> 3) * 8];   // 8-channel block = 32 bytes = 8 floats
         blk[ch & 7] = hi;
         blk[8 + (ch & 7)] = lo;
@@ -88,7 +115,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     constexpr int NS = 9 * (CK / KS);
     // B (weight) fragments come from L2 and are requested PB steps ahead into a ring of NB register sets; the fp16
     // steps are 5x shorter than the fp32 ones, so they need the deeper prefetch to cover an L2 round trip.
-    constexpr int PB = (PREC && NT <= 2) ? 2 : 1, NB = PB + 1;
+    constexpr int PB = (PREC == 2) ? 5 : (PREC && NT <= 2) ? 2 : 1, NB = PB + 1;   // bf16 steps are a third of the split ones again
     static_assert(NS % 2 == 0 && NS % NB == 0, "fragment ring parity must be the same in every chunk");
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
     __shared__ float xin[FUSE_C3 ? 3 * XH * XS : 1];
@@ -279,8 +306,8 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 
     while (true) {
         f32x16 acc[MT][NT];
-        f32x16 corr[PREC ? MT : 1][PREC ? NT : 1];   // PREC 1: sum of the cross terms, scaled by 2^11
-        if constexpr (PREC) {
+        f32x16 corr[PREC == 1 ? MT : 1][PREC == 1 ? NT : 1];   // PREC 1: sum of the cross terms, scaled by 2^11
+        if constexpr (PREC == 1) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                             const f32x4 v = pf_get_v(pf[i]);
                             f16x4 hi, lo;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { _Float16 h_, l_; vad_split(v[e], h_, l_); hi[e] = h_; lo[e] = l_; }
+                            for (int e = 0; e < 4; ++e) { _Float16 h_, l_; vad_split_p<PREC>(v[e], h_, l_); hi[e] = h_; lo[e] = l_; }
                             float* blk = &tile[(tid >> 3) * PS + i * 32 * PS + (c4 >> 1) * 8 + (c4 & 1) * 2];
                             *(f16x4*)blk = hi;
                             *(f16x4*)(blk + 4) = lo;
@@ -458,21 +485,15 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #pragma unroll
                     for (int mt = 0; mt < MH; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            acc[mt][nt] = MFMA16(ah[0][mt], bh[bcur][nt], acc[mt][nt]);
-                            corr[mt][nt] = MFMA16(ah[0][mt], bl[bcur][nt], corr[mt][nt]);
-                            corr[mt][nt] = MFMA16(al[0][mt], bh[bcur][nt], corr[mt][nt]);
-                        }
+                        for (int nt = 0; nt < NT; ++nt)
+                            vad_mma16<PREC>(acc[mt][nt], corr[PREC == 1 ? mt : 0][PREC == 1 ? nt : 0], ah[0][mt], al[0][mt], bh[bcur][nt], bl[bcur][nt]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (s + 1 < NS) LOAD_A_HALF(s + 1, 0, MH);
 #pragma unroll
                     for (int mt = MH; mt < MT; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            acc[mt][nt] = MFMA16(ah[0][mt], bh[bcur][nt], acc[mt][nt]);
-                            corr[mt][nt] = MFMA16(ah[0][mt], bl[bcur][nt], corr[mt][nt]);
-                            corr[mt][nt] = MFMA16(al[0][mt], bh[bcur][nt], corr[mt][nt]);
-                        }
+                        for (int nt = 0; nt < NT; ++nt)
+                            vad_mma16<PREC>(acc[mt][nt], corr[PREC == 1 ? mt : 0][PREC == 1 ? nt : 0], ah[0][mt], al[0][mt], bh[bcur][nt], bl[bcur][nt]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (s + 1 < NS) LOAD_A_HALF(s + 1, MH, MT);
                 }
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
             }
             STAMP(5);
         }
-        if constexpr (PREC) {
+        if constexpr (PREC == 1) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

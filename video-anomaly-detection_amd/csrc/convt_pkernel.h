@@ -26,7 +26,7 @@ struct ConvTP2 {
 };
 
 template <int MT, int NT, int ACT, int PREC>
-__global__ __launch_bounds__(256, (MT * NT * (PREC ? 2 : 1) <= 4) ? 4 : 2) void convt2x2_pkernel(ConvTP2 p) {
+__global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) void convt2x2_pkernel(ConvTP2 p) {
     constexpr int KS = PREC ? 16 : 8;
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const unsigned gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC ? 2 : 1) <= 4) ? 4 : 2) void 
         }
         unsigned bo[NT];
         int qd[NT], co[NT];
-        f32x16 acc[MT][NT], corr[PREC ? MT : 1][PREC ? NT : 1];
+        f32x16 acc[MT][NT], corr[PREC == 1 ? MT : 1][PREC == 1 ? NT : 1];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int g = ng * NT + nt;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC ? 2 : 1) <= 4) ? 4 : 2) void 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[mt][nt][r] = bv;
-                    if constexpr (PREC) corr[mt][nt][r] = 0.f;
+                    if constexpr (PREC == 1) corr[mt][nt][r] = 0.f;
                 }
         }
 
@@ -102,26 +102,25 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC ? 2 : 1) <= 4) ? 4 : 2) void 
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 _Float16 h_, l_;
-                                vad_split(a0[u][mt][e], h_, l_); ah[e] = h_; al[e] = l_;
-                                vad_split(a1[u][mt][e], h_, l_); ah[4 + e] = h_; al[4 + e] = l_;
+                                vad_split_p<PREC>(a0[u][mt][e], h_, l_); ah[e] = h_; al[e] = l_;
+                                vad_split_p<PREC>(a1[u][mt][e], h_, l_); ah[4 + e] = h_; al[4 + e] = l_;
                             }
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-                                acc[mt][nt] = MFMA16(ah, bh[u][nt], acc[mt][nt]);
-                                corr[mt][nt] = MFMA16(ah, bl[u][nt], corr[mt][nt]);
-                                corr[mt][nt] = MFMA16(al, bh[u][nt], corr[mt][nt]);
-                            }
+                            for (int nt = 0; nt < NT; ++nt)
+                                vad_mma16<PREC>(acc[mt][nt], corr[PREC == 1 ? mt : 0][PREC == 1 ? nt : 0], ah, al, bh[u][nt], bl[u][nt]);
                         }
                     }
                 }
             }
 #undef CT_LOAD
+            if constexpr (PREC == 1) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(corr[mt][nt][r], 0x1p-11f, acc[mt][nt][r]);
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(corr[mt][nt][r], 0x1p-11f, acc[mt][nt][r]);
+            }
         } else {
             f32x4 a[2][MT], b[2][NT];
 #define CT_LOAD(buf, ks)                                                                          \

@@ -653,8 +653,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 // torch layouts -> the kernels' MFMA operand orders, on the device (the parameters change every step)
 // split != 0: the split-fp16 operand form of the same weights (csrc/pack.cpp, conv_pkernel.h): per 16 input channels and
 // output channel, two halves h of [8 x hi | 8 x lo] fp16 with hi = fp16(w), lo = fp16((w - hi) * 2^11); same byte count.
-__device__ __forceinline__ void put_split(float* dst, size_t group16, int k, float v) {      // k = channel index inside the 16
+// split == 2: bf16 operands in the same slots: hi = bf16(w), lo unused (conv_pkernel.h, PREC 2)
+__device__ __forceinline__ void put_split(float* dst, size_t group16, int k, float v, int mode) {      // k = channel index inside the 16
     _Float16* o = (_Float16*)dst + (group16 * 2 + ((k >> 3) & 1)) * 16;
+    if (mode == 2) {
+        o[k & 7] = __builtin_bit_cast(_Float16, (__bf16)v);
+        o[8 + (k & 7)] = (_Float16)0.f;
+        return;
+    }
     const _Float16 hi = (_Float16)v;
     o[k & 7] = hi;
     o[8 + (k & 7)] = (_Float16)((v - (float)hi) * 2048.0f);
@@ -667,8 +673,8 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* w, int c
         const float v = w[idx];
         // data gradient = the same convolution with the taps rotated by 180 degrees and the channel roles swapped
         if (split) {
-            if (fwd) put_split(fwd, ((size_t)tap * (cin / 16) + ci / 16) * cout + co, ci & 15, v);
-            if (dgrad) put_split(dgrad, ((size_t)(8 - tap) * (cout / 16) + co / 16) * cin + ci, co & 15, v);
+            if (fwd) put_split(fwd, ((size_t)tap * (cin / 16) + ci / 16) * cout + co, ci & 15, v, split);
+            if (dgrad) put_split(dgrad, ((size_t)(8 - tap) * (cout / 16) + co / 16) * cin + ci, co & 15, v, split);
         } else {
             if (fwd) fwd[(((size_t)tap * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
             if (dgrad) dgrad[(((size_t)(8 - tap) * (cout / 8) + co / 8) * cin + ci) * 8 + (co & 7)] = v;
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int 
         const int q = (int)(idx & 3), co = (int)((idx >> 2) % cout), ci = (int)(idx / (4ll * cout));
         const float v = w[idx];
         if (fwd) {
-            if (split) put_split(fwd, ((size_t)q * (cin / 16) + ci / 16) * cout + co, ci & 15, v);
+            if (split) put_split(fwd, ((size_t)q * (cin / 16) + ci / 16) * cout + co, ci & 15, v, split);
             else fwd[(((size_t)q * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = v;
         }
         // data gradient = 1x1 convolution over the space-to-depth gradient (K index q*cout+co, N index ci); that GEMM
@@ -1028,8 +1034,8 @@ extern "C" int vad_adam_step(float* p, const float* g, float* m, float* v, long 
 
 extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv3x3: bad arguments");
-    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "train_pack_conv3x3: precision=%d must be 0 (fp32) or 1 (split fp16)", precision);
-    const int split = precision == VAD_PREC_SPLIT;    // the packed layout follows the arithmetic mode, like the host packers
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "train_pack_conv3x3: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
+    const int split = precision;                      // the packed layout follows the arithmetic mode, like the host packers (2 = bf16 in the hi slots)
     VAD_REQUIRE(!split || (cin % 16 == 0 && (!dgrad || cout % 16 == 0)), "train_pack_conv3x3: split precision needs channel counts in multiples of 16");
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(9ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad, split);
     VAD_LAUNCH_CHECK();
@@ -1038,8 +1044,8 @@ extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, fl
 
 extern "C" int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_iohw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || (4 * cout) % 8 == 0), "train_pack_convt2x2: bad arguments");
-    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "train_pack_convt2x2: precision=%d must be 0 (fp32) or 1 (split fp16)", precision);
-    const int split = precision == VAD_PREC_SPLIT;
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "train_pack_convt2x2: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
+    const int split = precision;
     VAD_REQUIRE(!split || cin % 16 == 0, "train_pack_convt2x2: split precision needs cin in multiples of 16");
     hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad, split);
     VAD_LAUNCH_CHECK();

@@ -221,7 +221,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
                                      const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
                                      int precision, float* loss, float* recon, void* stream) {
     VAD_REQUIRE(x && params && grads && workspace && loss, "vid_train_fwd_bwd: null pointer");
-    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "vid_train_fwd_bwd: precision=%d must be 0 (fp32) or 1 (split fp16)", precision);
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "vid_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
     // Arithmetic mode (argument `precision`): 0 = exact fp32 everywhere (the parity path); 1 = the 3x3 and transposed
     // convolutions (forward and data gradients) take split-fp16 operands (22-bit products, fp32 accumulate), everything
     // else - first layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam - stays fp32.

@@ -145,7 +145,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
     VAD_REQUIRE(x && params && grads && workspace && loss, "img_train_fwd_bwd: null pointer");
     // precision VAD_PREC_SPLIT: the 3x3 / transposed convolutions (forward + data gradients) on split-fp16 operands, as in
     // the video step; first layer, last layer, weight gradients, BatchNorm, criterion and Adam stay fp32
-    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "img_train_fwd_bwd: precision=%d must be 0 (fp32) or 1 (split fp16)", precision);
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "img_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
     VAD_REQUIRE(loss_kind >= 0 && loss_kind <= 2, "img_train_fwd_bwd: loss_kind must be 0 (mse), 1 (ssim) or 2 (combined)");
     ImgPlan p;
     VAD_REQUIRE(make_plan(p, n, h, w, latent), "img_train_fwd_bwd: unsupported configuration (N=%d %dx%d latent=%d): H, W multiples "

@@ -33,6 +33,8 @@ hipEvent_t prof_event() {         // g_prof_mu held
 
 VadProfScope::VadProfScope(int slot_, hipStream_t stream_) : slot(-1), stream(stream_), end(nullptr) {
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;     // timing events have no place inside a captured graph
+    if (hipStreamIsCapturing(stream_, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
     hipEvent_t a, b;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -79,6 +81,38 @@ extern "C" const char* vad_prof_slot_name(int model, int slot) {
 }
 
 #define TRY(call) do { int rc_ = (call); if (rc_ != VAD_OK) return rc_; } while (0)
+
+// ------------------------------------------------------------------------------ hipGraph capture / replay
+// The scoring entry points only launch kernels (and record / wait events between `stream` and the library's helper
+// streams), so ONE call can be captured into a hipGraph and replayed: at the reference's call sizes (batch 16 images,
+// evaluate.py:240; 4 clips x 16 frames, evaluate_video.py:416; one window, evaluate_video.py:344) a call is 16-45 short
+// launches and the host-side launch cost is a visible part of it.
+extern "C" int vad_graph_begin(void* stream) {
+    VAD_HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return VAD_OK;
+}
+extern "C" int vad_graph_end(void* stream, void** exec_out) {
+    VAD_REQUIRE(exec_out, "graph_end: null pointer");
+    *exec_out = nullptr;
+    hipGraph_t graph = nullptr;
+    VAD_HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &graph));
+    VAD_REQUIRE(graph, "graph_end: the capture produced no graph (was it invalidated by a synchronising call?)");
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return vad_fail(VAD_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    *exec_out = (void*)exec;
+    return VAD_OK;
+}
+extern "C" int vad_graph_launch(void* exec, void* stream) {
+    VAD_REQUIRE(exec, "graph_launch: null graph");
+    VAD_HIP_TRY(hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream));
+    return VAD_OK;
+}
+extern "C" int vad_graph_destroy(void* exec) {
+    if (exec) VAD_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)exec));
+    return VAD_OK;
+}
 
 static std::atomic<int> g_vad_tail_group{0};   // debug: frames per dec4.0 -> tail sub-group (0 = the whole launch group)
 extern "C" int vad_debug_set_tail_group(int frames) { g_vad_tail_group = frames; return VAD_OK; }

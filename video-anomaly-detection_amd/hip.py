@@ -20,8 +20,8 @@ SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step
 
 VAD_OK = 0
 ABI_VERSION = 2
-PREC_FP32, PREC_SPLIT = 0, 1
-PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT}
+PREC_FP32, PREC_SPLIT, PREC_BF16 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16}     # bf16: training entry points only
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 X_F32_NCHW, X_U8_NHWC = 0, 1
 PROF_SLOTS = 32
@@ -157,6 +157,10 @@ SIGNATURES = {
     "vad_vid_num_windows": (_ll, [_ll, _i, _i]),
     "vad_vid_windows_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "vad_vid_score_windows": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_graph_begin": (_i, [_vp]),
+    "vad_graph_end": (_i, [_vp, C.POINTER(_vp)]),
+    "vad_graph_launch": (_i, [_vp, _vp]),
+    "vad_graph_destroy": (_i, [_vp]),
     "vad_prof_enable": (_i, [_i]),
     "vad_prof_reset": (_i, []),
     "vad_prof_read": (_i, [_vp, _vp]),
@@ -194,6 +198,45 @@ def check(rc: int, what: str = "") -> None:
     if rc != VAD_OK:
         msg = lib().vad_last_error().decode("utf-8", "replace")
         raise VadError(f"{what or 'libvad_hip'} failed (code {rc}): {msg}")
+
+
+class CapturedCall:
+    """One scoring call captured into a hipGraph (vad_graph_*): `replay()` relaunches it on the current stream with the
+    same buffers; `outputs` are the tensors it writes.  Built by `model.capture(...)`."""
+
+    def __init__(self, run, inputs, outputs, keep):
+        import torch
+        self.inputs, self.outputs, self._keep = inputs, outputs, keep
+        self._exec = _vp()
+        l = lib()
+        side = torch.cuda.Stream()                       # capture on a side stream, never on the legacy default stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            check(l.vad_graph_begin(side.cuda_stream), "vad_graph_begin")
+            try:
+                run()
+            finally:
+                rc = l.vad_graph_end(side.cuda_stream, C.byref(self._exec))
+            check(rc, "vad_graph_end")
+        torch.cuda.current_stream().wait_stream(side)
+        calls["graph_capture"] = calls.get("graph_capture", 0) + 1
+
+    def replay(self, x=None):
+        """Relaunch; with `x` given its contents are first copied into the captured input buffer."""
+        if x is not None:
+            self.inputs.copy_(x)
+        check(lib().vad_graph_launch(self._exec, current_stream()), "vad_graph_launch")
+        calls["graph_replay"] = calls.get("graph_replay", 0) + 1
+        return self.outputs
+
+    __call__ = replay
+
+    def __del__(self):
+        try:
+            if self._exec:
+                lib().vad_graph_destroy(self._exec)
+        except Exception:                                 # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 def ptr(t) -> int:

@@ -206,10 +206,12 @@ class VideoTrainer(_FlatTrainer):
     def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
                  eps: float = 1e-8, process_group=None, precision: str = "fp32"):
         self._check_model(model, VideoAutoencoder, "VideoTrainer")
-        if precision not in ("fp32", "split"):
-            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
+        if precision not in ("fp32", "split", "bf16"):
+            raise hip.VadError(f"precision must be 'fp32', 'split' or 'bf16', got {precision!r}")
         #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
-        #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32
+        #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32.
+        #: "bf16" (BASELINE.json configs[4]): the same convolutions on bf16 operands (8-bit significands, fp32 accumulate),
+        #: fp32 master weights / BatchNorm / loss / weight gradients / Adam; gated by loss-curve agreement, not parity
         self.precision = precision
         l = hip.lib()
         self.cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
@@ -251,8 +253,8 @@ class ImageTrainer(_FlatTrainer):
                  process_group=None, loss: str = "mse", ssim_weight: float = 0.5, window_size: int = 11, precision: str = "fp32"):
         from .autoencoder import ConvAutoencoder
         self._check_model(model, ConvAutoencoder, "ImageTrainer")
-        if precision not in ("fp32", "split"):
-            raise hip.VadError(f"precision must be 'fp32' or 'split', got {precision!r}")
+        if precision not in ("fp32", "split", "bf16"):
+            raise hip.VadError(f"precision must be 'fp32', 'split' or 'bf16', got {precision!r}")
         self.precision = precision
         if loss not in self._KINDS:
             raise hip.VadError(f"loss must be one of {sorted(self._KINDS)}, got {loss!r}")

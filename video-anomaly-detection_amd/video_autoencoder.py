@@ -152,6 +152,8 @@ class VideoAutoencoder(nn.Module):
     def _packed(self, device) -> torch.Tensor:
         l = hip.lib()
         mode = hip.precision_mode(self.precision)
+        if mode == hip.PREC_BF16:
+            raise hip.VadError("precision 'bf16' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32' or 'split'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
@@ -179,7 +181,20 @@ class VideoAutoencoder(nn.Module):
             self._hip.key = None
         return super().train(mode)
 
-    def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False):
+    def capture(self, x: torch.Tensor, seq=True, frame=True, errmap=False, recon=False) -> "hip.CapturedCall":
+        """Capture ONE scoring call on clips shaped like `x` into a hipGraph and return the replayable call (see
+        ConvAutoencoder.capture).  At the reference's sizes (4 clips x 16 frames, evaluate_video.py:416; one window,
+        evaluate_video.py:344) a call is ~45 short launches on two streams (the ConvLSTM layer wavefront is captured with
+        its fork / join); replaying them as one graph removes the per-launch host cost."""
+        if not self._use_hip():
+            raise hip.VadError("capture is an inference entry point: call under eval() and torch.no_grad()")
+        want = dict(seq=seq, frame=frame, errmap=errmap, recon=recon)
+        xs = x.clone()
+        eager = self._run_hip(xs, **want)
+        out = {k: torch.empty_like(v) for k, v in eager.items()}
+        return hip.CapturedCall(lambda: self._run_hip(xs, out=out, **want), xs, out, keep=(self._hip.packed, self._hip.ws))
+
+    def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False, out=None):
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,T,H,W,3]: normalised inside the kernels (row f-3)
         if x.dim() != 5 or (x.shape[4] if u8 else x.shape[2]) != 3:
             raise hip.VadError(f"expected float input [B,T,3,H,W] or uint8 input [B,T,H,W,3], got {x.dtype} {tuple(x.shape)}")
@@ -202,15 +217,16 @@ class VideoAutoencoder(nn.Module):
         if nbytes == 0:
             raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
         ws = self._hip.workspace(nbytes, dev)
-        out = {}
-        if seq:
-            out["seq"] = torch.empty(b, dtype=torch.float32, device=dev)
-        if frame:
-            out["frame"] = torch.empty(b, t, dtype=torch.float32, device=dev)
-        if errmap:
-            out["errmap"] = torch.empty(b, t, 1, h, w, dtype=torch.float32, device=dev)
-        if recon:
-            out["recon"] = torch.empty(b, t, 3, h, w, dtype=torch.float32, device=dev)
+        if out is None:                                   # (a captured call hands in its own output tensors)
+            out = {}
+            if seq:
+                out["seq"] = torch.empty(b, dtype=torch.float32, device=dev)
+            if frame:
+                out["frame"] = torch.empty(b, t, dtype=torch.float32, device=dev)
+            if errmap:
+                out["errmap"] = torch.empty(b, t, 1, h, w, dtype=torch.float32, device=dev)
+            if recon:
+                out["recon"] = torch.empty(b, t, 3, h, w, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             hip.check(l.vad_vid_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, t, h, w, *dims,
                                         packed.data_ptr(), ws.data_ptr(), ws.numel(),
