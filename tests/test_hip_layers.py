@@ -66,6 +66,13 @@ def test_conv3x3_c3_fused(h, w):
     got = H.conv3x3_c3_fused(x, w0, b0, bn0, w1, b1, bn1)
     assert got.shape == ref.shape and np.isfinite(got).all()
     assert max_abs(got, ref) < ATOL
+    l = H.hip.lib()                       # persistent kernel == one-tile-per-work-group kernel, bit for bit
+    try:
+        l.vad_debug_set_conv_variant(0)
+        one_tile = H.conv3x3_c3_fused(x, w0, b0, bn0, w1, b1, bn1)
+    finally:
+        l.vad_debug_set_conv_variant(1)
+    assert np.array_equal(got, one_tile)
 
 
 def test_conv3x3_no_bn_and_frame_strides():
