@@ -20,6 +20,7 @@ struct TailP {
     int tiles_x, tiles_y;
     int xt, xs;           // x frame of activation frame n is (n / xt) * xs + n % xt (xt == 0: n)
     int xu8;              // x is uint8 NHWC [N,H2,W2,3]
+    unsigned nitems;      // convT tail: n * h * tiles_x wave items
 };
 
 // original-input value of (frame nx, channel c, pixel y,x)
@@ -187,70 +188,84 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
     block_partial(esum, red, &p.partials[(size_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx]);
 }
 
+// ConvTranspose2d(32->3, k2, s2) + Tanh + error: a 32 -> 12 GEMV per input pixel (12 = 3 channels x 2x2 output pixels), no
+// reuse between pixels - so no LDS and no barrier.  One WAVE owns 64 consecutive input pixels of one row: a lane reads its
+// pixel's 32 channels (128 B, eight 16-byte loads) and the 12 original-input values it is scored against (float2 per
+// channel and output row) all up front, so both streams are in flight together and the other resident waves (no LDS:
+// occupancy is set by registers only) cover their latency; weights and bias are wave-uniform scalar operands.  The first
+// version staged an 8x32-pixel tile through LDS behind a barrier, one thread per pixel, and issued the x loads only after
+// the 384 FMAs: 2.26 TB/s of algorithmic bytes (1.27 us per 256x256 frame).  Per-(row, segment) sums go to `partials`
+// (h * ceil(w/64) per frame); score_finalize_kernel adds them in a fixed order.
 template <int CIN>
 __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
-    constexpr int TH = 8, TW = 32, PS = CIN + 4;
-    __shared__ __attribute__((aligned(16))) float tile[TH * TW * PS];
-    __shared__ float red[4];
-    const int tid = threadIdx.x;
-    unsigned L = blockIdx.x;
-    const int tx = L % p.tiles_x; L /= p.tiles_x;
-    const int ty = L % p.tiles_y;
-    const int n = L / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const int nx = p.xt ? (n / p.xt) * p.xs + n % p.xt : n;   // source frame this activation frame is scored against
-    const float* src = p.in + (size_t)n * p.h * p.w_ * CIN;
-    for (int idx = tid; idx < TH * TW * (CIN / 4); idx += 256) {
-        const int c4 = idx % (CIN / 4), pix = idx / (CIN / 4);
-        const int gy = y0 + pix / TW, gx = x0 + pix % TW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy < p.h && gx < p.w_) v = *(const f32x4*)(src + ((size_t)gy * p.w_ + gx) * CIN + c4 * 4);
-        *(f32x4*)&tile[pix * PS + c4 * 4] = v;
+    static_assert(CIN == 32, "eight 16-byte loads per pixel");
+    const int lane = threadIdx.x & 63;
+    const unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (item >= p.nitems) return;                                   // wave-uniform
+    const int segs = p.tiles_x, H = p.h, W = p.w_;
+    unsigned r = item;
+    const int sx = r % segs; r /= segs;
+    const int y = r % H;
+    const int n = r / H;
+    const int x = sx * 64 + lane;
+    const bool ok = x < W;
+    const int nx = p.xt ? (n / p.xt) * p.xs + n % p.xt : n;         // source frame this activation frame is scored against
+    const int h2 = 2 * H, w2 = 2 * W;
+    const size_t plane = (size_t)h2 * w2;
+
+    f32x4 a[CIN / 4];
+    const f32x4* src = (const f32x4*)(p.in + (((size_t)n * H + y) * W + (ok ? x : 0)) * CIN);
+#pragma unroll
+    for (int c4 = 0; c4 < CIN / 4; ++c4) a[c4] = src[c4];
+    float2 xv[2][3];
+    if (!p.xu8) {
+        const float* xs = p.x + (size_t)nx * 3 * plane + (size_t)(2 * y) * w2 + 2 * (ok ? x : 0);
+#pragma unroll
+        for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+            for (int co = 0; co < 3; ++co) xv[ra][co] = *(const float2*)(xs + co * plane + (size_t)ra * w2);
+    } else {
+#pragma unroll
+        for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+                xv[ra][co] = make_float2(tail_x(p, nx, co, 2 * y + ra, 2 * (ok ? x : 0), h2, w2), tail_x(p, nx, co, 2 * y + ra, 2 * (ok ? x : 0) + 1, h2, w2));
     }
-    __syncthreads();
 
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = p.bias[k >> 2];
-    const float* row = &tile[tid * PS];
 #pragma unroll
     for (int c4 = 0; c4 < CIN / 4; ++c4) {
-        const f32x4 a = *(const f32x4*)(row + c4 * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float* wr = p.w + (c4 * 4 + j) * 12;   // IOHW row: (co, a, b), wave-uniform
 #pragma unroll
-            for (int k = 0; k < 12; ++k) acc[k] = fmaf(a[j], wr[k], acc[k]);
+            for (int k = 0; k < 12; ++k) acc[k] = fmaf(a[c4][j], wr[k], acc[k]);
         }
     }
-    const int y = y0 + tid / TW, x = x0 + tid % TW;
     float e = 0.f;
-    if (y < p.h && x < p.w_) {
-        const int h2 = 2 * p.h, w2 = 2 * p.w_;
-        const size_t plane = (size_t)h2 * w2;
+    if (ok) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int ra = 0; ra < 2; ++ra) {
             float ea[2] = {0.f, 0.f};
-            const size_t o = (size_t)n * 3 * plane + (size_t)(2 * y + a) * w2 + 2 * x;
-            const size_t ox = (size_t)nx * 3 * plane + (size_t)(2 * y + a) * w2 + 2 * x;
+            const size_t o = (size_t)n * 3 * plane + (size_t)(2 * y + ra) * w2 + 2 * x;
 #pragma unroll
             for (int co = 0; co < 3; ++co) {
-                float2 xv;
-                if (p.xu8) xv = make_float2(tail_x(p, nx, co, 2 * y + a, 2 * x, h2, w2), tail_x(p, nx, co, 2 * y + a, 2 * x + 1, h2, w2));
-                else xv = *(const float2*)(p.x + ox + co * plane);
-                const float r0 = vad_tanh(acc[co * 4 + a * 2 + 0]), r1 = vad_tanh(acc[co * 4 + a * 2 + 1]);
-                const float d0 = xv.x - r0, d1 = xv.y - r1;
+                const float r0 = vad_tanh(acc[co * 4 + ra * 2 + 0]), r1 = vad_tanh(acc[co * 4 + ra * 2 + 1]);
+                const float d0 = xv[ra][co].x - r0, d1 = xv[ra][co].y - r1;
                 ea[0] += d0 * d0;
                 ea[1] += d1 * d1;
                 if (p.recon) *(float2*)(p.recon + o + co * plane) = make_float2(r0, r1);
             }
             if (p.errmap)
-                *(float2*)(p.errmap + (size_t)n * plane + (size_t)(2 * y + a) * w2 + 2 * x) =
+                *(float2*)(p.errmap + (size_t)n * plane + (size_t)(2 * y + ra) * w2 + 2 * x) =
                     make_float2(ea[0] / 3.0f, ea[1] / 3.0f);
             e += ea[0] + ea[1];
         }
     }
-    block_partial(e, red, &p.partials[(size_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx]);
+    const float s = wave_sum(e);
+    if (lane == 0) p.partials[(size_t)n * ((size_t)H * segs) + (size_t)y * segs + sx] = s;
 }
 
 // One 64-lane block per clip (t frames): lane l adds partials l, l+64, ... in order, then the
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(64) void score_finalize_kernel(const float* partial
 
 extern "C" int vad_score_partials(int kind, int h2, int w2) {
     if (kind == 0) return ((h2 + TAIL_T - 1) / TAIL_T) * ((w2 + TAIL_T - 1) / TAIL_T);
-    if (kind == 1) return ((h2 / 2 + 7) / 8) * ((w2 / 2 + 31) / 32);
+    if (kind == 1) return (h2 / 2) * ((w2 / 2 + 63) / 64);          // one partial per (input row, 64-pixel segment)
     return vad_fail(VAD_ERR_ARG, "score_partials: kind must be 0 (conv3x3 tail) or 1 (convT tail)");
 }
 
@@ -314,10 +329,11 @@ int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float
     VAD_REQUIRE(cin == 32, "convt2x2_to3_score: cin=%d unsupported (the reference's decoder.9 has 32)", cin);
     VAD_REQUIRE(n > 0 && h > 0 && w > 0, "convt2x2_to3_score: bad shape");
     VAD_REQUIRE(t >= 0 && clip_stride >= 0 && (t == 0 || clip_stride > 0), "convt2x2_to3_score: bad window mapping");
-    TailP p{in, w_iohw, bias3, (const float*)x, partials, recon, errmap, h, w, (w + 31) / 32, (h + 7) / 8, (t == clip_stride) ? 0 : t, clip_stride, fmt == VAD_X_U8_NHWC};
-    const long long nb = (long long)n * p.tiles_x * p.tiles_y;
-    VAD_REQUIRE(nb < (1ll << 31), "convt2x2_to3_score: grid too large");
-    hipLaunchKernelGGL((convt2x2_to3_score_kernel<32>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+    TailP p{in, w_iohw, bias3, (const float*)x, partials, recon, errmap, h, w, (w + 63) / 64, h, (t == clip_stride) ? 0 : t, clip_stride, fmt == VAD_X_U8_NHWC, 0u};
+    const long long items = (long long)n * h * p.tiles_x;
+    VAD_REQUIRE(items < (1ll << 31), "convt2x2_to3_score: grid too large");
+    p.nitems = (unsigned)items;
+    hipLaunchKernelGGL((convt2x2_to3_score_kernel<32>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
