@@ -225,7 +225,7 @@ def test_trainer_rejects_unsupported_models(vad):
     with pytest.raises(vad.hip.VadError, match="does not support this configuration"):
         vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=288).cuda())       # hidden > 256
     with pytest.raises(vad.hip.VadError, match="precision"):
-        vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32).cuda(), precision="bf16")
+        vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32).cuda(), precision="fp8")
     tr = vad.VideoTrainer(vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32).cuda())
     with pytest.raises(vad.hip.VadError, match="multiples of 16"):
         tr.step(torch.zeros(1, 2, 3, 24, 24, device="cuda"))
