@@ -129,7 +129,7 @@ def test_argument_errors_without_gpu(vad):
     assert lib.vad_img_workspace_bytes(16, 250, 256, 256) == 0
     assert lib.vad_img_workspace_bytes(16, 256, 256, 256) >= 2 * 16 * 256 * 256 * 32 * 4
     assert lib.vad_vid_nparams(2, 0) == 48 and lib.vad_vid_nparams(1, 1) == 48
-    assert lib.vad_score_partials(0, 256, 256) == 64 and lib.vad_score_partials(1, 256, 256) == 64
+    assert lib.vad_score_partials(0, 256, 256) == 64 and lib.vad_score_partials(1, 256, 256) == 256   # 32x32 tiles; 128 rows x 2 segments
     assert lib.vad_score_partials(7, 256, 256) < 0 and b"kind" in lib.vad_last_error()
 
 
