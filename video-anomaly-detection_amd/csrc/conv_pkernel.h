@@ -97,7 +97,10 @@ __device__ __forceinline__ void tile_put_t(float* tile, int pixoff_plus_ch, int 
 }
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0>
-__global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
+// Work-groups per CU: 3 where the exact-fp32 kernel fits 168 registers - the fused first layer and the one-or-two
+// accumulator tilings (cout 32: K = 288 per tile, so barriers, staging and the epilogue are a large share of a tile and a
+// third resident group covers them) - else 2.
+__global__ __launch_bounds__(256, (!PREC && (FUSE_C3 || (MT * NT <= 2 && MODE != MODE_LSTM))) ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
     static_assert(WM * WN == 4, "4 waves per work-group");
     static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
     static_assert(!FUSE_C3 || CK == 32, "fused first layer produces exactly one 32-channel chunk");
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #pragma unroll
     for (int s0 = 0; s0 < PB; ++s0) LOAD_B(s0, 0, s0);
 
-    float b0w[(FUSE_C3 && !PREC) ? 14 : 1];
+    float b0w[(FUSE_C3 && !PREC) ? 14 : 1];      // first-stage B fragments: re-read from L1 for every tile (see the frame loop)
     f16x8 b0h[(FUSE_C3 && PREC) ? 2 : 1], b0l[(FUSE_C3 && PREC) ? 2 : 1];
     float bias0 = 0.f;
     bool interior = false;
@@ -271,8 +274,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 b0l[ks] = __builtin_bit_cast(f16x8, ws[((ks * 32 + li) * 2 + lh) * 2 + 1]);
             }
         } else {
-#pragma unroll
-            for (int s0 = 0; s0 < 14; ++s0) b0w[s0] = p.w0[(s0 * 2 + lh) * 32 + li];
+            // (the 14 first-stage weights of a lane are loaded per tile, not held: with them resident the kernel needed 189
+            // registers, and under the 168 that three work-groups per CU allow hipcc spilled 21 values to scratch and
+            // reloaded them - staging offsets, store offsets - inside the frame loop, behind vmcnt(0) waits that also drain
+            // the next tile's prefetch)
         }
         bias0 = p.b0[li];
         interior = y0 > 0 && x0 > 0 && y0 + TH < H && x0 + 16 < W;
@@ -285,9 +290,6 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
         if constexpr (PREC) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) { asm volatile("" ::"v"(b0h[ks])); asm volatile("" ::"v"(b0l[ks])); }
-        } else {
-#pragma unroll
-            for (int s0 = 0; s0 < 14; ++s0) asm volatile("" ::"v"(b0w[s0]));
         }
         asm volatile("" ::"v"(bias0));
     }
@@ -332,6 +334,13 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
             __syncthreads();                       // every wave is done reading the previous stage
             STAMP(1);
             if constexpr (FUSE_C3) {
+                if constexpr (!PREC) {   // in flight during the LDS write and the barrier below; wave-coalesced 128-B rows, L1 hits
+#pragma unroll
+                    for (int s0 = 0; s0 < 14; ++s0) b0w[s0] = p.w0[(s0 * 2 + lh) * 32 + li];
+                    // pin them HERE: sunk to their first use they would be younger than the next tile's prefetch, and waiting
+                    // for them (vmcnt is in order) would drain that prefetch in front of the first-stage MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int i = 0; i < NPF; ++i) {
                     const int idx = tid + 256 * i;
@@ -341,6 +350,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 STAMP(2);
                 __syncthreads();
                 STAMP(3);
+                if constexpr (!PREC) {   // retire the (old, long arrived) weight loads BEFORE the prefetch goes out: no vmcnt wait is
+#pragma unroll                           // left in front of the first-stage MFMAs that would also drain the prefetch
+                    for (int s0 = 0; s0 < 14; ++s0) asm volatile("" ::"v"(b0w[s0]));
+                }
                 if (has_next) { ISSUE(nn, 0); }
                 STAMP(7);
                 // Fused first layer: Conv2d(3->32)+BN+LeakyReLU of the tile AND its halo, K = 27 padded to 28
@@ -393,28 +406,37 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 } else {
                 constexpr int TPW = (NT0 + 3) / 4;
                 f32x16 c0[TPW];
-                float av[TPW][14];
+                int abase0[TPW];
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
                     const int q = (wave + 4 * u) * 32 + li, qc = q < NPIX ? q : NPIX - 1;
-                    const int abase0 = (qc / LW) * XS + (qc % LW);
+                    abase0[u] = (qc / LW) * XS + (qc % LW);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c0[u][r] = bias0;
-#pragma unroll
-                    for (int s0 = 0; s0 < 14; ++s0) {
-                        const int k0 = 2 * s0, k1 = 2 * s0 + 1;
-                        const int o0 = ((k0 / 9) * XH + (k0 % 9) / 3) * XS + (k0 % 3);
-                        const int o1 = (k1 < 27) ? ((k1 / 9) * XH + (k1 % 9) / 3) * XS + (k1 % 3) : 0;
-                        av[u][s0] = xin[abase0 + (lh ? o1 : o0)];
-                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
+                // the 14 k-steps in two halves: gather 7 x TPW A values, then their MFMAs (all 42 values at once cost 21 more
+                // live registers than three work-groups per CU leave, and hipcc spilled loop-carried offsets instead)
 #pragma unroll
-                for (int s0 = 0; s0 < 14; ++s0)
+                for (int h0 = 0; h0 < 14; h0 += 7) {
+                    float av[TPW][7];
 #pragma unroll
-                    for (int u = 0; u < TPW; ++u) c0[u] = MFMA32(av[u][s0], b0w[s0], c0[u]);
-                __builtin_amdgcn_s_setprio(0);
+                    for (int u = 0; u < TPW; ++u)
+#pragma unroll
+                        for (int s0 = 0; s0 < 7; ++s0) {
+                            const int k0 = 2 * (h0 + s0), k1 = 2 * (h0 + s0) + 1;
+                            const int o0 = ((k0 / 9) * XH + (k0 % 9) / 3) * XS + (k0 % 3);
+                            const int o1 = (k1 < 27) ? ((k1 / 9) * XH + (k1 % 9) / 3) * XS + (k1 % 3) : 0;
+                            av[u][s0] = xin[abase0[u] + (lh ? o1 : o0)];
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int s0 = 0; s0 < 7; ++s0)
+#pragma unroll
+                        for (int u = 0; u < TPW; ++u) c0[u] = MFMA32(av[u][s0], b0w[h0 + s0], c0[u]);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
                     const int t = wave + 4 * u;
