@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (row f-1)")
     ap.add_argument("--graph", action="store_true", help="capture the step's scoring call into a hipGraph once and replay it every step (1 GPU, image / video)")
     ap.add_argument("--no-wavefront", action="store_true", help="video: ConvLSTM layers strictly one after the other (A/B of the small-batch wavefront)")
+    ap.add_argument("--always-wavefront", action="store_true", help="video: ConvLSTM layer wavefront at any batch size (A/B)")
     ap.add_argument("--conv-variant", type=int, default=-1, help="vad_debug_set_conv_variant bits (A/B; 9 = never the small-grid ConvLSTM kernel)")
     ap.add_argument("--tail-group", type=int, default=0, help="frames per dec4.0 -> tail sub-group (0 = auto)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
@@ -116,6 +117,8 @@ def main():
         lib.vad_debug_set_tail_group(args.tail_group)
     if args.no_wavefront:
         lib.vad_debug_set_lstm_wavefront(0)
+    if args.always_wavefront:
+        lib.vad_debug_set_lstm_wavefront(2)
     if args.conv_variant >= 0:
         lib.vad_debug_set_conv_variant(args.conv_variant)
 

@@ -600,21 +600,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     }
     const int ctiles = p.cout / 32;            // output-channel tiles, one after the other (one for every reference layer)
     float pre[NST];
-    // staging element e = tid + 256*j -> (plane c, halo row ly, halo column lx); recomputed, not held in registers
+    // staging element e = tid + 256*j -> (plane c, halo row ly, halo column lx).  Its offset inside a frame relative to the
+    // tile origin and its (ly, lx) are fixed for the life of the work-group: computed ONCE (the divisions by 18 and 34 per
+    // element and tile, plus the bounds tests, were ~25 VALU instructions per element and tile - on a pipe the exact-fp32
+    // MFMAs share; the kernel had 1,467 VALU instructions for its 56 MFMAs and ran at 0.48 matrix-pipe utilisation).
+    // Interior tiles (the majority) add one tile base per element; border tiles test (ly, lx) against the image.
+    unsigned rel[NST];          // element offset (in input elements) relative to the tile's first halo pixel; ~0u past the tile
+    unsigned lyx[NST];          // ly << 8 | lx
+    int lds_pos[NST];           // where the element goes in the LDS tile
+    const unsigned plane_e = p.xu8 ? 1u : (unsigned)(p.h * p.w_), px_e = p.xu8 ? 3u : 1u;   // u8 NHWC: pixel stride 3, channel stride 1
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int e = tid + 256 * j, lx = e % 18, t = e / 18, ly = t % LH, c = t / LH;
+        rel[j] = e < NE ? (unsigned)((ly * p.w_ + lx) * (int)px_e) + (unsigned)c * plane_e : ~0u;
+        lyx[j] = (unsigned)(ly << 8 | lx);
+        lds_pos[j] = (c * LH + ly) * RS + lx;
+    }
+    const unsigned frame_elems = 3u * (unsigned)(p.h * p.w_);
     auto fetch = [&](unsigned L) {
         const int tx = L % p.tiles_x; L /= p.tiles_x;
         const int ty = L % p.tiles_y;
         const int n = L / p.tiles_y;
-        const float* xin = p.x + (size_t)n * 3 * p.h * p.w_;
-        const unsigned char* xin8 = (const unsigned char*)p.x + (size_t)n * 3 * p.h * p.w_;
+        const int gy0 = ty * TH - 1, gx0 = tx * 16 - 1;                       // first halo pixel of the tile
+        const bool inner = gy0 >= 0 && gx0 >= 0 && gy0 + LH <= p.h && gx0 + 18 <= p.w_;      // wave-uniform
+        const int origin = (gy0 * p.w_ + gx0) * (int)px_e;                    // negative on top / left border tiles
+        // branch-free: elements outside the image (or past the tile) get the out-of-range offset and the buffer load
+        // returns 0 by itself; one uniform branch selects the input format
+        unsigned off[NST];
 #pragma unroll
         for (int j = 0; j < NST; ++j) {
-            const int e = tid + 256 * j, lx = e % 18, t = e / 18, ly = t % LH, c = t / LH;
-            const int gy = ty * TH - 1 + ly, gx = tx * 16 - 1 + lx;
-            float v = 0.f;
-            if (e < NE && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w_)
-                v = p.xu8 ? vad_norm_u8(xin8[((size_t)gy * p.w_ + gx) * 3 + c]) : xin[((size_t)c * p.h + gy) * p.w_ + gx];
-            pre[j] = v;
+            bool ok = rel[j] != ~0u;
+            if (!inner) {
+                const int gy = gy0 + (int)(lyx[j] >> 8), gx = gx0 + (int)(lyx[j] & 255u);
+                ok = ok && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
+            }
+            off[j] = ok ? (unsigned)(origin + (int)rel[j]) : VAD_OOB;
+        }
+        if (p.xu8) {
+            const __amdgpu_buffer_rsrc_t r = vad_rsrc((const unsigned char*)p.x + (size_t)n * frame_elems, frame_elems);
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const unsigned b = __builtin_amdgcn_raw_buffer_load_b8(r, (int)off[j], 0, 0);
+                pre[j] = off[j] == VAD_OOB ? 0.f : vad_norm_u8(b & 255u);      // padding is 0.0 AFTER normalisation
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t r = vad_rsrc(p.x + (size_t)n * frame_elems, frame_elems * 4u);
+#pragma unroll
+            for (int j = 0; j < NST; ++j) pre[j] = vad_bload1(r, off[j] == VAD_OOB ? VAD_OOB : off[j] * 4u, 0);
         }
     };
     // B fragments + bias: ONE register set, (re)loaded only when the channel tile changes - once per work-group for every
@@ -626,10 +658,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     for (; L < p.nblocks; L += gridDim.x) {
         __syncthreads();                                   // every wave is done reading the previous tile
 #pragma unroll
-        for (int j = 0; j < NST; ++j) {
-            const int e = tid + 256 * j, lx = e % 18, t = e / 18;
-            if (e < NE) tile[((t / LH) * LH + t % LH) * RS + lx] = pre[j];
-        }
+        for (int j = 0; j < NST; ++j)
+            if (rel[j] != ~0u) tile[lds_pos[j]] = pre[j];
         __syncthreads();
         const unsigned Ln = L + gridDim.x;
         if (Ln < p.nblocks) fetch(Ln);                     // in flight during the MFMAs below
@@ -638,6 +668,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
         const int ty = t_ % p.tiles_y;
         const int n = t_ / p.tiles_y;
         const int y0 = ty * TH, x0 = tx * 16;
+        const __amdgpu_buffer_rsrc_t rout = vad_rsrc(p.out + (size_t)n * (POOL ? (p.h >> 1) * (p.w_ >> 1) : p.h * p.w_) * p.cout,
+                                                     (unsigned)((POOL ? (p.h >> 1) * (p.w_ >> 1) : p.h * p.w_) * p.cout) * 4u);
         for (int nt = 0; nt < ctiles; ++nt) {
             const int co = nt * 32 + li;
             if (have != nt) {
@@ -674,12 +706,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                     const int wq = 2 * q + lh;
                     float v[4];
 #pragma unroll
-                    for (int pos = 0; pos < 4; ++pos) v[pos] = vad_act(acc[mt][4 * q + pos], ACT);
+                    for (int pos = 0; pos < 4; ++pos) v[pos] = POOL ? acc[mt][4 * q + pos] : vad_act(acc[mt][4 * q + pos], ACT);
                     if (POOL) {
-                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one activation
+                        // per window instead of four
+                        const float m = vad_act(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), ACT);
                         const int oy = (y0 >> 1) + (wave * MTW + mt), ox = (x0 >> 1) + wq;
-                        if (oy < (p.h >> 1) && ox < (p.w_ >> 1))
-                            p.out[(((size_t)n * (p.h >> 1) + oy) * (p.w_ >> 1) + ox) * p.cout + co] = m;
+                        // branch-free: a window outside the (pooled) image gets the out-of-range offset and the store is dropped
+                        const bool ok = oy < (p.h >> 1) && ox < (p.w_ >> 1);
+                        vad_bstore1(m, rout, ok ? (unsigned)(__mul24(__mul24(oy, p.w_ >> 1) + ox, p.cout) + co) * 4u : VAD_OOB, 0);
                     } else {
 #pragma unroll
                         for (int pos = 0; pos < 4; ++pos) {
@@ -711,6 +746,8 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
     // persistent kernel (tiles of 32 rows x 16 columns) for the pooled form; the un-pooled form (training forward) writes
     // 8.4 MB per 256x256 frame and is faster with many small work-groups in flight (measured 4.0 vs 6.5 us/frame)
     if (kn.variant != 0 && pool) {
+        VAD_REQUIRE(12ll * h * wd < (1ll << 31) && (long long)h * wd * cout < (1ll << 31),
+                    "conv3x3_c3: frame %dx%d (cout %d) too large for the 32-bit offsets inside one frame", h, wd, cout);
         ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 31) / 32, 0, fmt == VAD_X_U8_NHWC};
         const long long nb = (long long)n * p.tiles_x * p.tiles_y;
         VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");

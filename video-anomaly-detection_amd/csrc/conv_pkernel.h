@@ -589,10 +589,10 @@ __global__ __launch_bounds__(256, (!PREC && (FUSE_C3 || (MT * NT <= 2 && MODE !=
                         const unsigned so = mt * erow + 2 * q * ecol;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            float v[4];
-#pragma unroll
-                            for (int pos = 0; pos < 4; ++pos) v[pos] = vad_act(acc[mt][nt][4 * q + pos], ACT);
-                            vad_bstore1(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), ro, ok ? eoff[nt] : VAD_OOB, so);
+                            // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one
+                            // activation per window instead of four (VALU work shares the pipe with the exact-fp32 MFMAs)
+                            const float m = fmaxf(fmaxf(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1]), fmaxf(acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]));
+                            vad_bstore1(vad_act(m, ACT), ro, ok ? eoff[nt] : VAD_OOB, so);
                         }
                     }
                 }

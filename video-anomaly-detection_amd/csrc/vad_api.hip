@@ -281,8 +281,8 @@ static int side_streams(int layers, VadSideStreams** out) {
     return VAD_OK;
 }
 
-static std::atomic<int> g_vad_lstm_wavefront{1};   // debug: 0 = always the sequential layers-outer order
-extern "C" int vad_debug_set_lstm_wavefront(int on) { g_vad_lstm_wavefront = on != 0; return VAD_OK; }
+static std::atomic<int> g_vad_lstm_wavefront{1};   // debug: 0 = always the sequential layers-outer order, 2 = wavefront at any size
+extern "C" int vad_debug_set_lstm_wavefront(int on) { g_vad_lstm_wavefront = on; return VAD_OK; }
 
 // clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
 int vid_run(const void* xv, int x_format, int precision, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
@@ -340,7 +340,8 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         // order).  Small ones (the reference's batch sizes; a step is then one wave's serial K loop on a fraction of the
         // CUs) run the layers as a wavefront on helper streams.
         const long long lstm_groups = (long long)nc * ((w16 + 15) / 16) * ((h16 + 3) / 4) * (hid / 64);
-        if (layers > 1 && lstm_groups < 256 && g_vad_lstm_wavefront.load(std::memory_order_relaxed)) {
+        const int wf = g_vad_lstm_wavefront.load(std::memory_order_relaxed);
+        if (layers > 1 && ((lstm_groups < 256 && wf) || wf == 2)) {
             VadSideStreams* S = nullptr;
             TRY(side_streams(layers, &S));
             VAD_HIP_TRY(hipEventRecord(S->fork, s));                          // the encoder's output is ready
