@@ -35,9 +35,17 @@ __device__ __forceinline__ unsigned vad_xcd_remap(unsigned b, unsigned nb) {
     return base + (b >> 3);
 }
 
+// LeakyReLU(0.2) as max(v, 0.2 v): the same value as the select for every input (0.2 v < v exactly when v > 0), in two
+// VALU instructions instead of v_mul + v_cmp + v_cndmask plus the VCC wait states - these epilogues run on the pipe the
+// exact-fp32 MFMAs use.  One plain v_max_f32 each (fmaxf adds a canonicalising v_max(v, v) per operand under IEEE mode).
+__device__ __forceinline__ float vad_vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float vad_act(float v, int act) {
-    if (act == VAD_ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
-    if (act == VAD_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == VAD_ACT_LEAKY) return vad_vmax(v, 0.2f * v);
+    if (act == VAD_ACT_RELU) return vad_vmax(v, 0.f);
     return v;
 }
 
