@@ -38,7 +38,8 @@ extern "C" {
 #define VAD_PREC_SPLIT 1
 /*   VAD_PREC_BF16  bf16 operands (round to nearest even), one v_mfma_f32_32x32x16_bf16 per 16 channels, fp32 accumulate -
  *      TRAINING ONLY (BASELINE.json configs[4] names bf16): accepted by vad_conv3x3, vad_convt2x2, vad_train_pack_* and the
- *      vad_*_train_fwd_bwd entry points; master weights, BatchNorm, statistics, loss, weight gradients and Adam stay fp32.
+ *      vad_conv_wgrad and the vad_*_train_fwd_bwd entry points; master weights, BatchNorm, statistics, loss, the first /
+ *      last layer and Adam stay fp32 (weight gradients: bf16 operands, fp32 accumulation).
  *      8 significant bits: the scoring entry points and host packers reject it (scores would miss the 1e-4 bar by 60x). */
 #define VAD_PREC_BF16 2
 
@@ -200,8 +201,11 @@ int vad_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, 
  *   taps 1, layout 3: ConvTranspose2d(32->3) from the 32-column dpre of vad_convt_to3_mse, dw (32, 3, 2, 2)
  *   taps 1, layout 4: Conv2d k1 (VideoAutoencoder.proj) weight gradient, dw OIHW (ncols, cin, 1, 1) */
 size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int ncols);
+/* precision VAD_PREC_FP32 / VAD_PREC_SPLIT: exact fp32 (v_mfma_f32_32x32x2_f32, two pixels per instruction);
+ * VAD_PREC_BF16: both operands rounded to bf16, v_mfma_f32_32x32x16_bf16 (16 pixels per instruction), fp32 accumulation and
+ * fp32 split-K partials. */
 int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
-                   int taps, int layout, void* stream);
+                   int taps, int layout, int precision, void* stream);
 /* First-layer weight gradient: x NCHW [n,3,h,w], g [n,h,w,cout] -> dw OIHW (cout,3,3,3). */
 size_t vad_conv_c3_wgrad_ws_floats(int n, int h, int cout);
 int vad_conv_c3_wgrad(const float* x_nchw, const float* g, float* dw, float* ws, int n, int h, int w, int cout,
@@ -242,8 +246,9 @@ int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, f
  * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim,
  * lstm_num_layers) (both dims multiples of 32, hidden <= 256; `proj` is the 1x1 conv when they differ): train-mode forward (batch-statistics BatchNorm, running stats updated when `running`
  * is given), nn.MSELoss, and the full backward.  precision VAD_PREC_FP32: exact fp32; VAD_PREC_SPLIT / VAD_PREC_BF16: the 3x3
- * and transposed convolutions (forward + data gradients) use split-fp16 / bf16 operands with fp32 accumulation, the rest
- * (first and last layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam, master weights) stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
+ * and transposed convolutions (forward + data gradients) use split-fp16 / bf16 operands with fp32 accumulation (bf16: the
+ * weight gradients too), the rest (first and last layer, 1x1 data gradients, BatchNorm, gates, loss, Adam, master weights;
+ * in split mode also the weight gradients) stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
  * floats, torch layouts in named_parameters() order (see csrc/train_step.hip); running: vad_vid_train_nstats floats,
  * {running_mean, running_var} per BatchNorm in module order.  x [B,T,3,H,W]; loss: device float[1];
  * recon (nullable) [B,T,3,H,W].  Every gradient is overwritten (no accumulation), so there is no zero_grad.

@@ -203,8 +203,12 @@ def _check_conv3x3_gradients(vad, n, h, w, cin, cout, precision):
     ad, gd = H.nhwc(a), H.nhwc(g)
     dw = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
     ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, 9, cin, cout))
-    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), gd.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, H.stream()))
+    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), gd.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, 0, H.stream()))
     _close(dw.cpu().numpy(), wtt.grad.numpy(), 1e-4, "dW")
+    # bf16 operands (VAD_PREC_BF16): 16 pixels per MFMA, fp32 accumulation; ~2^-9 per product, averaging over the pixel sum
+    dwb = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), gd.data_ptr(), dwb.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, 2, H.stream()))
+    _close(dwb.cpu().numpy(), wtt.grad.numpy(), 1e-2, "dW (bf16 operands)")
 
     # data gradient = forward kernel on the re-packed weight (device-side packing of the live parameter)
     wd = H.dev(wt)
@@ -240,8 +244,11 @@ def _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision):
     g_s2d = torch.from_numpy(g).permute(0, 2, 3, 1).reshape(n, h, 2, w, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(n, h, w, 4 * cout).contiguous().cuda()
     dw = torch.full((cin, cout, 2, 2), float("nan"), device="cuda")
     ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, 1, cin, 4 * cout))
-    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), g_s2d.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, H.stream()))
+    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), g_s2d.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, 0, H.stream()))
     _close(dw.cpu().numpy(), wtt.grad.numpy(), 1e-4, "dW")
+    dwb = torch.full((cin, cout, 2, 2), float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), g_s2d.data_ptr(), dwb.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, 2, H.stream()))
+    _close(dwb.cpu().numpy(), wtt.grad.numpy(), 1e-2, "dW (bf16 operands)")
 
     wd = H.dev(wt)
     fwd = _ws(l.vad_pack_convt2x2_floats(cin, cout))
@@ -307,7 +314,7 @@ def test_last_layer_convt_tanh_mse_forward_backward(vad, n, h, w):
     _close(db.cpu().numpy(), bt.grad.numpy(), 1e-4, "d bias")
     dw = torch.full((32, 3, 2, 2), float("nan"), device="cuda")
     ws2 = _ws(l.vad_conv_wgrad_ws_floats(n, h, 1, 32, 32))
-    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), dpre.data_ptr(), dw.data_ptr(), ws2.data_ptr(), n, h, w, 32, 32, 1, 3, H.stream()))
+    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), dpre.data_ptr(), dw.data_ptr(), ws2.data_ptr(), n, h, w, 32, 32, 1, 3, 0, H.stream()))
     _close(dw.cpu().numpy(), wtt.grad.numpy(), 1e-4, "dW")
 
 

@@ -461,6 +461,112 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
             }
 }
 
+// bf16 form of the same GEMM (VAD_PREC_BF16, BASELINE configs[4]'s dtype): v_mfma_f32_32x32x16_bf16 consumes 16 pixels per
+// instruction - lane (li, kb) supplies the 8 consecutive pixels x0 + 8 kb + (0..7) of ITS channel / column, read as 8 (3x3:
+// 10, one pixel of halo either side) dword loads whose 32 lanes cover one 128-byte NHWC row each, rounded to bf16 (nearest
+// even) and packed on the fly; the three dx taps of a row are the element windows [0,8) [1,9) [2,10) of those 10 values
+// (even- and odd-aligned pair packings).  fp32 accumulation, same split-K partials and reduction as the exact kernel.  Per 16
+// pixels a wave issues 38 loads and 9 MFMAs of 32 cycles (the exact kernel: 9 x 8 MFMAs of 64 cycles): it is bound by the
+// vector L1, ~8x the exact kernel's rate.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wg_pk(float a, float b) { return __builtin_bit_cast(unsigned, wg_bf16x2{(__bf16)a, (__bf16)b}); }
+__device__ __forceinline__ wg_bf16x8 wg_frag(unsigned a, unsigned b, unsigned c, unsigned d) { return __builtin_bit_cast(wg_bf16x8, u32x4{a, b, c, d}); }
+
+template <int TAPS, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
+    const int lane = threadIdx.x & 63, li = lane & 31, kb = lane >> 5;
+    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= p.nitems) return;
+    const int ct = item % p.ci_tiles; item /= p.ci_tiles;
+    const int cgp = item % p.col_groups;
+    const int split = item / p.col_groups;
+    const int H = p.h, W = p.w, total_rows = p.n * H;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * 4u;
+    f32x16 acc[TAPS][NT];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.f;
+    constexpr int NR = TAPS == 9 ? 3 : 1, HALO = TAPS == 9 ? 1 : 0, NE = 8 + 2 * HALO;
+    const unsigned pix_a = (unsigned)(p.cin * 4), pix_g = (unsigned)(p.ncols * 4);
+    const unsigned lane_a = (unsigned)((ct * 32 + li) * 4), lane_g = (unsigned)((cgp * NT * 32 + li) * 4);
+    const __amdgpu_buffer_rsrc_t rzero = vad_rsrc(p.a, 0);
+    for (int row = r0; row < r1; ++row) {
+        const int n_ = row / H, ly = row - n_ * H;
+        const float* fa = p.a + (size_t)n_ * H * W * p.cin;
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n_ * H * W * p.ncols, g_bytes);
+        const unsigned gbase = (unsigned)(ly * W) * pix_g;
+        __amdgpu_buffer_rsrc_t rrow[NR];
+        unsigned rbase[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int yy = ly + (NR == 3 ? i - 1 : 0);
+            const bool rok = yy >= 0 && yy < H;
+            rrow[i] = rok ? vad_rsrc(fa, a_bytes) : rzero;       // rows above / below the image: zero-sized descriptor -> zeros
+            rbase[i] = rok ? (unsigned)(yy * W) * pix_a : 0u;
+        }
+        for (int lx = 0; lx < W; lx += 16) {
+            const int px0 = lx + 8 * kb;
+            // every load of the step first (38 in flight), then the conversions and the MFMAs
+            float gv[NT][8], av[NR][NE];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int x = px0 + e;
+                const unsigned off = x < W ? lane_g + (unsigned)x * pix_g : VAD_OOB;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) gv[nt][e] = vad_bload1(rg, off, gbase + (unsigned)(nt * 128));
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int x = px0 + e - HALO;
+                    av[i][e] = vad_bload1(rrow[i], (unsigned)x < (unsigned)W ? lane_a + (unsigned)x * pix_a : VAD_OOB, rbase[i]);
+                }
+            wg_bf16x8 gb[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                gb[nt] = wg_frag(wg_pk(gv[nt][0], gv[nt][1]), wg_pk(gv[nt][2], gv[nt][3]), wg_pk(gv[nt][4], gv[nt][5]), wg_pk(gv[nt][6], gv[nt][7]));
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                if constexpr (TAPS == 9) {
+                    unsigned pe[5], po[4];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) pe[k] = wg_pk(av[i][2 * k], av[i][2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) po[k] = wg_pk(av[i][2 * k + 1], av[i][2 * k + 2]);
+                    const wg_bf16x8 f0 = wg_frag(pe[0], pe[1], pe[2], pe[3]);      // dx = 0: pixels x-1 .. x+6
+                    const wg_bf16x8 f1 = wg_frag(po[0], po[1], po[2], po[3]);      // dx = 1: pixels x   .. x+7
+                    const wg_bf16x8 f2 = wg_frag(pe[1], pe[2], pe[3], pe[4]);      // dx = 2: pixels x+1 .. x+8
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[i * 3 + 0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, gb[nt], acc[i * 3 + 0][nt], 0, 0, 0);
+                        acc[i * 3 + 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, gb[nt], acc[i * 3 + 1][nt], 0, 0, 0);
+                        acc[i * 3 + 2][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, gb[nt], acc[i * 3 + 2][nt], 0, 0, 0);
+                    }
+                } else {
+                    const wg_bf16x8 f = wg_frag(wg_pk(av[0][0], av[0][1]), wg_pk(av[0][2], av[0][3]), wg_pk(av[0][4], av[0][5]), wg_pk(av[0][6], av[0][7]));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, gb[nt], acc[0][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                p.ws[(((size_t)split * TAPS + t) * p.cin + ci) * p.ncols + (cgp * NT + nt) * 32 + li] = acc[t][nt][r];
+            }
+}
+
 // First layer (input NCHW, 3 channels): M index k = c*9 + tap (27, padded to 32), A gathered from the input planes.
 struct WgradC3P {
     const float* x; const float* g; float* ws;
@@ -931,8 +1037,9 @@ extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int 
 }
 
 extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
-                              int taps, int layout, void* stream) {
+                              int taps, int layout, int precision, void* stream) {
     VAD_REQUIRE(a && g && dw && ws && n > 0 && h > 0 && w > 0, "conv_wgrad: bad arguments");
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "conv_wgrad: precision=%d must be 0 (fp32), 1 (split: weight gradients stay fp32) or 2 (bf16)", precision);
     VAD_REQUIRE(cin % 32 == 0 && ncols % 32 == 0 && cin > 0 && ncols > 0, "conv_wgrad: cin=%d ncols=%d must be multiples of 32", cin, ncols);
     VAD_REQUIRE((taps == 9 && layout == 0) || (taps == 1 && (layout == 1 || layout == 3 || layout == 4)), "conv_wgrad: taps/layout mismatch");
     VAD_REQUIRE(layout != 1 || ncols % 128 == 0, "conv_wgrad: convT gradient needs ncols = 4*cout");
@@ -951,7 +1058,11 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     p.nitems = (unsigned)items;
     const dim3 grid((unsigned)((items + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
-    if (taps == 9) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), grid, dim3(256), 0, s, p);
+    if (precision == VAD_PREC_BF16) {
+        if (taps == 9) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<9, 1>), grid, dim3(256), 0, s, p);
+        else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1>), grid, dim3(256), 0, s, p);
+    } else if (taps == 9) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), grid, dim3(256), 0, s, p);
     else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();

@@ -304,14 +304,14 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     if (g_vad_train_stop == 20) return VAD_OK;      // debug: g0 = gradient of the last decoder activation, dpre intact
 
     // ================================================================================== backward
-    TRY(vad_conv_wgrad(ws + p.r[2], ws + p.dpre, G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, s));
+    TRY(vad_conv_wgrad(ws + p.r[2], ws + p.dpre, G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, precision, s));
     for (int j = 2; j >= 0; --j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
         const float* in = j == 0 ? dec_in : ws + p.r[j - 1];
         // g0 = d r_j (dense, 2hj x 2wj) -> g2 = d u_j in the space-to-depth view [N][hj][wj][4*co]
         TRY(vad_bn_act_pool_bwd(ws + p.u[j], ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.d_g[j], G + p.d_be[j],
                                 ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
-        TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, s));
+        TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, precision, s));
         // bias of a conv that feeds a batch-statistics BatchNorm: sum(dy) = gamma*invstd*(sum(dz) - M*k1 - k2*sum(xhat)) = 0
         // exactly (the batch mean removes any constant).  Autograd returns ~1e-9 rounding noise there, which Adam turns
         // into a +-lr random walk; an exact zero costs no pass over the tensor and leaves the bias where it is.
@@ -322,7 +322,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     // g0 = gradient of the decoder input [b*T+t][hw][L]; through proj when present
     const float* dhseq = g0;
     if (p.proj) {
-        TRY(vad_conv_wgrad(ws + p.hseq, g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, s));
+        TRY(vad_conv_wgrad(ws + p.hseq, g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, precision, s));
         TRY(vad_chan_sum(g0, (long long)N * hw, L, G + p.pj_b, ws + p.chan_ws, s));
         TRY(vad_conv1x1(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, s));
         dhseq = g2;
@@ -344,7 +344,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
             TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, ws + p.dcat[l] + tt * slab, 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, precision, s));
         }
         // weight / bias gradients of the cell's convolution over all steps at once (frames = T*B)
-        TRY(vad_conv_wgrad(ws + p.cat[l], ws + p.dzl[l], G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, s));
+        TRY(vad_conv_wgrad(ws + p.cat[l], ws + p.dzl[l], G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s));
         TRY(vad_chan_sum(ws + p.dzl[l], (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s));
         if (g_vad_train_stop == 10 + l) return VAD_OK;
     }
@@ -361,7 +361,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         if (k == 0) {
             TRY(vad_conv_c3_wgrad(x, g2, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
         } else {
-            TRY(vad_conv_wgrad(ws + p.a[k - 1], g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, s));
+            TRY(vad_conv_wgrad(ws + p.a[k - 1], g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s));
             TRY(vad_conv3x3(g2, 0, ws + p.pk_e_dg[k], zeros, g0, 0, N, hk, wk, co, ci, VAD_ACT_NONE, 0, precision, s));
         }
     }

@@ -231,7 +231,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
         if (j < 3) {      // conv-BN-ReLU: g0 = d rc_j -> g2 = d yc_j -> weight gradient, g0 = d rt_j
             TRY(vad_bn_act_pool_bwd(ws + p.yc[j], ws + p.st_dc[j], P + p.dc_g[j], P + p.dc_be[j], g0, 0, 0, 0, 0, g2, 0, G + p.dc_g[j], G + p.dc_be[j],
                                     ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
-            TRY(vad_conv_wgrad(ws + p.rt[j], g2, G + p.dc_w[j], ws + p.wgrad_ws, N, 2 * hj, 2 * wj, co, co, 9, 0, s));
+            TRY(vad_conv_wgrad(ws + p.rt[j], g2, G + p.dc_w[j], ws + p.wgrad_ws, N, 2 * hj, 2 * wj, co, co, 9, 0, precision, s));
             VAD_HIP_TRY(hipMemsetAsync(G + p.dc_b[j], 0, (size_t)co * sizeof(float), s));       // structurally zero (train_step.hip)
             TRY(vad_conv3x3(g2, 0, ws + p.pk_dc_dg[j], zeros, g0, 0, N, 2 * hj, 2 * wj, co, co, VAD_ACT_NONE, 0, precision, s));
         }
@@ -239,7 +239,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
         const float* in = j == 0 ? ws + p.p[3] : ws + p.rc[j - 1];
         TRY(vad_bn_act_pool_bwd(ws + p.ut[j], ws + p.st_dt[j], P + p.dt_g[j], P + p.dt_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.dt_g[j], G + p.dt_be[j],
                                 ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
-        TRY(vad_conv_wgrad(in, g2, G + p.dt_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, s));
+        TRY(vad_conv_wgrad(in, g2, G + p.dt_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, precision, s));
         VAD_HIP_TRY(hipMemsetAsync(G + p.dt_b[j], 0, (size_t)co * sizeof(float), s));
         TRY(vad_conv1x1(g2, ws + p.pk_dt_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, s));
     }
@@ -247,7 +247,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
         const int ci = p.c[i], co = p.c[i + 1], hi = H >> i, wi = W >> i;
         TRY(vad_bn_act_pool_bwd(ws + p.yb[i], ws + p.st_eb[i], P + p.eb_g[i], P + p.eb_be[i], g0, 0, 0, 0, 0, g2, 0, G + p.eb_g[i], G + p.eb_be[i],
                                 ws + p.ksums, ws + p.chan_ws, N, hi, wi, co, VAD_ACT_LEAKY, 1, s));
-        TRY(vad_conv_wgrad(ws + p.a[i], g2, G + p.eb_w[i], ws + p.wgrad_ws, N, hi, wi, co, co, 9, 0, s));
+        TRY(vad_conv_wgrad(ws + p.a[i], g2, G + p.eb_w[i], ws + p.wgrad_ws, N, hi, wi, co, co, 9, 0, precision, s));
         VAD_HIP_TRY(hipMemsetAsync(G + p.eb_b[i], 0, (size_t)co * sizeof(float), s));
         TRY(vad_conv3x3(g2, 0, ws + p.pk_eb_dg[i], zeros, g0, 0, N, hi, wi, co, co, VAD_ACT_NONE, 0, precision, s));          // g0 = d a_i
         TRY(vad_bn_act_pool_bwd(ws + p.ya[i], ws + p.st_ea[i], P + p.ea_g[i], P + p.ea_be[i], g0, 0, 0, 0, 0, g2, 0, G + p.ea_g[i], G + p.ea_be[i],
@@ -256,7 +256,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
         if (i == 0) {
             TRY(vad_conv_c3_wgrad(x, g2, G + p.ea_w[0], ws + p.wgrad_ws, N, hi, wi, co, s));
         } else {
-            TRY(vad_conv_wgrad(ws + p.p[i - 1], g2, G + p.ea_w[i], ws + p.wgrad_ws, N, hi, wi, ci, co, 9, 0, s));
+            TRY(vad_conv_wgrad(ws + p.p[i - 1], g2, G + p.ea_w[i], ws + p.wgrad_ws, N, hi, wi, ci, co, 9, 0, precision, s));
             TRY(vad_conv3x3(g2, 0, ws + p.pk_ea_dg[i], zeros, g0, 0, N, hi, wi, co, ci, VAD_ACT_NONE, 0, precision, s));      // g0 = d p_{i-1}
         }
     }

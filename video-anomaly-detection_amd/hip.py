@@ -112,7 +112,7 @@ SIGNATURES = {
     "vad_lstm_gates_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _vp]),
     "vad_lstm_gates_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "vad_conv_wgrad_ws_floats": (_sz, [_i, _i, _i, _i, _i]),
-    "vad_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_conv_c3_wgrad_ws_floats": (_sz, [_i, _i, _i]),
     "vad_conv_c3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_convt_to3_mse_ws_floats": (_sz, [_i, _i, _i]),
