@@ -97,10 +97,10 @@ __device__ __forceinline__ void tile_put_t(float* tile, int pixoff_plus_ch, int 
 }
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0>
-// Work-groups per CU: 3 where the exact-fp32 kernel fits 168 registers - the fused first layer and the one-or-two
-// accumulator tilings (cout 32: K = 288 per tile, so barriers, staging and the epilogue are a large share of a tile and a
-// third resident group covers them) - else 2.
-__global__ __launch_bounds__(256, (!PREC && (FUSE_C3 || (MT * NT <= 2 && MODE != MODE_LSTM))) ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
+// Work-groups per CU: 3 for the exact-fp32 fused first layer (it fits 168 registers; its three barriers per tile need the
+// third resident group), else 2 (three groups measured no gain on the cout-32 tilings, and the deeper weight prefetch below
+// needs the registers).
+__global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
     static_assert(WM * WN == 4, "4 waves per work-group");
     static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
     static_assert(!FUSE_C3 || CK == 32, "fused first layer produces exactly one 32-channel chunk");
@@ -118,7 +118,12 @@ __global__ __launch_bounds__(256, (!PREC && (FUSE_C3 || (MT * NT <= 2 && MODE !=
     constexpr int NS = 9 * (CK / KS);
     // B (weight) fragments come from L2 and are requested PB steps ahead into a ring of NB register sets; the fp16
     // steps are 5x shorter than the fp32 ones, so they need the deeper prefetch to cover an L2 round trip.
-    constexpr int PB = (PREC == 2) ? 5 : (PREC && NT <= 2) ? 2 : 1, NB = PB + 1;   // bf16 steps are a third of the split ones again
+    // Exact fp32: a step is 1,000+ cycles, one step ahead covers L2 - but vmcnt counts loads AND stores in order (gfx9), so
+    // the weight fragments requested after a tile's epilogue wait behind all of its stores.  The fragments of the next tile's
+    // first PB steps therefore go out BEFORE the stores (section "next frame's first B fragments" below): with PB = 1 only
+    // step 0 ran while the stores drained and the un-pooled layers (4x the stores of the pooled ones) lost 10-20 % there.
+    constexpr int PB32 = (MODE == MODE_POOL || FUSE_C3) ? 1 : 3;
+    constexpr int PB = (PREC == 2) ? 5 : (PREC && NT <= 2) ? 2 : PREC ? 1 : PB32, NB = PB + 1;   // bf16 steps are a third of the split ones again
     static_assert(NS % 2 == 0 && NS % NB == 0, "fragment ring parity must be the same in every chunk");
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
     __shared__ float xin[FUSE_C3 ? 3 * XH * XS : 1];
