@@ -341,6 +341,7 @@ static void launch_conv3_act(const Conv3P& p, hipStream_t s, int precision, int 
         if (!cap) grid_cap = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>, ~0u);
         Conv3P q = p;
         q.dbg = g_vad_dbg;
+        q.stagger = kn.stagger * 2;   // debug (variant bit 1, exact kernels): bit 1 = drop the epilogue's stores (prices them)
         hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
     }
 }

@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     // the weight fragments requested after a tile's epilogue wait behind all of its stores.  The fragments of the next tile's
     // first PB steps therefore go out BEFORE the stores (section "next frame's first B fragments" below): with PB = 1 only
     // step 0 ran while the stores drained and the un-pooled layers (4x the stores of the pooled ones) lost 10-20 % there.
+    // (The same in-order rule couples the weight stream to the input-tile prefetch - weight loads issued after ISSUE() retire
+    // behind it - but a depth of 8 on the cout-32 tiling, enough to cover an HBM round trip, measured no different from 3.)
     constexpr int PB32 = (MODE == MODE_POOL || FUSE_C3) ? 1 : 3;
     constexpr int PB = (PREC == 2) ? 5 : (PREC && NT <= 2) ? 2 : PREC ? 1 : PB32, NB = PB + 1;   // bf16 steps are a third of the split ones again
     static_assert(NS % 2 == 0 && NS % NB == 0, "fragment ring parity must be the same in every chunk");
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 }
             }
         } else {
-            const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
+            const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, (p.stagger & 2) ? 0u : out_bytes);   // stagger bit 1 (debug): zero-sized = every store dropped
             if (MODE == MODE_POOL) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
