@@ -319,9 +319,11 @@ int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, 
                   const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips,
                   float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
 
-/* Developer switches for A/B timing in one process (process-wide, debug only; the library never writes them itself and
- * results are bit-identical): 0 = one tile per work-group, 1 = persistent work-groups with register prefetch of the next
- * stage (default). */
+/* Developer switches for A/B timing in one process (process-wide, debug only; the library never writes them itself).
+ * Bit 0: 1 = persistent work-groups with register prefetch of the next stage (default), 0 = one tile per work-group
+ * (bit-identical results).  Bit 1: pricing runs whose results are NOT valid - exact kernels drop their epilogue stores,
+ * split kernels read no weights.  Bit 2: alternative cout-64 tiling.  Bit 3: never use the small-grid (16x16x4) ConvLSTM
+ * kernel (bit-identical results). */
 int vad_debug_set_conv_variant(int variant);
 /* 0 = run the ConvLSTM layers strictly one after the other on the caller's stream; 1 (default) = small launch groups run
  * them as a wavefront: layer l step t on a library-owned helper stream as soon as layer l-1 step t is done (fork / join by

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3P p) {
 static std::atomic<unsigned long long*> g_vad_dbg{nullptr};
 extern "C" int vad_debug_set_stamp_buffer(void* p) { g_vad_dbg = (unsigned long long*)p; return VAD_OK; }
 static std::atomic<int> g_vad_conv_bits{1};   // bit 0: 1 = persistent + register prefetch (default), 0 = one tile per work-group;
-                                              // bit 1: price the weight traffic (split kernels); bit 2: alternative cout-64 tiling;
+                                              // bit 1: pricing runs, results invalid (exact: drop epilogue stores; split: no weight reads);
+                                              // bit 2: alternative cout-64 tiling;
                                               // bit 3: never use the small-grid (16x16x4) ConvLSTM kernel
 extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 15; return VAD_OK; }
 struct ConvKnobs {
