@@ -153,3 +153,18 @@ def test_trained_model_gate_oracle(vad, golden):
     assert rel_err(s, g["scores"]) < SCORE_RTOL
     assert abs(vad.scoring.roc_auc(g["labels"], s) - float(g["auroc"])) < 1e-12
     assert s[g["labels"] == 1].mean() > s[g["labels"] == 0].mean()
+
+
+def test_every_fixture_has_a_generator():
+    """tests/golden/*.npz are data captured from the reference by tests/golden/make_golden.py: every committed fixture must
+    be one the script can regenerate (and vice versa), so that no vector is an orphan of unknown origin."""
+    import ast
+    from pathlib import Path
+    here = Path(__file__).resolve().parent / "golden"
+    src = (here / "make_golden.py").read_text()
+    tree = ast.parse(src)
+    names = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "FIXTURES" for t in node.targets):
+            names = {k.value for k in node.value.keys}
+    assert names and names == {p.name for p in here.glob("*.npz")}
