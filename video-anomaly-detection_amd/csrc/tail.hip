@@ -189,17 +189,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
 }
 
 // ConvTranspose2d(32->3, k2, s2) + Tanh + error: a 32 -> 12 GEMV per input pixel (12 = 3 channels x 2x2 output pixels), no
-// reuse between pixels - so no LDS and no barrier.  One WAVE owns 64 consecutive input pixels of one row: a lane reads its
-// pixel's 32 channels (128 B, eight 16-byte loads) and the 12 original-input values it is scored against (float2 per
-// channel and output row) all up front, so both streams are in flight together and the other resident waves (no LDS:
-// occupancy is set by registers only) cover their latency; weights and bias are wave-uniform scalar operands.  The first
-// version staged an 8x32-pixel tile through LDS behind a barrier, one thread per pixel, and issued the x loads only after
-// the 384 FMAs: 2.26 TB/s of algorithmic bytes (1.27 us per 256x256 frame).  Per-(row, segment) sums go to `partials`
-// (h * ceil(w/64) per frame); score_finalize_kernel adds them in a fixed order.
+// reuse between pixels - so no LDS tile and no barrier.  One WAVE owns 64 consecutive input pixels of one row and reads them
+// fully coalesced: load i (of 8) takes pixels 8i + lane/8, channel quad lane%8, i.e. 1 KiB contiguous per instruction.  A
+// lane therefore holds a 4-channel slice of 8 pixels; it multiplies them by ITS 4 x 12 weights (48 registers, read once),
+// and the 8 lanes of a pixel group transpose-reduce the partial sums (as in the conv3x3 tail above) so that lane c4 ends up
+// with the 12 finished outputs of pixel 8 c4 + lane/8: Tanh, error against the original input (loaded up front with the
+// activations, so both streams are in flight together) and the optional stores run on all 64 lanes.  History: an 8x32-pixel
+// LDS tile behind a barrier, one thread per pixel, x loaded after the FMAs ran at 2.26 TB/s of algorithmic bytes; one lane
+// per pixel reading its own 128 B (64 different lines per load instruction) at 3.6 TB/s.  Per-(row, segment) sums go to
+// `partials` (h * ceil(w/64) per frame); score_finalize_kernel adds them in a fixed order.
 template <int CIN>
 __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
-    static_assert(CIN == 32, "eight 16-byte loads per pixel");
-    const int lane = threadIdx.x & 63;
+    static_assert(CIN == 32, "eight channel quads per pixel, eight lanes per pixel group");
+    const int lane = threadIdx.x & 63, g = lane >> 3, c4 = lane & 7;
     const unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (item >= p.nitems) return;                                   // wave-uniform
     const int segs = p.tiles_x, H = p.h, W = p.w_;
@@ -207,16 +209,19 @@ __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
     const int sx = r % segs; r /= segs;
     const int y = r % H;
     const int n = r / H;
-    const int x = sx * 64 + lane;
+    const int x = sx * 64 + 8 * c4 + g;                             // the pixel this lane finishes
     const bool ok = x < W;
     const int nx = p.xt ? (n / p.xt) * p.xs + n % p.xt : n;         // source frame this activation frame is scored against
     const int h2 = 2 * H, w2 = 2 * W;
     const size_t plane = (size_t)h2 * w2;
 
-    f32x4 a[CIN / 4];
-    const f32x4* src = (const f32x4*)(p.in + (((size_t)n * H + y) * W + (ok ? x : 0)) * CIN);
+    f32x4 a[8];
+    const float* row = p.in + ((size_t)n * H + y) * W * CIN + 4 * c4;
 #pragma unroll
-    for (int c4 = 0; c4 < CIN / 4; ++c4) a[c4] = src[c4];
+    for (int i = 0; i < 8; ++i) {
+        const int xi = sx * 64 + 8 * i + g;                         // (pixels past the row end: read pixel 0, result discarded)
+        a[i] = *(const f32x4*)(row + (size_t)(xi < W ? xi : 0) * CIN);
+    }
     float2 xv[2][3];
     if (!p.xu8) {
         const float* xs = p.x + (size_t)nx * 3 * plane + (size_t)(2 * y) * w2 + 2 * (ok ? x : 0);
@@ -231,17 +236,45 @@ __global__ __launch_bounds__(256) void convt2x2_to3_score_kernel(TailP p) {
             for (int co = 0; co < 3; ++co)
                 xv[ra][co] = make_float2(tail_x(p, nx, co, 2 * y + ra, 2 * (ok ? x : 0), h2, w2), tail_x(p, nx, co, 2 * y + ra, 2 * (ok ? x : 0) + 1, h2, w2));
     }
+    f32x4 wq[12];                                                   // rows 4 c4 .. 4 c4 + 3 of the IOHW weight: [j][k = (co, a, b)]
+#pragma unroll
+    for (int q = 0; q < 12; ++q) wq[q] = *(const f32x4*)(p.w + c4 * 48 + 4 * q);
 
     float acc[12];
+    const bool h4 = c4 & 4, h2b = c4 & 2, h1 = c4 & 1;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = p.bias[k >> 2];
+    for (int co = 0; co < 3; ++co) {                                // one output channel (4 of the 12 columns) at a time: 32 live partials
+        float v[8][4];
 #pragma unroll
-    for (int c4 = 0; c4 < CIN / 4; ++c4) {
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* wr = p.w + (c4 * 4 + j) * 12;   // IOHW row: (co, a, b), wave-uniform
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = co * 4 + kk;                          // weight (j, k) = wq[(12 j + k) / 4][(12 j + k) % 4]
+                float sacc = a[i][0] * wq[k / 4][k % 4];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) acc[k] = fmaf(a[c4][j], wr[k], acc[k]);
+                for (int j = 1; j < 4; ++j) sacc = fmaf(a[i][j], wq[(12 * j + k) / 4][(12 * j + k) % 4], sacc);
+                v[i][kk] = sacc;
+            }
+        // transpose-reduce over the 8 channel-quad lanes: lane c4 ends with pixel index i == c4
+        float r4[4][4], r2[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float keep = h4 ? v[q + 4][kk] : v[q][kk], send = h4 ? v[q][kk] : v[q + 4][kk];
+                r4[q][kk] = keep + __shfl_xor(send, 4);
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float keep = h2b ? r4[q + 2][kk] : r4[q][kk], send = h2b ? r4[q][kk] : r4[q + 2][kk];
+                r2[q][kk] = keep + __shfl_xor(send, 2);
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float keep = h1 ? r2[1][kk] : r2[0][kk], send = h1 ? r2[0][kk] : r2[1][kk];
+            acc[co * 4 + kk] = keep + __shfl_xor(send, 1) + p.bias[co];
         }
     }
     float e = 0.f;
