@@ -29,6 +29,29 @@ __device__ __forceinline__ float tail_x(const TailP& p, size_t nx, int c, int y,
     return p.x[(nx * 3 + c) * (size_t)h2 * w2 + (size_t)y * w2 + x];
 }
 
+// the same value in two halves: the raw 32-bit load (issued early, so that waiting for it does not drain the younger
+// activation prefetches behind it - vmcnt retires in order) and its conversion at the point of use
+// The input format is a template argument there: with a run-time branch hipcc joins the two load paths on one register and
+// puts a vmcnt(0) in front of the load, which drains the queue just the same.
+template <bool XU8>
+__device__ __forceinline__ void tail_x_raw(const TailP& p, size_t nx, int y, int x, int h2, int w2, unsigned (&raw)[3]) {
+    if (XU8) {
+        // bytes 0,1 as ONE (unaligned) 16-bit load, split at the use: hipcc merges two byte loads into this load anyway, and
+        // then splits it right behind the load - a wait in the wrong place again
+        const unsigned char* q = (const unsigned char*)p.x + (nx * h2 * w2 + (size_t)y * w2 + x) * 3;
+        raw[0] = *(const unsigned short*)q;
+        raw[1] = q[2];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) raw[c] = __float_as_uint(p.x[(nx * 3 + c) * (size_t)h2 * w2 + (size_t)y * w2 + x]);
+    }
+}
+template <bool XU8>
+__device__ __forceinline__ float tail_x_cvt(const unsigned (&raw)[3], int c) {
+    if (XU8) return vad_norm_u8((unsigned char)(c == 0 ? raw[0] & 0xffu : c == 1 ? raw[0] >> 8 : raw[1]));
+    return __uint_as_float(raw[c]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -53,6 +76,7 @@ __device__ __forceinline__ void block_partial(float e, float* red, float* dst) {
 // with 32-B contiguous accesses per row.
 constexpr int TAIL_T = 32;   // tile side (output pixels) of the conv3x3 tail
 
+template <bool XU8>
 __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,7 +129,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
     f32x4 col[TAIL_T + 2][3];                  // col[k] = input column x0 - 1 + k (registers; static indices)
     // Columns 1..16 of a tile are always inside the image (W % 16 == 0): immediate offsets, no checks.
     // Column 0 (x0-1) and columns >= 17 may fall outside: the address is clamped (wave-uniform) and the
-    // two columns that can carry zero padding into a kept output (x = -1 and x = W) are multiplied by 0.
+    // two columns that can carry zero padding into a kept output (x = -1 and x = W) are multiplied by 0 - at their FIRST USE
+    // (MASK_COL, step k-2), not behind the load: a multiply there waits for the column just requested, i.e. for everything.
 #define LOAD_COL(k)                                                                          \
     {                                                                                        \
         if ((k) >= 1 && (k) <= 16) {                                                         \
@@ -114,13 +139,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
         } else {                                                                             \
             const int xx_ = x0 - 1 + (k);                                                    \
             const int xc_ = xx_ < 0 ? 0 : (xx_ > W - 1 ? W - 1 : xx_);                       \
-            const float mk_ = (xx_ == xc_) ? 1.f : 0.f;                                      \
-            _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                  \
-                f32x4 v_ = *(const f32x4*)(base + voff[r] + (xc_ - x0 - 15) * 128);          \
-                if ((k) == 0 || (k) == 17 || (k) == 33) v_ *= mk_;                           \
-                col[k][r] = v_;                                                              \
-            }                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 3; ++r)                                    \
+                col[k][r] = *(const f32x4*)(base + voff[r] + (xc_ - x0 - 15) * 128);         \
         }                                                                                    \
+    }
+#define MASK_COL(k)                                                                          \
+    if ((k) == 0 || (k) == 17 || (k) == 33) {                                                \
+        const int xx_ = x0 - 1 + (k);                                                        \
+        const float mk_ = (xx_ >= 0 && xx_ < W) ? 1.f : 0.f;                                 \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) col[k][r] *= mk_;                      \
     }
 #pragma unroll
     for (int k = 0; k < 2 + D; ++k) LOAD_COL(k);
@@ -128,10 +155,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
     const size_t plane = (size_t)H * W;
     float esum = 0.f;
     float v[8][3];
+    unsigned xraw[3] = {0u, 0u, 0u};
 #pragma unroll
     for (int s = 0; s < TAIL_T; ++s) {
+        if ((s & 7) == 0) {
+            // original-input values of the pixel this lane finishes 7 steps from now: requested BEFORE the columns below, so
+            // the wait at their use leaves the column prefetch in flight (loaded at the use they cost a vmcnt(0) - the whole
+            // queue drained plus one exposed HBM round trip - four times per tile)
+            const int x = x0 + s + cg;
+            if (y < H && x < W) tail_x_raw<XU8>(p, n, y, x, H, W, xraw);
+        }
         if (s + 2 + D < TAIL_T + 2) LOAD_COL(s + 2 + D);
         __builtin_amdgcn_sched_barrier(0);
+        if (s == 0) MASK_COL(0);
+        MASK_COL(s + 2);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -175,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
                 float e = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float d = tail_x(p, n, c, y, x, H, W) - rc[c];
+                    const float d = tail_x_cvt<XU8>(xraw, c) - rc[c];
                     e += d * d;
                     if (p.recon) p.recon[o + c * plane] = rc[c];
                 }
@@ -185,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_to3_score_kernel(TailP p) {
         }
     }
 #undef LOAD_COL
+#undef MASK_COL
     block_partial(esum, red, &p.partials[(size_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx]);
 }
 
@@ -343,7 +381,8 @@ int vad_conv3x3_to3_score_fmt(const float* in, const float* w_packed, const floa
     TailP p{in, w_packed, bias3, (const float*)x, partials, recon, errmap, h2, w2, (w2 + TAIL_T - 1) / TAIL_T, (h2 + TAIL_T - 1) / TAIL_T, 0, 0, fmt == VAD_X_U8_NHWC};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_to3_score: grid too large");
-    hipLaunchKernelGGL(conv3x3_to3_score_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.xu8) hipLaunchKernelGGL(conv3x3_to3_score_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_to3_score_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
