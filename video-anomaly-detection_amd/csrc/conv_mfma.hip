@@ -602,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     }
     const int ctiles = p.cout / 32;            // output-channel tiles, one after the other (one for every reference layer)
     float pre[NST];
+    bool oob[NST];              // uint8 input only: element is padding
     // staging element e = tid + 256*j -> (plane c, halo row ly, halo column lx).  Its offset inside a frame relative to the
     // tile origin and its (ly, lx) are fixed for the life of the work-group: computed ONCE (the divisions by 18 and 34 per
     // element and tile, plus the bounds tests, were ~25 VALU instructions per element and tile - on a pipe the exact-fp32
@@ -642,8 +643,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
             const __amdgpu_buffer_rsrc_t r = vad_rsrc((const unsigned char*)p.x + (size_t)n * frame_elems, frame_elems);
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
-                const unsigned b = __builtin_amdgcn_raw_buffer_load_b8(r, (int)off[j], 0, 0);
-                pre[j] = off[j] == VAD_OOB ? 0.f : vad_norm_u8(b & 255u);      // padding is 0.0 AFTER normalisation
+                // the RAW byte stays in flight (0x100 marks padding: 0.0 AFTER normalisation); it is normalised where it is
+                // written to LDS - arithmetic here would wait for each load in turn, eight exposed round trips per tile
+                const unsigned b = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off[j], 0, 0);
+                pre[j] = __uint_as_float(b);
+                oob[j] = off[j] == VAD_OOB;
             }
         } else {
             const __amdgpu_buffer_rsrc_t r = vad_rsrc(p.x + (size_t)n * frame_elems, frame_elems * 4u);
@@ -660,8 +664,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     for (; L < p.nblocks; L += gridDim.x) {
         __syncthreads();                                   // every wave is done reading the previous tile
 #pragma unroll
-        for (int j = 0; j < NST; ++j)
-            if (rel[j] != ~0u) tile[lds_pos[j]] = pre[j];
+        for (int j = 0; j < NST; ++j) {
+            float v = pre[j];
+            if (p.xu8) v = oob[j] ? 0.f : vad_norm_u8(__float_as_uint(v));
+            if (rel[j] != ~0u) tile[lds_pos[j]] = v;
+        }
         __syncthreads();
         const unsigned Ln = L + gridDim.x;
         if (Ln < p.nblocks) fetch(Ln);                     // in flight during the MFMAs below
@@ -679,6 +686,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                 for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
                 bv = p.bias[co];
                 have = nt;
+                // retire these loads HERE, inside the branch: left pending, hipcc guards the first MFMA below with a
+                // vmcnt(0) that runs on every tile - and, vmcnt being in order, drains the next tile's prefetch issued just
+                // above, tile after tile (the kernel sat at 0.56 matrix-pipe utilisation with its prefetch fully exposed)
+#pragma unroll
+                for (int s = 0; s < 14; ++s) asm volatile("" ::"v"(b[s]));
+                asm volatile("" ::"v"(bv));
             }
             f32x16 acc[MTW];
 #pragma unroll

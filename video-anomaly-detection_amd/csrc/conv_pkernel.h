@@ -187,18 +187,18 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 
     typedef typename std::conditional<FUSE_C3 != 0, float, f32x4>::type pf_t;
     pf_t pf[NPF];    // next stage's input, in flight
+    float cpv[MODE == MODE_LSTM ? MT : 1][16];   // ConvLSTM: previous cell state of this lane's outputs, in flight during the last chunk
 
     // both sources of a two-source (ConvLSTM) launch have the same channel count (host-checked), so svo serves both
     const unsigned in_bytes = FUSE_C3 ? (unsigned)(3 * H * W) * (p.xu8 ? 1u : 4u) : (unsigned)(H * W) * (unsigned)p.cin_a * 4u;
 #define ISSUE(n_, ch_)                                                                                   \
     {                                                                                                    \
         if constexpr (FUSE_C3) {                                                                         \
-            if (p.xu8) {   /* uint8 frames: normalise here; padding must be 0.0 AFTER normalisation */          \
+            if (p.xu8) {   /* uint8 frames: the RAW byte stays in flight; it is normalised where it is written to LDS  \
+                              (arithmetic behind the load would wait for it here: five exposed round trips per tile) */ \
                 const __amdgpu_buffer_rsrc_t r_ = vad_rsrc((const unsigned char*)p.in + (size_t)(n_) * p.in_fs, in_bytes); \
-                _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                     \
-                    const unsigned b_ = __builtin_amdgcn_raw_buffer_load_b8(r_, (int)svo[i_], 0, 0);     \
-                    pf_set(pf[i_], svo[i_] == VAD_OOB ? 0.f : vad_norm_u8(b_ & 255u));                   \
-                }                                                                                        \
+                _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_)                                       \
+                    pf_set(pf[i_], __uint_as_float((unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r_, (int)svo[i_], 0, 0))); \
             } else {                                                                                     \
                 const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(p.in + (size_t)(n_) * p.in_fs, in_bytes);     \
                 _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf_set(pf[i_], vad_bload1(r_, svo[i_], 0)); \
@@ -352,7 +352,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 for (int i = 0; i < NPF; ++i) {
                     const int idx = tid + 256 * i;
                     const int lx = idx % XW, t = idx / XW;   // t = c * XH + ly
-                    if (idx < TOT) xin[t * XS + lx] = pf_get_f(pf[i]);
+                    float xv = pf_get_f(pf[i]);
+                    // uint8 frames: normalise now; padding must be 0.0 AFTER normalisation
+                    if (p.xu8) xv = svo[i] == VAD_OOB ? 0.f : vad_norm_u8(__float_as_uint(xv));
+                    if (idx < TOT) xin[t * XS + lx] = xv;
                 }
                 STAMP(2);
                 __syncthreads();
@@ -498,6 +501,23 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 STAMP(3);
                 if (ch + 1 < nch) { ISSUE(n, ch + 1); }
                 else if (has_next) { ISSUE(nn, 0); }
+                if constexpr (MODE == MODE_LSTM) {
+                    // previous cell state of this tile: requested one chunk (36 k-steps) before the epilogue reads it.  Loaded in
+                    // the epilogue each value cost a vmcnt(0) - its own round trip plus the acknowledgement of the two stores in
+                    // front of it - 16 times per tile in a row.
+                    if (ch + 1 == nch) {
+                        const __amdgpu_buffer_rsrc_t rc_in = vad_rsrc(p.c_prev ? p.c_prev + (size_t)n * (out_bytes / 4) : p.c_out, p.c_prev ? out_bytes : 0u);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int dy = 2 * mt + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1);
+                                const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + dx) < ow);
+                                cpv[mt][r] = vad_bload1(rc_in, ok ? eoff[0] : VAD_OOB, dy * erow + dx * ecol);   // zero-sized descriptor -> 0 (initial state)
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             if constexpr (PREC) { LOAD_A_HALF(0, 0, MT); } else { LOAD_A(0, 0); }
             STAMP(4);
@@ -567,7 +587,6 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
         // Stores go through a buffer descriptor of this frame's output: offset = lane part (VGPR) + wave-uniform
         // (row, column) part (SGPR); elements outside a partial tile get offset VAD_OOB and are dropped.
         if (MODE == MODE_LSTM) {
-            const __amdgpu_buffer_rsrc_t rc_in = vad_rsrc(p.c_prev ? p.c_prev + (size_t)n * (out_bytes / 4) : p.c_out, p.c_prev ? out_bytes : 0u);
             const __amdgpu_buffer_rsrc_t rc_out = vad_rsrc(p.c_out + (size_t)n * (out_bytes / 4), out_bytes);
             const __amdgpu_buffer_rsrc_t rh_out = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
 #pragma unroll
@@ -578,9 +597,8 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                     const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + dx) < ow);
                     const unsigned vo = ok ? eoff[0] : VAD_OOB;                 // gate 0's channel == hidden channel
                     const unsigned so = dy * erow + dx * ecol;
-                    const float cp = vad_bload1(rc_in, vo, so);                  // zero-sized descriptor -> 0 (initial state)
                     float cn, hn;
-                    vad_lstm_cell(acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r], cp, cn, hn);
+                    vad_lstm_cell(acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r], cpv[mt][r], cn, hn);
                     vad_bstore1(cn, rc_out, vo, so);
                     vad_bstore1(hn, rh_out, vo, so);
                 }

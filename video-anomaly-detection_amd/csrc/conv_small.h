@@ -55,14 +55,8 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
     const unsigned wtap = (unsigned)(p.cin / 8) * wstep;           // bytes per tap
     const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 9u * wtap);
     unsigned wl[4];
-    f32x4 acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co = g * hid + hc;
-        wl[g] = (unsigned)co * 32u + 4u * (unsigned)kc;
-        const float bv = p.bias[co];
-        acc[g] = f32x4{bv, bv, bv, bv};
-    }
+    for (int g = 0; g < 4; ++g) wl[g] = (unsigned)(g * hid + hc) * 32u + 4u * (unsigned)kc;
 
     const int nch_a = p.cin_a / CK;
     const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
@@ -100,6 +94,26 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
 #pragma unroll
     for (int s0 = 0; s0 < PB; ++s0) SLOAD_B(s0, 0, s0);
 
+    // Every other load of the prologue goes out behind the first tile and the first weights, and nothing waits before all
+    // of them are requested: ONE round trip in front of the first MFMA (bias -> accumulators -> tile was three in a row, ~3 us
+    // of a ~35 us launch).
+    const size_t cfs = (size_t)H * W * hid;
+    float cpv[4];                            // previous cell state of this lane's 2x2 block (r = (dy, dx) of window kq)
+    {   // branch-free: a zero-sized descriptor (initial state) or an out-of-range offset (partial tile) reads 0.0
+        const __amdgpu_buffer_rsrc_t rc = vad_rsrc(p.c_prev ? p.c_prev + (size_t)n * cfs : p.c_out, p.c_prev ? (unsigned)cfs * 4u : 0u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+            cpv[r] = vad_bload1(rc, (y < H && x < W) ? (unsigned)(__mul24(__mul24(y, W) + x, hid) + hc) * 4u : VAD_OOB, 0);
+        }
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float bv = p.bias[g * hid + hc];
+        acc[g] = f32x4{bv, bv, bv, bv};
+    }
+
     for (int ch = 0; ch < nch; ++ch) {
         __syncthreads();                               // every wave is done reading the previous chunk
 #pragma unroll
@@ -132,8 +146,6 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
 #undef SLOAD_B
 
     // epilogue: registers r = 2x2 pixel block (dy = r>>1, dx = r&1) of window kq; gates of hidden channel hc in this lane
-    const size_t cfs = (size_t)H * W * hid;
-    const float* cprev = p.c_prev ? p.c_prev + (size_t)n * cfs : nullptr;
     float* cout_ = p.c_out + (size_t)n * cfs;
     float* hout = p.out + (size_t)n * p.out_fs;
 #pragma unroll
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
         if (y < H && x < W) {
             const size_t o = ((size_t)y * W + x) * hid + hc;
             float cn, hn;
-            vad_lstm_cell(acc[0][r], acc[1][r], acc[2][r], acc[3][r], cprev ? cprev[o] : 0.f, cn, hn);
+            vad_lstm_cell(acc[0][r], acc[1][r], acc[2][r], acc[3][r], cpv[r], cn, hn);
             cout_[o] = cn;
             hout[o] = hn;
         }

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
     const unsigned wstep = (unsigned)p.cout * (PREC ? 64u : 32u);      // bytes per (q, k-step) slab
     const unsigned wq = (unsigned)nk * wstep;                          // bytes per quadrant
     const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 4u * wq);
+    const __amdgpu_buffer_rsrc_t rz = vad_rsrc(p.w, 0u);              // zero-sized: every load through it returns 0 at once
     const unsigned in_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u;
     const int oh = 2 * H, ow = 2 * W;
     const unsigned out_bytes = (unsigned)(oh * ow) * (unsigned)p.cout * 4u;
@@ -81,20 +82,26 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
 #define CT_LOAD(buf, ks)                                                                          \
     {                                                                                             \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
-            a0[buf][mt] = vad_bload4(ra, ao[mt], (unsigned)(ks) * 64u);                           \
-            a1[buf][mt] = vad_bload4(ra, ao[mt], (unsigned)(ks) * 64u + 16u);                     \
+            a0[buf][mt] = vad_bload4(ra_, ao[mt], (unsigned)(ks) * 64u);                           \
+            a1[buf][mt] = vad_bload4(ra_, ao[mt], (unsigned)(ks) * 64u + 16u);                     \
         }                                                                                         \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                       \
-            bh[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw, bo[nt], (unsigned)(ks) * wstep)); \
-            bl[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw, bo[nt] + 16u, (unsigned)(ks) * wstep)); \
+            bh[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw_, bo[nt], (unsigned)(ks) * wstep)); \
+            bl[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw_, bo[nt] + 16u, (unsigned)(ks) * wstep)); \
         }                                                                                         \
     }
-            CT_LOAD(0, 0);
+            { const __amdgpu_buffer_rsrc_t ra_ = ra, rw_ = rw; CT_LOAD(0, 0); }
             for (int ks = 0; ks < nk; ks += 2) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if (ks + u < nk) {
-                        if (ks + u + 1 < nk) { if (u == 0) { CT_LOAD(1, ks + 1); } else { CT_LOAD(0, ks + 2); } }
+                    {
+                        // nk is even (cin % 32 == 0, host-checked).  The prefetch is UNCONDITIONAL - behind the last step it goes
+                        // through a zero-sized descriptor (answered with zeros, no memory access): issued under
+                        // `if (ks+u+1 < nk)`, hipcc merged the two paths into a vmcnt(0) in front of the MFMAs, which waits for the
+                        // prefetch it has just issued - every k-step paid a full L2 round trip.
+                        const bool more = ks + u + 1 < nk;
+                        const __amdgpu_buffer_rsrc_t ra_ = more ? ra : rz, rw_ = more ? rw : rz;
+                        if (u == 0) { CT_LOAD(1, ks + 1); } else { CT_LOAD(0, ks + 2); }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
@@ -125,15 +132,21 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
             f32x4 a[2][MT], b[2][NT];
 #define CT_LOAD(buf, ks)                                                                          \
     {                                                                                             \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) a[buf][mt] = vad_bload4(ra, ao[mt], (unsigned)(ks) * 32u); \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = vad_bload4(rw, bo[nt], (unsigned)(ks) * wstep); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) a[buf][mt] = vad_bload4(ra_, ao[mt], (unsigned)(ks) * 32u); \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = vad_bload4(rw_, bo[nt], (unsigned)(ks) * wstep); \
     }
-            CT_LOAD(0, 0);
+            { const __amdgpu_buffer_rsrc_t ra_ = ra, rw_ = rw; CT_LOAD(0, 0); }
             for (int ks = 0; ks < nk; ks += 2) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if (ks + u < nk) {
-                        if (ks + u + 1 < nk) { if (u == 0) { CT_LOAD(1, ks + 1); } else { CT_LOAD(0, ks + 2); } }
+                    {
+                        // nk is even (cin % 32 == 0, host-checked).  The prefetch is UNCONDITIONAL - behind the last step it goes
+                        // through a zero-sized descriptor (answered with zeros, no memory access): issued under
+                        // `if (ks+u+1 < nk)`, hipcc merged the two paths into a vmcnt(0) in front of the MFMAs, which waits for the
+                        // prefetch it has just issued - every k-step paid a full L2 round trip.
+                        const bool more = ks + u + 1 < nk;
+                        const __amdgpu_buffer_rsrc_t ra_ = more ? ra : rz, rw_ = more ? rw : rz;
+                        if (u == 0) { CT_LOAD(1, ks + 1); } else { CT_LOAD(0, ks + 2); }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
