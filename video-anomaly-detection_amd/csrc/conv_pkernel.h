@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     constexpr int PB = (PREC == 2) ? 5 : (PREC && NT <= 2) ? 2 : PREC ? 1 : PB32, NB = PB + 1;   // bf16 steps are a third of the split ones again
     static_assert(NS % 2 == 0 && NS % NB == 0, "fragment ring parity must be the same in every chunk");
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
+    // raw input halo of the fused first layer.  Two barriers per frame, not three: the NEXT frame's halo is written right
+    // behind the barrier that ends this frame's first stage (every wave is done reading the buffer) and is published by the
+    // barrier at the top of the next frame.  (A second buffer would let it go out earlier still, but 4.8 KB more LDS per
+    // work-group drops the kernel from three work-groups per CU to two.)
     __shared__ float xin[FUSE_C3 ? 3 * XH * XS : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -212,6 +216,19 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
         }                                                                                                \
     }
 
+    // fused first layer: the staged raw values of pf go to the halo buffer `xb_` (uint8 frames are normalised here; padding
+    // must be 0.0 AFTER normalisation)
+#define XWRITE(xb_)                                                                                      \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                             \
+            const int idx_ = tid + 256 * i_;                                                             \
+            const int lx_ = idx_ % XW, t_ = idx_ / XW;   /* t = c * XH + ly */                           \
+            float xv_ = pf_get_f(pf[i_]);                                                                \
+            if (p.xu8) xv_ = svo[i_] == VAD_OOB ? 0.f : vad_norm_u8(__float_as_uint(xv_));               \
+            if (idx_ < TOT) (xb_)[t_ * XS + lx_] = xv_;                                                  \
+        }                                                                                                \
+    }
+
 #ifdef VAD_STAMPS
     unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_n = 0;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -220,6 +237,12 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     int n = fg;
     if (n >= p.n) return;                                          // (grid never exceeds the work; defensive)
     ISSUE(n, 0);
+    if constexpr (FUSE_C3) {
+        // first frame's halo (published by the barrier at the top of the frame loop), then the second frame's prefetch: from
+        // here on pf always holds the frame AFTER the one being computed
+        XWRITE(xin);
+        if (n + fgroups < p.n) { ISSUE(n + fgroups, 0); }
+    }
 
     // per-lane weight rows / bias of this cout block
     f32x4 a[2][MT], b[NB][NT];          // PREC 0 fragments
@@ -341,30 +364,13 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
             __syncthreads();                       // every wave is done reading the previous stage
             STAMP(1);
             if constexpr (FUSE_C3) {
-                if constexpr (!PREC) {   // in flight during the LDS write and the barrier below; wave-coalesced 128-B rows, L1 hits
+                if constexpr (!PREC) {   // wave-coalesced 128-B rows, L1 hits; nothing younger is in flight when the MFMAs wait for them
 #pragma unroll
                     for (int s0 = 0; s0 < 14; ++s0) b0w[s0] = p.w0[(s0 * 2 + lh) * 32 + li];
-                    // pin them HERE: sunk to their first use they would be younger than the next tile's prefetch, and waiting
-                    // for them (vmcnt is in order) would drain that prefetch in front of the first-stage MFMAs
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int i = 0; i < NPF; ++i) {
-                    const int idx = tid + 256 * i;
-                    const int lx = idx % XW, t = idx / XW;   // t = c * XH + ly
-                    float xv = pf_get_f(pf[i]);
-                    // uint8 frames: normalise now; padding must be 0.0 AFTER normalisation
-                    if (p.xu8) xv = svo[i] == VAD_OOB ? 0.f : vad_norm_u8(__float_as_uint(xv));
-                    if (idx < TOT) xin[t * XS + lx] = xv;
-                }
                 STAMP(2);
-                __syncthreads();
                 STAMP(3);
-                if constexpr (!PREC) {   // retire the (old, long arrived) weight loads BEFORE the prefetch goes out: no vmcnt wait is
-#pragma unroll                           // left in front of the first-stage MFMAs that would also drain the prefetch
-                    for (int s0 = 0; s0 < 14; ++s0) asm volatile("" ::"v"(b0w[s0]));
-                }
-                if (has_next) { ISSUE(nn, 0); }
                 STAMP(7);
                 // Fused first layer: Conv2d(3->32)+BN+LeakyReLU of the tile AND its halo, K = 27 padded to 28
                 // (14 MFMAs per 32 pixels), written straight into the LDS tile the 32->32 convolution reads.
@@ -474,6 +480,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 STAMP(8);
                 __syncthreads();
                 STAMP(9);
+                // NEXT frame's halo (prefetched a whole frame ago) into the buffer every wave has finished reading, then the
+                // prefetch of the frame after it: in flight during the main loop below and the next first stage
+                if (has_next) { XWRITE(xin); }
+                if (nn + fgroups < p.n) { ISSUE(nn + fgroups, 0); }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)     // accumulators start after the fused stage: its registers are dead now
 #pragma unroll
@@ -647,6 +657,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #undef LOAD_A_HALF
 #undef LOAD_B
 #undef ISSUE
+#undef XWRITE
 #ifdef VAD_STAMPS
     if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
