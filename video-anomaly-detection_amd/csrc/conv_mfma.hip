@@ -659,7 +659,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     // reference layer.  (Without restrict the compiler cannot hoist loads out of the tile loop past the stores.)
     float b[14], bv = 0.f;
     int have = -1;
-    unsigned L = blockIdx.x;
+    // XCD-aware walk: in every round of gridDim.x tiles, the work-groups of one XCD take a CONTIGUOUS run of tiles (four tile
+    // rows at 256x256), so neighbours that share 128-byte input lines (a tile row is 18 floats of a line; a line spans two
+    // tiles) share an L2.  Dealt round-robin, every XCD fetched the lines for itself: 1.91 GB per 640 frames for 0.50 GB of
+    // input (FETCH_SIZE, profiles/r02_pmc_traffic_video.json before this change).
+    unsigned L = vad_xcd_remap(blockIdx.x, gridDim.x);
     if (L < p.nblocks) fetch(L);
     for (; L < p.nblocks; L += gridDim.x) {
         __syncthreads();                                   // every wave is done reading the previous tile
