@@ -51,8 +51,13 @@ __device__ __forceinline__ float vad_act(float v, int act) {
 
 // Gate non-linearities of the ConvLSTM epilogue on the hardware transcendental unit (v_exp_f32 / v_rcp_f32,
 // ~1 ulp each): 4-5 instructions instead of the ~40 of libm's expf/tanhf, absolute error ~1e-7.
-__device__ __forceinline__ float vad_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
-__device__ __forceinline__ float vad_tanh(float v) { return __builtin_fmaf(-2.0f, __frcp_rn(__expf(2.0f * v) + 1.0f), 1.0f); }
+// Reciprocal on the transcendental unit (v_rcp_f32, 1 ulp).  `__frcp_rn` / `1.0f / x` is the correctly rounded division: ten VALU
+// instructions (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup) - five of them per ConvLSTM cell made 800 of the
+// ~900 VALU instructions of that kernel's epilogue, on the pipe its MFMAs use.  The sigmoid / tanh built on it stay within
+// ~2e-7 of libm's (tests hold the scores to 1e-5 of the oracle).
+__device__ __forceinline__ float vad_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float vad_sigmoid(float v) { return vad_rcp(1.0f + __expf(-v)); }
+__device__ __forceinline__ float vad_tanh(float v) { return __builtin_fmaf(-2.0f, vad_rcp(__expf(2.0f * v) + 1.0f), 1.0f); }
 // ConvLSTMCell state update (reference models/video_autoencoder.py:76-83) from the four gate pre-activations.  The
 // contractions are spelled out so that every kernel that fuses it (32x32x2 persistent / one-tile forms, 16x16x4 small-grid
 // form) rounds identically: c' = fma(sigmoid(f), c, sigmoid(i)*tanh(g)), h' = sigmoid(o) * tanh(c').
