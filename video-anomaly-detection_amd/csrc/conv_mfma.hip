@@ -778,15 +778,10 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
         if (!cap) cap_ = cap = persistent_grid(conv3x3_c3_pkernel<POOL, ACT>, ~0u);                        \
         hipLaunchKernelGGL((conv3x3_c3_pkernel<POOL, ACT>), dim3(p.nblocks < cap ? p.nblocks : cap), dim3(256), 0, s, p); \
     }
-        if (pool) {
-            if (act == VAD_ACT_LEAKY) C3P_LAUNCH(1, VAD_ACT_LEAKY)
-            else if (act == VAD_ACT_RELU) C3P_LAUNCH(1, VAD_ACT_RELU)
-            else C3P_LAUNCH(1, VAD_ACT_NONE)
-        } else {
-            if (act == VAD_ACT_LEAKY) C3P_LAUNCH(0, VAD_ACT_LEAKY)
-            else if (act == VAD_ACT_RELU) C3P_LAUNCH(0, VAD_ACT_RELU)
-            else C3P_LAUNCH(0, VAD_ACT_NONE)
-        }
+        // (pooled form only: the un-pooled instantiation of this kernel needed 256 registers + 276 bytes of scratch)
+        if (act == VAD_ACT_LEAKY) C3P_LAUNCH(1, VAD_ACT_LEAKY)
+        else if (act == VAD_ACT_RELU) C3P_LAUNCH(1, VAD_ACT_RELU)
+        else C3P_LAUNCH(1, VAD_ACT_NONE)
 #undef C3P_LAUNCH
         VAD_LAUNCH_CHECK();
         return VAD_OK;
