@@ -587,9 +587,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
 // the current one is computed (3 planes x 34 x 18 values = 8 per thread).
 template <int POOL, int ACT>
 __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
+    static_assert(POOL == 1, "pooled form only (the un-pooled one is the non-persistent kernel above)");
     constexpr int MTW = 4, TH = 2 * MTW * 4, LH = TH + 2, RS = 20, NE = 3 * LH * 18, NST = (NE + 255) / 256;
-    __shared__ float tile[3 * LH * RS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float tile[3 * LH * RS + 1];              // + one dummy slot: staging slots past the tile write there
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int prow = (li >> 1) & 1, pcol = 2 * (li >> 2) + (li & 1);
     int koff[14];
@@ -602,22 +604,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     }
     const int ctiles = p.cout / 32;            // output-channel tiles, one after the other (one for every reference layer)
     float pre[NST];
-    bool oob[NST];              // uint8 input only: element is padding
-    // staging element e = tid + 256*j -> (plane c, halo row ly, halo column lx).  Its offset inside a frame relative to the
-    // tile origin and its (ly, lx) are fixed for the life of the work-group: computed ONCE (the divisions by 18 and 34 per
-    // element and tile, plus the bounds tests, were ~25 VALU instructions per element and tile - on a pipe the exact-fp32
-    // MFMAs share; the kernel had 1,467 VALU instructions for its 56 MFMAs and ran at 0.48 matrix-pipe utilisation).
-    // Interior tiles (the majority) add one tile base per element; border tiles test (ly, lx) against the image.
-    unsigned rel[NST];          // element offset (in input elements) relative to the tile's first halo pixel; ~0u past the tile
-    unsigned lyx[NST];          // ly << 8 | lx
-    int lds_pos[NST];           // where the element goes in the LDS tile
+    bool oob[NST];              // uint8 input, border tiles only: element is padding
+    // VALU work shares the pipe with the exact-fp32 MFMAs, and this kernel has only 56 MFMAs per tile to
+    // hide it behind: everything that does not change from tile to tile is computed ONCE per work-group, and what changes is
+    // wave-uniform and rides in the scalar offset of the buffer instructions.
+    //   staging element e = tid + 256*j -> (plane c, halo row ly, halo column lx): its BYTE offset relative to the tile's
+    //   first halo pixel (rel[j], VAD_OOB past the tile), its (ly, lx) for the border tiles, its LDS slot;
+    //   epilogue: the lane's part of an output offset (column half lh, channel li).
+    const unsigned esz = p.xu8 ? 1u : 4u;
     const unsigned plane_e = p.xu8 ? 1u : (unsigned)(p.h * p.w_), px_e = p.xu8 ? 3u : 1u;   // u8 NHWC: pixel stride 3, channel stride 1
+    unsigned rel[NST];
+    unsigned lyx[NST];          // ly << 8 | lx
+    int lds_pos[NST];
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
         const int e = tid + 256 * j, lx = e % 18, t = e / 18, ly = t % LH, c = t / LH;
-        rel[j] = e < NE ? (unsigned)((ly * p.w_ + lx) * (int)px_e) + (unsigned)c * plane_e : ~0u;
+        rel[j] = e < NE ? ((unsigned)((ly * p.w_ + lx) * (int)px_e) + (unsigned)c * plane_e) * esz : VAD_OOB;
         lyx[j] = (unsigned)(ly << 8 | lx);
-        lds_pos[j] = (c * LH + ly) * RS + lx;
+        lds_pos[j] = e < NE ? (c * LH + ly) * RS + lx : 3 * LH * RS;
     }
     const unsigned frame_elems = 3u * (unsigned)(p.h * p.w_);
     auto fetch = [&](unsigned L) {
@@ -626,39 +630,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
         const int n = L / p.tiles_y;
         const int gy0 = ty * TH - 1, gx0 = tx * 16 - 1;                       // first halo pixel of the tile
         const bool inner = gy0 >= 0 && gx0 >= 0 && gy0 + LH <= p.h && gx0 + 18 <= p.w_;      // wave-uniform
-        const int origin = (gy0 * p.w_ + gx0) * (int)px_e;                    // negative on top / left border tiles
-        // branch-free: elements outside the image (or past the tile) get the out-of-range offset and the buffer load
-        // returns 0 by itself; one uniform branch selects the input format
-        unsigned off[NST];
+        const int origin = (gy0 * p.w_ + gx0) * (int)px_e * (int)esz;         // bytes; negative on top / left border tiles
+        const __amdgpu_buffer_rsrc_t r = vad_rsrc((const char*)p.x + (size_t)n * frame_elems * esz, frame_elems * esz);
+        // one uniform branch selects the input format, one the tile kind; an interior tile (most of them) costs no vector
+        // arithmetic at all: per-lane offset rel[j] + scalar offset origin
+        if (inner) {
+            if (p.xu8) {
 #pragma unroll
-        for (int j = 0; j < NST; ++j) {
-            bool ok = rel[j] != ~0u;
-            if (!inner) {
-                const int gy = gy0 + (int)(lyx[j] >> 8), gx = gx0 + (int)(lyx[j] & 255u);
-                ok = ok && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
-            }
-            off[j] = ok ? (unsigned)(origin + (int)rel[j]) : VAD_OOB;
-        }
-        if (p.xu8) {
-            const __amdgpu_buffer_rsrc_t r = vad_rsrc((const unsigned char*)p.x + (size_t)n * frame_elems, frame_elems);
+                for (int j = 0; j < NST; ++j) {
+                    // the RAW byte stays in flight; it is normalised where it is written to LDS - arithmetic here would wait
+                    // for each load in turn, eight exposed round trips per tile
+                    pre[j] = __uint_as_float((unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, (int)rel[j], origin, 0));
+                    oob[j] = false;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < NST; ++j) {
-                // the RAW byte stays in flight (0x100 marks padding: 0.0 AFTER normalisation); it is normalised where it is
-                // written to LDS - arithmetic here would wait for each load in turn, eight exposed round trips per tile
-                const unsigned b = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off[j], 0, 0);
-                pre[j] = __uint_as_float(b);
-                oob[j] = off[j] == VAD_OOB;
+                for (int j = 0; j < NST; ++j) pre[j] = vad_bload1(r, rel[j], (unsigned)origin);
             }
         } else {
-            const __amdgpu_buffer_rsrc_t r = vad_rsrc(p.x + (size_t)n * frame_elems, frame_elems * 4u);
+            // border tile: elements outside the image get the out-of-range offset and the buffer load returns 0 by itself
 #pragma unroll
-            for (int j = 0; j < NST; ++j) pre[j] = vad_bload1(r, off[j] == VAD_OOB ? VAD_OOB : off[j] * 4u, 0);
+            for (int j = 0; j < NST; ++j) {
+                const int gy = gy0 + (int)(lyx[j] >> 8), gx = gx0 + (int)(lyx[j] & 255u);
+                const bool ok = rel[j] != VAD_OOB && (unsigned)gy < (unsigned)p.h && (unsigned)gx < (unsigned)p.w_;
+                const unsigned off = ok ? (unsigned)(origin + (int)rel[j]) : VAD_OOB;
+                if (p.xu8) {
+                    pre[j] = __uint_as_float((unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, (int)off, 0, 0));
+                    oob[j] = !ok;                                              // padding is 0.0 AFTER normalisation
+                } else {
+                    pre[j] = vad_bload1(r, off, 0);
+                }
+            }
         }
     };
     // B fragments + bias: ONE register set, (re)loaded only when the channel tile changes - once per work-group for every
     // reference layer.  (Without restrict the compiler cannot hoist loads out of the tile loop past the stores.)
     float b[14], bv = 0.f;
     int have = -1;
+    const int oh = p.h >> 1, ow = p.w_ >> 1;
+    const unsigned orow = (unsigned)(ow * p.cout) * 4u, ocol = (unsigned)p.cout * 4u;      // bytes per pooled output row / pixel
     // XCD-aware walk: in every round of gridDim.x tiles, the work-groups of one XCD take a CONTIGUOUS run of tiles (four tile
     // rows at 256x256), so neighbours that share 128-byte input lines (a tile row is 18 floats of a line; a line spans two
     // tiles) share an L2.  Dealt round-robin, every XCD fetched the lines for itself: 1.91 GB per 640 frames for 0.50 GB of
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
         for (int j = 0; j < NST; ++j) {
             float v = pre[j];
             if (p.xu8) v = oob[j] ? 0.f : vad_norm_u8(__float_as_uint(v));
-            if (rel[j] != ~0u) tile[lds_pos[j]] = v;
+            tile[lds_pos[j]] = v;
         }
         __syncthreads();
         const unsigned Ln = L + gridDim.x;
@@ -681,10 +691,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
         const int ty = t_ % p.tiles_y;
         const int n = t_ / p.tiles_y;
         const int y0 = ty * TH, x0 = tx * 16;
-        const __amdgpu_buffer_rsrc_t rout = vad_rsrc(p.out + (size_t)n * (POOL ? (p.h >> 1) * (p.w_ >> 1) : p.h * p.w_) * p.cout,
-                                                     (unsigned)((POOL ? (p.h >> 1) * (p.w_ >> 1) : p.h * p.w_) * p.cout) * 4u);
+        const __amdgpu_buffer_rsrc_t rout = vad_rsrc(p.out + (size_t)n * (oh * ow) * p.cout, (unsigned)(oh * ow * p.cout) * 4u);
+        // this wave's first pooled row / the tile's first pooled column, as a byte offset inside the frame (scalar)
+        const int oy0 = (y0 >> 1) + wave * MTW, ox0 = x0 >> 1;
+        const unsigned ubase = (unsigned)oy0 * orow + (unsigned)ox0 * ocol;
+        const bool full = oy0 + MTW <= oh && ox0 + 8 <= ow;                    // wave-uniform: no window of this wave is outside
         for (int nt = 0; nt < ctiles; ++nt) {
             const int co = nt * 32 + li;
+            const unsigned lanepart = (unsigned)(lh * p.cout + co) * 4u;
             if (have != nt) {
 #pragma unroll
                 for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                 have = nt;
                 // retire these loads HERE, inside the branch: left pending, hipcc guards the first MFMA below with a
                 // vmcnt(0) that runs on every tile - and, vmcnt being in order, drains the next tile's prefetch issued just
-                // above, tile after tile (the kernel sat at 0.56 matrix-pipe utilisation with its prefetch fully exposed)
+                // above, tile after tile
 #pragma unroll
                 for (int s = 0; s < 14; ++s) asm volatile("" ::"v"(b[s]));
                 asm volatile("" ::"v"(bv));
@@ -722,26 +736,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
             for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int wq = 2 * q + lh;
-                    float v[4];
-#pragma unroll
-                    for (int pos = 0; pos < 4; ++pos) v[pos] = POOL ? acc[mt][4 * q + pos] : vad_act(acc[mt][4 * q + pos], ACT);
-                    if (POOL) {
-                        // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one activation
-                        // per window instead of four
-                        const float m = vad_act(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), ACT);
-                        const int oy = (y0 >> 1) + (wave * MTW + mt), ox = (x0 >> 1) + wq;
-                        // branch-free: a window outside the (pooled) image gets the out-of-range offset and the store is dropped
-                        const bool ok = oy < (p.h >> 1) && ox < (p.w_ >> 1);
-                        vad_bstore1(m, rout, ok ? (unsigned)(__mul24(__mul24(oy, p.w_ >> 1) + ox, p.cout) + co) * 4u : VAD_OOB, 0);
-                    } else {
-#pragma unroll
-                        for (int pos = 0; pos < 4; ++pos) {
-                            const int y = y0 + 2 * (wave * MTW + mt) + (pos >> 1), x = x0 + 2 * wq + (pos & 1);
-                            if (y < p.h && x < p.w_)
-                                p.out[(((size_t)n * p.h + y) * p.w_ + x) * p.cout + co] = v[pos];
-                        }
-                    }
+                    // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one activation
+                    // per window instead of four; vad_vmax = one v_max_f32 (fmaxf adds a canonicalising max per operand)
+                    const float m = vad_act(vad_vmax(vad_vmax(acc[mt][4 * q], acc[mt][4 * q + 1]), vad_vmax(acc[mt][4 * q + 2], acc[mt][4 * q + 3])), ACT);
+                    // lane part (column half, channel) + scalar part (row, column pair); a window outside the pooled image
+                    // (partial tiles only) gets the out-of-range offset and the store is dropped
+                    unsigned vo = lanepart;
+                    if (!full) vo = ((oy0 + mt) < oh && (ox0 + 2 * q + lh) < ow) ? lanepart : VAD_OOB;
+                    vad_bstore1(m, rout, vo, ubase + (unsigned)mt * orow + (unsigned)(2 * q) * ocol);
                 }
             }
         }
