@@ -269,28 +269,34 @@ extern "C" int vad_debug_set_stamp_buffer(void* p) { g_vad_dbg = (unsigned long 
 static std::atomic<int> g_vad_conv_bits{1};   // bit 0: 1 = persistent + register prefetch (default), 0 = one tile per work-group;
                                               // bit 1: pricing runs, results invalid (exact: drop epilogue stores; split: no weight reads);
                                               // bit 2: alternative cout-64 tiling;
-                                              // bit 3: never use the small-grid (16x16x4) ConvLSTM kernel
-extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 15; return VAD_OK; }
+                                              // bit 3: never use the small-grid (16x16x4) ConvLSTM kernel; bit 4: always use it
+extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 31; return VAD_OK; }
 struct ConvKnobs {
-    int variant, stagger, conv64, no_small;
+    int variant, stagger, conv64, no_small, all_small;
     ConvKnobs() {
         const int b = g_vad_conv_bits.load(std::memory_order_relaxed);
-        variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; no_small = (b >> 3) & 1;
+        variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; no_small = (b >> 3) & 1; all_small = (b >> 4) & 1;
     }
 };
 #define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT || precision == VAD_PREC_BF16, who ": precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1) or VAD_PREC_BF16 (2)", precision)
 
-template <typename K>
-static unsigned persistent_grid(K kernel, unsigned nblocks, int max_per_cu = 2) {
-    int per_cu = 0, dev = 0;
+static int vad_num_cus() {
     static std::atomic<int> ncu_cached{0};
     int ncu = ncu_cached.load(std::memory_order_relaxed);
     if (!ncu) {
+        int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
         ncu_cached = ncu;
     }
+    return ncu;
+}
+
+template <typename K>
+static unsigned persistent_grid(K kernel, unsigned nblocks, int max_per_cu = 2) {
+    int per_cu = 0;
+    const int ncu = vad_num_cus();
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     // Use EVERY resident slot the hardware offers: with fewer work-groups than slots the dispatcher packs some CUs
     // to their limit and leaves others with one group, and a persistent grid then runs at the pace of the fullest CU.
@@ -482,8 +488,17 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
     // Small grids (the reference's own batch sizes: 4 clips, or 1 window): the 32x32x2 tiling yields 8 work-groups per clip of
     // a 16x16 map, each a 123 us serial K loop; below one work-group per CU the 16x16x4 form (4x the waves, a quarter of the
     // latency, bit-identical results: conv_small.h) wins - 133 -> ~35 us per step at B <= 8.
+    // Above that the small form still wins where the large one quantises badly: a launch takes as long as its fullest CU, which
+    // runs m = ceil(groups / CUs) of the large work-groups two at a time (measured per step, 16x16 map, hid 128: 0.166 ms alone,
+    // 0.30 ms for a pair), while the small form's time is proportional to the work (0.354 ms at 64 clips).  40 clips: 0.281 ms
+    // large (64 CUs hold a pair, 192 one group and wait) vs 0.228 ms small; 64 clips: 0.320 vs 0.354.
     const long long nb_big = (long long)n * ((wd + 15) / 16) * ((h + 3) / 4) * (hid / 64);
-    if (precision == VAD_PREC_FP32 && kn.variant != 0 && !kn.no_small && nb_big < 256) {
+    const int ncu = vad_num_cus();
+    const long long m_big = (nb_big + ncu - 1) / ncu;
+    const double cost_big = 2.0 * (double)(m_big / 2) + 1.107 * (double)(m_big % 2);     // in units of half a pair's time
+    const double cost_small = 1.178 * (double)nb_big / (double)ncu;
+    const bool small_wins = nb_big < ncu || cost_small < cost_big;
+    if (precision == VAD_PREC_FP32 && kn.variant != 0 && !kn.no_small && (small_wins || kn.all_small)) {
         p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 1) / 2; p.cblocks = hid / 32;
         const long long nb = (long long)n * p.tiles_x * p.tiles_y * p.cblocks;
         p.nblocks = (unsigned)nb; p.n = n;
