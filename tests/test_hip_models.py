@@ -420,6 +420,23 @@ def test_video_fresh_inputs_vs_oracle(vad):
     assert max_abs(out["recon"].cpu().numpy(), ref["recon"].numpy()) < ACT_ATOL
 
 
+def test_empty_batches_give_empty_outputs(vad):
+    """Edge case: the reference's modules accept a batch of zero items (every torch layer does) and return empty tensors of the
+    right shape; so do the HIP-backed ones, without launching anything."""
+    mi, _ = _img_model(vad, 128, 7)
+    mv, _ = _vid_model(vad, 128, 128, 2, 43)
+    with torch.no_grad():
+        assert mi(torch.empty(0, 3, 64, 64, device="cuda")).shape == (0, 3, 64, 64)
+        assert mi.get_reconstruction_error(torch.empty(0, 3, 64, 64, device="cuda")).shape == (0,)
+        out = mv.score_all(torch.empty(0, 5, 3, 64, 64, device="cuda"))
+        assert out["seq"].shape == (0,) and out["frame"].shape == (0, 5) and out["recon"].shape == (0, 5, 3, 64, 64)
+        # a ragged tail after full batches: 5 clips in batches of 4 equal the same 5 clips in one call, bit for bit
+        x = torch.from_numpy(vad.synth.clips(99, 0, 5, 4, 3, 32, 32)).cuda()
+        whole = mv.score_all(x)["seq"]
+        parts = torch.cat([mv.score_all(x[:4])["seq"], mv.score_all(x[4:])["seq"]])
+        assert torch.equal(whole, parts)
+
+
 def test_full_size_properties(vad):
     """BASELINE configs[1]/[2] frame size (256x256), moderate batch: size-independent checks — score equals the
     mean of the error map, clip score equals the mean of frame scores, and a strided subset matches the oracle."""

@@ -216,6 +216,8 @@ class ConvAutoencoder(nn.Module):
                 out["recon"] = torch.empty(b, 3, h, w, dtype=torch.float32, device=dev)
             if latent:
                 out["latent"] = torch.empty(b, self.latent_dim, h // 16, w // 16, dtype=torch.float32, device=dev)
+        if b == 0:                                        # an empty batch gives empty outputs, as the reference's modules do
+            return out
         with torch.cuda.device(dev):
             hip.check(l.vad_img_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, h, w,
                                         self.latent_dim, packed.data_ptr(), ws.data_ptr(),

@@ -227,6 +227,8 @@ class VideoAutoencoder(nn.Module):
                 out["errmap"] = torch.empty(b, t, 1, h, w, dtype=torch.float32, device=dev)
             if recon:
                 out["recon"] = torch.empty(b, t, 3, h, w, dtype=torch.float32, device=dev)
+        if b == 0:                                        # an empty batch gives empty outputs, as the reference's modules do
+            return out
         with torch.cuda.device(dev):
             hip.check(l.vad_vid_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, t, h, w, *dims,
                                         packed.data_ptr(), ws.data_ptr(), ws.numel(),
