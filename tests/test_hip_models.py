@@ -197,6 +197,23 @@ def test_video_config2_full_size_vs_oracle(vad):
     assert rel_err(out["frame"][idx].cpu().numpy(), ref["frame"].numpy()) < SCORE_RTOL
 
 
+@pytest.mark.parametrize("clips", [24, 40, 48, 72])
+def test_video_scores_do_not_depend_on_the_convlstm_kernel_form(vad, clips):
+    """At 256x256 the ConvLSTM step is run by the small-grid (16x16x4) kernel or by the large (32x32x2) one, chosen per launch
+    from the number of clips (conv_mfma.hip, vad_convlstm_step: below one work-group per CU, and above it wherever the large
+    form would leave most CUs waiting for the fullest one - 40, 48, 72 clips).  Whatever the choice, a clip's scores are the
+    bits it gets inside the 64-clip launch group of configs[2] (large kernel) and alone (small kernel)."""
+    m, _ = _vid_model(vad, 128, 128, 2, 8)
+    x = vad.scoring.synth_frames_device(0xC0FFEE + 2, 0, 72 * 3).view(72, 3, 3, 256, 256)
+    with torch.no_grad():
+        big = m.score_seq_and_frames(x[:64])
+        got = m.score_seq_and_frames(x[:clips])
+        alone = m.score_seq_and_frames(x[clips - 1:clips])
+    k = min(clips, 64)
+    assert torch.equal(got["seq"][:k], big["seq"][:k]) and torch.equal(got["frame"][:k], big["frame"][:k])
+    assert torch.equal(got["seq"][-1:], alone["seq"]) and torch.equal(got["frame"][-1:], alone["frame"])
+
+
 def test_video_causal_and_clip_independent(vad):
     """Reference properties (SURVEY.md section 4): perturbing frames >= k leaves frame scores < k bit-identical;
     a clip's scores do not depend on the rest of the batch."""
