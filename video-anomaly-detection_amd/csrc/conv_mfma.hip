@@ -602,7 +602,6 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
 // the current one is computed (3 planes x 34 x 18 values = 8 per thread).
 template <int POOL, int ACT>
 __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
-    static_assert(POOL == 1, "pooled form only (the un-pooled one is the non-persistent kernel above)");
     constexpr int MTW = 4, TH = 2 * MTW * 4, LH = TH + 2, RS = 20, NE = 3 * LH * 18, NST = (NE + 255) / 256;
     __shared__ float tile[3 * LH * RS + 1];              // + one dummy slot: staging slots past the tile write there
     const int tid = threadIdx.x, lane = tid & 63;
@@ -682,8 +681,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     // reference layer.  (Without restrict the compiler cannot hoist loads out of the tile loop past the stores.)
     float b[14], bv = 0.f;
     int have = -1;
-    const int oh = p.h >> 1, ow = p.w_ >> 1;
-    const unsigned orow = (unsigned)(ow * p.cout) * 4u, ocol = (unsigned)p.cout * 4u;      // bytes per pooled output row / pixel
+    const int oh = POOL ? p.h >> 1 : p.h, ow = POOL ? p.w_ >> 1 : p.w_;
+    const unsigned orow = (unsigned)(ow * p.cout) * 4u, ocol = (unsigned)p.cout * 4u;      // bytes per output row / pixel
     // XCD-aware walk: in every round of gridDim.x tiles, the work-groups of one XCD take a CONTIGUOUS run of tiles (four tile
     // rows at 256x256), so neighbours that share 128-byte input lines (a tile row is 18 floats of a line; a line spans two
     // tiles) share an L2.  Dealt round-robin, every XCD fetched the lines for itself: 1.91 GB per 640 frames for 0.50 GB of
@@ -707,13 +706,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
         const int n = t_ / p.tiles_y;
         const int y0 = ty * TH, x0 = tx * 16;
         const __amdgpu_buffer_rsrc_t rout = vad_rsrc(p.out + (size_t)n * (oh * ow) * p.cout, (unsigned)(oh * ow * p.cout) * 4u);
-        // this wave's first pooled row / the tile's first pooled column, as a byte offset inside the frame (scalar)
-        const int oy0 = (y0 >> 1) + wave * MTW, ox0 = x0 >> 1;
+        // this wave's first output row / the tile's first output column, as a byte offset inside the frame (scalar)
+        const int oy0 = POOL ? (y0 >> 1) + wave * MTW : y0 + 2 * wave * MTW, ox0 = POOL ? x0 >> 1 : x0;
         const unsigned ubase = (unsigned)oy0 * orow + (unsigned)ox0 * ocol;
-        const bool full = oy0 + MTW <= oh && ox0 + 8 <= ow;                    // wave-uniform: no window of this wave is outside
+        const bool full = POOL ? (oy0 + MTW <= oh && ox0 + 8 <= ow) : (oy0 + 2 * MTW <= oh && ox0 + 16 <= ow);   // wave-uniform
         for (int nt = 0; nt < ctiles; ++nt) {
             const int co = nt * 32 + li;
-            const unsigned lanepart = (unsigned)(lh * p.cout + co) * 4u;
+            const unsigned lanepart = (unsigned)((POOL ? lh : 2 * lh) * p.cout + co) * 4u;
             if (have != nt) {
 #pragma unroll
                 for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
@@ -751,14 +750,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
             for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one activation
-                    // per window instead of four; vad_vmax = one v_max_f32 (fmaxf adds a canonicalising max per operand)
-                    const float m = vad_act(vad_vmax(vad_vmax(acc[mt][4 * q], acc[mt][4 * q + 1]), vad_vmax(acc[mt][4 * q + 2], acc[mt][4 * q + 3])), ACT);
-                    // lane part (column half, channel) + scalar part (row, column pair); a window outside the pooled image
-                    // (partial tiles only) gets the out-of-range offset and the store is dropped
-                    unsigned vo = lanepart;
-                    if (!full) vo = ((oy0 + mt) < oh && (ox0 + 2 * q + lh) < ow) ? lanepart : VAD_OOB;
-                    vad_bstore1(m, rout, vo, ubase + (unsigned)mt * orow + (unsigned)(2 * q) * ocol);
+                    if constexpr (POOL) {
+                        // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one activation
+                        // per window instead of four; vad_vmax = one v_max_f32 (fmaxf adds a canonicalising max per operand)
+                        const float m = vad_act(vad_vmax(vad_vmax(acc[mt][4 * q], acc[mt][4 * q + 1]), vad_vmax(acc[mt][4 * q + 2], acc[mt][4 * q + 3])), ACT);
+                        // lane part (column half, channel) + scalar part (row, column pair); a window outside the pooled image
+                        // (partial tiles only) gets the out-of-range offset and the store is dropped
+                        unsigned vo = lanepart;
+                        if (!full) vo = ((oy0 + mt) < oh && (ox0 + 2 * q + lh) < ow) ? lanepart : VAD_OOB;
+                        vad_bstore1(m, rout, vo, ubase + (unsigned)mt * orow + (unsigned)(2 * q) * ocol);
+                    } else {
+                        // un-pooled (training forward): the window's four pixels (dy = pos >> 1, dx = pos & 1) at column 4q + 2 lh + dx
+#pragma unroll
+                        for (int pos = 0; pos < 4; ++pos) {
+                            unsigned vo = lanepart;
+                            if (!full) vo = ((oy0 + 2 * mt + (pos >> 1)) < oh && (ox0 + 4 * q + 2 * lh + (pos & 1)) < ow) ? lanepart : VAD_OOB;
+                            vad_bstore1(vad_act(acc[mt][4 * q + pos], ACT), rout, vo,
+                                        ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
+                        }
+                    }
                 }
             }
         }
@@ -779,9 +789,10 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
     VAD_REQUIRE(act == VAD_ACT_LEAKY || act == VAD_ACT_RELU || act == VAD_ACT_NONE, "conv3x3_c3: bad act");
     hipStream_t s = (hipStream_t)stream;
     const ConvKnobs kn;
-    // persistent kernel (tiles of 32 rows x 16 columns) for the pooled form; the un-pooled form (training forward) writes
-    // 8.4 MB per 256x256 frame and is faster with many small work-groups in flight (measured 4.0 vs 6.5 us/frame)
-    if (kn.variant != 0 && pool) {
+    // persistent kernel (tiles of 32 rows x 16 columns) for both forms.  The un-pooled one (training forward) writes 8.4 MB per
+    // 256x256 frame: 2.6 us/frame = 3.5 TB/s with the scalar-offset buffer stores (the one-tile-per-work-group kernel, with a
+    // 64-bit address computed per store, needs 3.8 us; an earlier persistent form with the same address arithmetic 6.5 us).
+    if (kn.variant != 0) {
         VAD_REQUIRE(12ll * h * wd < (1ll << 31) && (long long)h * wd * cout < (1ll << 31),
                     "conv3x3_c3: frame %dx%d (cout %d) too large for the 32-bit offsets inside one frame", h, wd, cout);
         ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 31) / 32, 0, fmt == VAD_X_U8_NHWC};
@@ -795,10 +806,15 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
         if (!cap) cap_ = cap = persistent_grid(conv3x3_c3_pkernel<POOL, ACT>, ~0u);                        \
         hipLaunchKernelGGL((conv3x3_c3_pkernel<POOL, ACT>), dim3(p.nblocks < cap ? p.nblocks : cap), dim3(256), 0, s, p); \
     }
-        // (pooled form only: the un-pooled instantiation of this kernel needed 256 registers + 276 bytes of scratch)
-        if (act == VAD_ACT_LEAKY) C3P_LAUNCH(1, VAD_ACT_LEAKY)
-        else if (act == VAD_ACT_RELU) C3P_LAUNCH(1, VAD_ACT_RELU)
-        else C3P_LAUNCH(1, VAD_ACT_NONE)
+        if (pool) {
+            if (act == VAD_ACT_LEAKY) C3P_LAUNCH(1, VAD_ACT_LEAKY)
+            else if (act == VAD_ACT_RELU) C3P_LAUNCH(1, VAD_ACT_RELU)
+            else C3P_LAUNCH(1, VAD_ACT_NONE)
+        } else {
+            if (act == VAD_ACT_LEAKY) C3P_LAUNCH(0, VAD_ACT_LEAKY)
+            else if (act == VAD_ACT_RELU) C3P_LAUNCH(0, VAD_ACT_RELU)
+            else C3P_LAUNCH(0, VAD_ACT_NONE)
+        }
 #undef C3P_LAUNCH
         VAD_LAUNCH_CHECK();
         return VAD_OK;
