@@ -51,7 +51,21 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long lon
     if (row < rows) {
         f32x4 pv = {0.f, 0.f, 0.f, 0.f};
         if (pivot) pv = *(const f32x4*)&pivot[4 * c4];
-        for (long long p = p0 + row; p < p1; p += rows) {
+        // four loads in flight per thread (same accumulation order): one at a time, a CU's 2048 threads keep 32 KB in flight and
+        // the pass ran at 3.8 TB/s
+        long long p = p0 + row;
+        for (; p + 3 * rows < p1; p += 4 * rows) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)&y[(p + (long long)u * rows) * c + 4 * c4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 d = v[u] - pv;
+                s0 += d;
+                s1 += d * d;
+            }
+        }
+        for (; p < p1; p += rows) {
             const f32x4 v = *(const f32x4*)&y[p * c + 4 * c4] - pv;
             s0 += v;
             s1 += v * v;
