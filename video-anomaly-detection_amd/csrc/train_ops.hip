@@ -647,8 +647,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long long idx = (long long)blockIdx.x * 64 + e;
     float s = 0.f;
-    if (idx < total)
-        for (int k = sl; k < splits; k += 4) s += ws[(size_t)k * total + idx];
+    if (idx < total) {
+        // four partials in flight per thread, added in the same order (one at a time the pass was a chain of memory round trips:
+        // 0.93 ms per training step for ~1.2 GB of partials)
+        int k = sl;
+        for (; k + 12 < splits; k += 16) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ws[(size_t)(k + 4 * u) * total + idx];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; k < splits; k += 4) s += ws[(size_t)k * total + idx];
+    }
     part[sl][e] = s;
     __syncthreads();
     if (sl != 0 || idx >= total) return;
