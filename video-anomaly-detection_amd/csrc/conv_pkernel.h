@@ -97,7 +97,7 @@ __device__ __forceinline__ void tile_put_t(float* tile, int pixoff_plus_ch, int 
 }
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0>
-// Work-groups per CU: 3 for the exact-fp32 fused first layer (it fits 168 registers; its three barriers per tile need the
+// Work-groups per CU: 3 for the exact-fp32 fused first layer (it fits 168 registers; its two barriers per tile need the
 // third resident group), else 2 (three groups measured no gain on the cout-32 tilings, and the deeper weight prefetch below
 // needs the registers).
 __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_pkernel(Conv3P p) {
