@@ -268,7 +268,7 @@ def main():
         # (tools/pmc_traffic.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); only valid for the default shape.
         traffic, traffic_source = None, None
         pmcs = sorted((REPO / "profiles").glob(f"r*_pmc_traffic_{args.workload}.json"))     # newest round last
-        if pmcs and hw == 256 and not args.batch and int(model.chunk) == (128 if args.workload == "image" else 64) and (args.workload != "video" or t == 10):
+        if pmcs and hw == 256 and not args.batch and int(model.chunk) == (512 if args.workload == "image" else 64) and (args.workload != "video" or t == 10):
             traffic = round(json.loads(pmcs[-1].read_text())["traffic_bytes_per_launch"])
             traffic_source = f"profiles/{pmcs[-1].name} (separate rocprofv3 --pmc passes of this command, not this run)"
         roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_pkernel (fp32 32x32x2 MFMA; all launches)",

@@ -117,9 +117,10 @@ class _HipScorer:
 class ConvAutoencoder(nn.Module):
     """Reference `ConvAutoencoder(in_channels=3, latent_dim=256)` (models/autoencoder.py:149-221)."""
 
-    #: frames per launch group (workspace = 2 x chunk x 8.4 MB at 256x256); large enough that every layer launches
-    #: several work-groups per resident slot
-    chunk = 128
+    #: frames per launch group (workspace = 2 x chunk x 8.4 MB at 256x256 = 8 GiB of the 288): the whole 512-frame batch of
+    #: configs[1] in one group - every launch has a ramp-up and a tail, and 16 launches per step instead of 64 measured +1.1 %
+    #: (64 / 128 / 256 / 512 frames per group: 16.13 / 16.39 / 16.54 / 16.57 k frames/s)
+    chunk = 512
     #: "fp32" = exact fp32 MFMA (default, the parity path); "split" = 3 x fp16 MFMA with fp32 accumulate (opt-in,
     #: 22-bit products; see include/vad_hip.h VAD_PREC_SPLIT).  Per model: the mode travels with every call as an argument
     precision = "fp32"
