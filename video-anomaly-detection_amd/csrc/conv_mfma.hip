@@ -519,6 +519,8 @@ struct ConvC3P {
     int h, w_, cout, tiles_x, tiles_y;
     unsigned nblocks;
     int xu8;                 // x is uint8 NHWC [N,H,W,3]
+    float* stats;            // nullable (persistent un-pooled kernel, cout == 32): per-work-group partial sums for BatchNorm,
+                             // stats[block][0][c] = sum(y - bias[c]), stats[block][1][c] = sum((y - bias[c])^2)
 };
 
 template <int MT, int POOL, int ACT>
@@ -681,6 +683,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     // reference layer.  (Without restrict the compiler cannot hoist loads out of the tile loop past the stores.)
     float b[14], bv = 0.f;
     int have = -1;
+    // BatchNorm statistics of the training forward, taken from the accumulators instead of a second pass over the 8.4 MB per
+    // frame this kernel has just written: two levels (per tile, then per work-group) so that a lane never adds more than 64 +
+    // ~100 terms in a row; shifted by the bias (the channel's mean is close to it), as chan_sums_kernel shifts by a sample
+    float st_s = 0.f, st_q = 0.f;
     const int oh = POOL ? p.h >> 1 : p.h, ow = POOL ? p.w_ >> 1 : p.w_;
     const unsigned orow = (unsigned)(ow * p.cout) * 4u, ocol = (unsigned)p.cout * 4u;      // bytes per output row / pixel
     // XCD-aware walk: in every round of gridDim.x tiles, the work-groups of one XCD take a CONTIGUOUS run of tiles (four tile
@@ -746,6 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) acc[mt] = MFMA32(av[s & 1][mt], b[s], acc[mt]);
             }
+            float ts = 0.f, tq = 0.f;        // this tile's share of the statistics
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
@@ -767,9 +774,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                             if (!full) vo = ((oy0 + 2 * mt + (pos >> 1)) < oh && (ox0 + 4 * q + 2 * lh + (pos & 1)) < ow) ? lanepart : VAD_OOB;
                             vad_bstore1(vad_act(acc[mt][4 * q + pos], ACT), rout, vo,
                                         ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
+                            if (p.stats) {   // (uniform)
+                                const float d = (full || vo != VAD_OOB) ? acc[mt][4 * q + pos] - bv : 0.f;
+                                ts += d;
+                                tq = fmaf(d, d, tq);
+                            }
                         }
                     }
                 }
+            }
+            st_s += ts;
+            st_q += tq;
+        }
+    }
+    if constexpr (!POOL) {
+        if (p.stats) {       // (uniform; host: cout == 32, so one channel tile and lane li = channel li)
+            __shared__ float red[4][2][32];
+            st_s += __shfl_xor(st_s, 32);
+            st_q += __shfl_xor(st_q, 32);
+            if (lh == 0) { red[wave][0][li] = st_s; red[wave][1][li] = st_q; }
+            __syncthreads();
+            if (tid < 64) {
+                const int j = tid >> 5;
+                p.stats[(size_t)blockIdx.x * 2 * p.cout + j * p.cout + li] = ((red[0][j][li] + red[1][j][li]) + red[2][j][li]) + red[3][j][li];
             }
         }
     }
@@ -782,6 +809,16 @@ extern "C" int vad_conv3x3_c3(const float* x, const float* w, const float* bias,
 
 int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias, float* out,
                        int n, int h, int wd, int cout, int act, int pool, void* stream) {
+    return vad_conv3x3_c3_stats(x, fmt, w, bias, out, n, h, wd, cout, act, pool, nullptr, nullptr, stream);
+}
+
+// stats / stats_blocks (both or neither): the persistent un-pooled kernel also writes per-work-group BatchNorm partial sums
+// [blocks][2][cout] (shifted by the bias) and *stats_blocks = the number of work-groups; *stats_blocks = 0 when the launch
+// could not provide them (the caller then makes its own pass over `out`).
+int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bias, float* out,
+                         int n, int h, int wd, int cout, int act, int pool, float* stats, int* stats_blocks, void* stream) {
+    if (stats_blocks) *stats_blocks = 0;
+    VAD_REQUIRE((stats == nullptr) == (stats_blocks == nullptr), "conv3x3_c3: stats and stats_blocks come together");
     VAD_REQUIRE(x && w && bias && out, "conv3x3_c3: null pointer");
     VAD_REQUIRE(fmt == VAD_X_F32_NCHW || fmt == VAD_X_U8_NHWC, "conv3x3_c3: bad input format %d", fmt);
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && cout > 0 && cout % 32 == 0, "conv3x3_c3: bad shape");
@@ -795,16 +832,19 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
     if (kn.variant != 0) {
         VAD_REQUIRE(12ll * h * wd < (1ll << 31) && (long long)h * wd * cout < (1ll << 31),
                     "conv3x3_c3: frame %dx%d (cout %d) too large for the 32-bit offsets inside one frame", h, wd, cout);
-        ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 31) / 32, 0, fmt == VAD_X_U8_NHWC};
+        ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 31) / 32, 0, fmt == VAD_X_U8_NHWC, nullptr};
         const long long nb = (long long)n * p.tiles_x * p.tiles_y;
         VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");
         p.nblocks = (unsigned)nb;
+        const bool with_stats = stats && !pool && act == VAD_ACT_NONE && cout == 32;
+        if (with_stats) p.stats = stats;
 #define C3P_LAUNCH(POOL, ACT)                                                                              \
     {                                                                                                      \
         static std::atomic<unsigned> cap_{0};                                                              \
         unsigned cap = cap_.load(std::memory_order_relaxed);                                               \
         if (!cap) cap_ = cap = persistent_grid(conv3x3_c3_pkernel<POOL, ACT>, ~0u);                        \
         hipLaunchKernelGGL((conv3x3_c3_pkernel<POOL, ACT>), dim3(p.nblocks < cap ? p.nblocks : cap), dim3(256), 0, s, p); \
+        if (with_stats) *stats_blocks = (int)(p.nblocks < cap ? p.nblocks : cap);                          \
     }
         if (pool) {
             if (act == VAD_ACT_LEAKY) C3P_LAUNCH(1, VAD_ACT_LEAKY)
@@ -819,7 +859,7 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
         VAD_LAUNCH_CHECK();
         return VAD_OK;
     }
-    ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 15) / 16, 0, fmt == VAD_X_U8_NHWC};
+    ConvC3P p{(const float*)x, w, bias, out, h, wd, cout, (wd + 15) / 16, (h + 15) / 16, 0, fmt == VAD_X_U8_NHWC, nullptr};
     const long long nb = (long long)n * p.tiles_x * p.tiles_y;
     VAD_REQUIRE(nb < (1ll << 31), "conv3x3_c3: grid too large");
     p.nblocks = (unsigned)nb;

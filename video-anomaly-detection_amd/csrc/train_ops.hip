@@ -946,6 +946,18 @@ extern "C" int vad_bn_stats(const float* y, long long npix, int c, float eps, fl
     return VAD_OK;
 }
 
+// BatchNorm statistics from partial sums a producer kernel wrote ([nblocks][2][c], shifted by `pivot`): the finalize half of
+// vad_bn_stats (internal: conv_mfma.hip's first-layer kernel is the producer).
+int vad_bn_stats_from_partials(const float* partials, int nblocks, long long npix, int c, float eps, float momentum, float* stats,
+                               float* running_mean, float* running_var, const float* pivot, void* stream) {
+    VAD_REQUIRE(partials && stats && pivot && nblocks > 0 && npix > 0 && chan_ok(c), "bn_stats_from_partials: bad arguments (c=%d)", c);
+    VAD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_from_partials: running_mean/var must come together");
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, partials, nblocks, c,
+                       (double)npix, 0, eps, momentum, stats, running_mean, running_var, (float*)nullptr, (float*)nullptr, pivot);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
 extern "C" int vad_chan_sum(const float* g, long long npix, int c, float* out, float* ws, void* stream) {
     VAD_REQUIRE(g && out && ws && npix > 0 && chan_ok(c), "chan_sum: bad arguments (c=%d)", c);
     const long long chunk = stats_chunk(npix);

@@ -156,6 +156,8 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     p.g[1] = p.g[2];      // (was the materialised routed gradient; kept in the debug layout as an alias)
     p.ksums = take(2 * 1024);
     p.zeros = take(1024);
+    // the first layer writes its BatchNorm partial sums itself: one [2][32] row per work-group, at most one per 32x16 tile
+    { const size_t v = N * (size_t)((W + 15) / 16) * (size_t)((H + 31) / 32) * 64; if (v > max_chan) max_chan = v; }
     p.chan_ws = take(max_chan);
     p.wgrad_ws = take(max_wgrad);
     p.to3_ws = take(vad_convt_to3_mse_ws_floats(p.N, H / 2, W / 2));
@@ -255,10 +257,12 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     for (int k = 0; k < 4; ++k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         float* y = ws + p.y[k];
-        if (k == 0) TRY(vad_conv3x3_c3(x, ws + p.pk_e[0], P + p.e_b[0], y, N, hk, wk, co, VAD_ACT_NONE, 0, s));
+        int sblocks = 0;      // > 0: the convolution wrote the BatchNorm partial sums itself (first layer: no second pass over y)
+        if (k == 0) TRY(vad_conv3x3_c3_stats(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s));
         else TRY(vad_conv3x3(ws + p.a[k - 1], 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, s));
         float* rs = running ? running + p.e_rs[k] : nullptr;
-        TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
+        if (sblocks > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[0], s));
+        else TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
         if (k < 3)
             TRY(vad_bn_act_pool_fwd(y, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.a[k], 0, 0, 0, 0, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         else   // latent features go straight into layer 0's operand buffers: frame b*T+t -> slot t*B+b, x-part

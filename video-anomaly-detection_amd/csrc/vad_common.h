@@ -105,6 +105,10 @@ __device__ __forceinline__ float vad_norm_u8(unsigned v) {
 // format-aware internals behind the float-only layer entry points of include/vad_hip.h
 int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias, float* out, int n, int h, int wd,
                        int cout, int act, int pool, void* stream);
+int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bias, float* out, int n, int h, int wd, int cout,
+                         int act, int pool, float* stats, int* stats_blocks, void* stream);   // + BatchNorm partial sums (training forward)
+int vad_bn_stats_from_partials(const float* partials, int nblocks, long long npix, int c, float eps, float momentum, float* stats,
+                               float* running_mean, float* running_var, const float* pivot, void* stream);
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1, const float* b1,
                              float* out, int n, int h, int wd, int precision, void* stream);
 // vad_score_finalize + the device-side blob check: when hdr != NULL and hdr[1] != want_tag every score becomes NaN
