@@ -37,6 +37,8 @@ struct Conv3P {
     unsigned nblocks;
     unsigned long long* dbg;                         // VAD_STAMPS diagnostic build only
     int stagger;                                     // persistent kernel: start delay of the upper half of the grid (x 8128 cycles)
+    float* stats;                                    // nullable; persistent MODE_PLAIN / VAD_ACT_NONE kernels (training forward): BatchNorm
+                                                     // partial sums [row][2][cout], row = frame group * tiles + tile, shifted by the bias
 };
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -307,12 +309,13 @@ static unsigned persistent_grid(K kernel, unsigned nblocks, int max_per_cu = 2) 
 
 // Persistent grid: (tiles per frame x cout blocks) work-group positions, replicated over `fgroups` frame groups
 // so that about (CUs x resident work-groups per CU) groups run; group g of a position walks frames g, g+fgroups, ...
+static thread_local unsigned t_vad_last_pgrid = 0;      // grid of this thread's latest persistent conv3x3 launch (0: not persistent)
 static unsigned persistent_grid_for(const Conv3P& p, unsigned cap) {
     const unsigned per_frame = (unsigned)(p.tiles_x * p.tiles_y * p.cblocks);
     unsigned fgroups = cap / per_frame;
     if (fgroups < 1) fgroups = 1;
     if (fgroups > (unsigned)p.n) fgroups = (unsigned)p.n;
-    return per_frame * fgroups;
+    return t_vad_last_pgrid = per_frame * fgroups;
 }
 
 // `variant`: 1 = persistent kernel, 0 = one tile per work-group (exact fp32 only); grid caps are per instantiation and
@@ -341,6 +344,7 @@ static void launch_conv3_act(const Conv3P& p, hipStream_t s, int precision, int 
         }
     }
     if (variant == 0) {
+        t_vad_last_pgrid = 0;
         hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(p.nblocks), dim3(256), 0, s, p);
     } else {
         static std::atomic<unsigned> grid_cap{0};
@@ -374,9 +378,28 @@ static int launch_conv3(Conv3P& p, int n, int act, hipStream_t s, int precision,
     return VAD_OK;
 }
 
+// upper bound of the partial-sum rows x 2 x cout floats a stats launch writes (persistent grid <= 4 work-groups per CU)
+size_t vad_conv3x3_stats_floats(int cout) { return (size_t)vad_num_cus() * 4 * 2 * (size_t)cout; }
+
+static int conv3_stats_rows(int rc, const Conv3P& p, bool with_stats, int* stats_rows) {
+    if (rc == VAD_OK && with_stats && t_vad_last_pgrid) *stats_rows = (int)(t_vad_last_pgrid / (unsigned)p.cblocks);
+    return rc;
+}
+
 extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, const float* bias,
                            float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
                            int act, int pool, int precision, void* stream) {
+    return vad_conv3x3_stats(in, in_fs, w, bias, out, out_fs, n, h, wd, cin, cout, act, pool, precision, nullptr, nullptr, stream);
+}
+
+// stats / stats_rows (both or neither; un-pooled, un-activated launches = the training forward): the persistent kernel also
+// writes BatchNorm partial sums [rows][2][cout] (shifted by the bias) and *stats_rows = their row count; 0 when the launch
+// could not provide them (the caller then makes its own pass over `out`).  Room needed: vad_conv3x3_stats_floats().
+int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const float* bias,
+                      float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
+                      int act, int pool, int precision, float* stats, int* stats_rows, void* stream) {
+    if (stats_rows) *stats_rows = 0;
+    VAD_REQUIRE((stats == nullptr) == (stats_rows == nullptr), "conv3x3: stats and stats_rows come together");
     VAD_REQUIRE(in && w && bias && out, "conv3x3: null pointer");
     VAD_REQUIRE_PREC("conv3x3");
     const ConvKnobs kn;
@@ -393,7 +416,11 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
     p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
     p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.hid = 0;
     hipStream_t s = (hipStream_t)stream;
-#define L3(CK, MT, NT, WM, WN, MODE) launch_conv3<CK, MT, NT, WM, WN, MODE>(p, n, act, s, precision, kn.variant, kn)
+    const bool with_stats = stats && !pool && act == VAD_ACT_NONE && kn.variant != 0;
+    p.stats = with_stats ? stats : nullptr;
+    t_vad_last_pgrid = 0;
+    // (every return below goes through L3; the row count is read back from the launch's grid)
+#define L3(CK, MT, NT, WM, WN, MODE) conv3_stats_rows(launch_conv3<CK, MT, NT, WM, WN, MODE>(p, n, act, s, precision, kn.variant, kn), p, with_stats, stats_rows)
     if (precision != VAD_PREC_FP32) {
         // split-fp16 operands double the accumulators (main + cross terms): keep one N-tile per wave (bf16 shares the tilings)
         if (cout % 128 == 0 && !kn.conv64)   // one B fragment per 4 M-tiles: halves the weight traffic through L1

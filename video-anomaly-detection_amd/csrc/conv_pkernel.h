@@ -144,6 +144,13 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     unsigned L = vad_xcd_remap(blockIdx.x % per_frame, per_frame);
     const int fg = blockIdx.x / per_frame, fgroups = gridDim.x / per_frame;
     const int cb = L % p.cblocks; L /= p.cblocks;
+    // BatchNorm statistics of the training forward (un-pooled, un-activated launches only): taken from the accumulators, two
+    // levels (per frame tile, then per work-group), shifted by the bias; row of this work-group in p.stats
+    constexpr bool STATS = MODE == MODE_PLAIN && ACT == VAD_ACT_NONE && !FUSE_C3;
+    const unsigned stats_row = (unsigned)(blockIdx.x / per_frame) * (unsigned)(p.tiles_x * p.tiles_y) + L;
+    float st_s[STATS ? NT : 1], st_q[STATS ? NT : 1];
+#pragma unroll
+    for (int nt = 0; nt < (STATS ? NT : 1); ++nt) st_s[nt] = st_q[nt] = 0.f;
     const int x0 = (L % p.tiles_x) * 16, y0 = (L / p.tiles_x) * TH;
     const int H = p.h, W = p.w_;
 
@@ -632,6 +639,9 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                     }
                 }
             } else {
+                float ts[STATS ? NT : 1], tq[STATS ? NT : 1];
+#pragma unroll
+                for (int nt = 0; nt < (STATS ? NT : 1); ++nt) ts[nt] = tq[nt] = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -642,10 +652,22 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                             const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + dx) < ow);
                             const unsigned so = dy * erow + dx * ecol;
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = 0; nt < NT; ++nt) {
                                 vad_bstore1(vad_act(acc[mt][nt][4 * q + pos], ACT), ro, ok ? eoff[nt] : VAD_OOB, so);
+                                if constexpr (STATS) {
+                                    if (p.stats) {   // (uniform)
+                                        const float d = ok ? acc[mt][nt][4 * q + pos] - bv[nt] : 0.f;
+                                        ts[nt] += d;
+                                        tq[nt] = fmaf(d, d, tq[nt]);
+                                    }
+                                }
+                            }
                         }
                     }
+                }
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { st_s[nt] += ts[nt]; st_q[nt] += tq[nt]; }
                 }
             }
         }
@@ -658,6 +680,29 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #undef LOAD_B
 #undef ISSUE
 #undef XWRITE
+    if constexpr (STATS) {
+        if (p.stats) {           // (uniform)  partial sums of this work-group: lane halves, then the WM waves of a column block
+            __syncthreads();     // every wave is done with the LDS tile: reuse it as [wave][sum | sum of squares][nt][32]
+            float* red = tile;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float a = st_s[nt] + __shfl_xor(st_s[nt], 32), q = st_q[nt] + __shfl_xor(st_q[nt], 32);
+                if (lh == 0) { red[((wave * 2 + 0) * NT + nt) * 32 + li] = a; red[((wave * 2 + 1) * NT + nt) * 32 + li] = q; }
+            }
+            __syncthreads();
+            if (wm == 0 && lh == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float t = red[((wn * 2 + j) * NT + nt) * 32 + li];
+#pragma unroll
+                        for (int m = 1; m < WM; ++m) t += red[(((m * WN + wn) * 2 + j) * NT + nt) * 32 + li];
+                        p.stats[((size_t)stats_row * 2 + j) * p.cout + cofs[nt]] = t;
+                    }
+            }
+        }
+    }
 #ifdef VAD_STAMPS
     if (p.dbg && lane == 0) {
         unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;

@@ -158,6 +158,7 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     p.zeros = take(1024);
     // the first layer writes its BatchNorm partial sums itself: one [2][32] row per work-group, at most one per 32x16 tile
     { const size_t v = N * (size_t)((W + 15) / 16) * (size_t)((H + 31) / 32) * 64; if (v > max_chan) max_chan = v; }
+    for (int k = 1; k < 4; ++k) { const size_t v = vad_conv3x3_stats_floats(p.encC[k + 1]); if (v > max_chan) max_chan = v; }   // so do the other encoder convolutions
     p.chan_ws = take(max_chan);
     p.wgrad_ws = take(max_wgrad);
     p.to3_ws = take(vad_convt_to3_mse_ws_floats(p.N, H / 2, W / 2));
@@ -259,9 +260,9 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         float* y = ws + p.y[k];
         int sblocks = 0;      // > 0: the convolution wrote the BatchNorm partial sums itself (first layer: no second pass over y)
         if (k == 0) TRY(vad_conv3x3_c3_stats(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s));
-        else TRY(vad_conv3x3(ws + p.a[k - 1], 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, s));
+        else TRY(vad_conv3x3_stats(ws + p.a[k - 1], 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, ws + p.chan_ws, &sblocks, s));
         float* rs = running ? running + p.e_rs[k] : nullptr;
-        if (sblocks > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[0], s));
+        if (sblocks > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[k], s));
         else TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
         if (k < 3)
             TRY(vad_bn_act_pool_fwd(y, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.a[k], 0, 0, 0, 0, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
