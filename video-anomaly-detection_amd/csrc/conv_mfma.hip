@@ -320,26 +320,36 @@ static unsigned persistent_grid_for(const Conv3P& p, unsigned cap) {
 
 // `variant`: 1 = persistent kernel, 0 = one tile per work-group (exact fp32 only); grid caps are per instantiation and
 // written once with the same value by whichever thread gets there first.
+// one persistent launch; ST = 1: the instantiation that also writes the BatchNorm partial sums (p.stats)
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int PREC, int ST>
+static void launch_conv3_persistent(const Conv3P& p, const Conv3P& q, hipStream_t s) {
+    static std::atomic<unsigned> grid_cap{0};
+    unsigned cap = grid_cap.load(std::memory_order_relaxed);
+    if (!cap) grid_cap = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, PREC, ST>, ~0u);
+    hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, PREC, ST>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
+}
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int PREC>
+static void launch_conv3_p(const Conv3P& p, const Conv3P& q, hipStream_t s) {
+    if constexpr (MODE == MODE_PLAIN && ACT == VAD_ACT_NONE) {
+        if (p.stats) { launch_conv3_persistent<CK, MT, NT, WM, WN, MODE, ACT, PREC, 1>(p, q, s); return; }
+    }
+    launch_conv3_persistent<CK, MT, NT, WM, WN, MODE, ACT, PREC, 0>(p, q, s);
+}
+
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT>
 static void launch_conv3_act(const Conv3P& p, hipStream_t s, int precision, int variant, const ConvKnobs& kn) {
     if (precision == VAD_PREC_SPLIT) {   // split-fp16 operands (persistent kernel only)
-        static std::atomic<unsigned> grid_cap1{0};
-        unsigned cap = grid_cap1.load(std::memory_order_relaxed);
-        if (!cap) grid_cap1 = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>, ~0u);
         Conv3P q = p;
         q.dbg = g_vad_dbg;
         q.stagger = kn.stagger;   // debug (variant bit 1): zero-sized weight descriptor = price the weight traffic
-        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 1>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
+        launch_conv3_p<CK, MT, NT, WM, WN, MODE, ACT, 1>(p, q, s);
         return;
     }
     if constexpr (MODE != MODE_LSTM) {   // bf16 operands (training convolutions; the ConvLSTM step is not offered in bf16)
         if (precision == VAD_PREC_BF16) {
-            static std::atomic<unsigned> grid_cap2{0};
-            unsigned cap = grid_cap2.load(std::memory_order_relaxed);
-            if (!cap) grid_cap2 = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 2>, ~0u);
             Conv3P q = p;
             q.dbg = g_vad_dbg;
-            hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, 2>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
+            launch_conv3_p<CK, MT, NT, WM, WN, MODE, ACT, 2>(p, q, s);
             return;
         }
     }
@@ -347,13 +357,10 @@ static void launch_conv3_act(const Conv3P& p, hipStream_t s, int precision, int 
         t_vad_last_pgrid = 0;
         hipLaunchKernelGGL((conv3x3_mfma_kernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(p.nblocks), dim3(256), 0, s, p);
     } else {
-        static std::atomic<unsigned> grid_cap{0};
-        unsigned cap = grid_cap.load(std::memory_order_relaxed);
-        if (!cap) grid_cap = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>, ~0u);
         Conv3P q = p;
         q.dbg = g_vad_dbg;
         q.stagger = kn.stagger * 2;   // debug (variant bit 1, exact kernels): bit 1 = drop the epilogue's stores (prices them)
-        hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
+        launch_conv3_p<CK, MT, NT, WM, WN, MODE, ACT, 0>(p, q, s);
     }
 }
 

@@ -96,7 +96,7 @@ __device__ __forceinline__ void tile_put_t(float* tile, int pixoff_plus_ch, int 
     }
 }
 
-template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0>
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0, int WITH_STATS = 0>
 // Work-groups per CU: 3 for the exact-fp32 fused first layer (it fits 168 registers; its two barriers per tile need the
 // third resident group), else 2 (three groups measured no gain on the cout-32 tilings, and the deeper weight prefetch below
 // needs the registers).
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     const int cb = L % p.cblocks; L /= p.cblocks;
     // BatchNorm statistics of the training forward (un-pooled, un-activated launches only): taken from the accumulators, two
     // levels (per frame tile, then per work-group), shifted by the bias; row of this work-group in p.stats
-    constexpr bool STATS = MODE == MODE_PLAIN && ACT == VAD_ACT_NONE && !FUSE_C3;
+    // (WITH_STATS: its own instantiation - the accumulators live across the frame loop and cost the training tilings, which
+    // are at their register limit, another 30-70 bytes of scratch when they are compiled in everywhere)
+    constexpr bool STATS = WITH_STATS && MODE == MODE_PLAIN && ACT == VAD_ACT_NONE && !FUSE_C3;
     const unsigned stats_row = (unsigned)(blockIdx.x / per_frame) * (unsigned)(p.tiles_x * p.tiles_y) + L;
     float st_s[STATS ? NT : 1], st_q[STATS ? NT : 1];
 #pragma unroll
