@@ -1054,6 +1054,18 @@ static int launch_convt(ConvTP& p, int act, hipStream_t s) {
 extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, const float* bias,
                             float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
                             int act, int precision, void* stream) {
+    return vad_convt2x2_stats(in, in_fs, w, bias, out, out_fs, n, h, wd, cin, cout, act, precision, nullptr, nullptr, stream);
+}
+
+// upper bound of the rows x 2 x cout floats a stats launch writes (one row per wave of a persistent grid, <= 4 work-groups per CU)
+size_t vad_convt2x2_stats_floats(int cout) { return (size_t)vad_num_cus() * 4 * 4 * 2 * (size_t)cout; }
+
+// stats / stats_rows as in vad_conv3x3_stats (un-activated launches, cout <= 128): [rows][2][cout], shifted by the bias
+int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const float* bias,
+                       float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
+                       int act, int precision, float* stats, int* stats_rows, void* stream) {
+    if (stats_rows) *stats_rows = 0;
+    VAD_REQUIRE((stats == nullptr) == (stats_rows == nullptr), "convt2x2: stats and stats_rows come together");
     VAD_REQUIRE(in && w && bias && out, "convt2x2: null pointer");
     VAD_REQUIRE_PREC("convt2x2");
     const ConvKnobs kn;
@@ -1082,13 +1094,17 @@ extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, co
     VAD_REQUIRE(items > 0 && items < (1ll << 31), "convt2x2: %lld work items out of range", items);
     q.nitems = (unsigned)items;
     const unsigned want = (unsigned)((items + 3) / 4);
-#define CT_LAUNCH_(A, MT_, NT_, P)                                                                           \
+    const bool with_stats = stats && act == VAD_ACT_NONE && cout <= 128;
+    q.stats = with_stats ? stats : nullptr;
+#define CT_LAUNCH_ST(A, MT_, NT_, P, ST)                                                                     \
     {                                                                                                        \
         static std::atomic<unsigned> cap_{0};                                                                \
         unsigned cap = cap_.load(std::memory_order_relaxed);                                                 \
-        if (!cap) cap_ = cap = persistent_grid(convt2x2_pkernel<MT_, NT_, A, P>, ~0u);                       \
-        hipLaunchKernelGGL((convt2x2_pkernel<MT_, NT_, A, P>), dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, q); \
+        if (!cap) cap_ = cap = persistent_grid(convt2x2_pkernel<MT_, NT_, A, P, ST>, ~0u);                   \
+        hipLaunchKernelGGL((convt2x2_pkernel<MT_, NT_, A, P, ST>), dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, q); \
+        if (ST) *stats_rows = (int)((want < cap ? want : cap) * 4);                                          \
     }
+#define CT_LAUNCH_(A, MT_, NT_, P) CT_LAUNCH_ST(A, MT_, NT_, P, 0)
 #define CT_LAUNCH(A)                                                                                         \
     {                                                                                                        \
         if (prec == VAD_PREC_SPLIT) CT_LAUNCH_(A, 2, 2, 1)                                                   \
@@ -1097,7 +1113,12 @@ extern "C" int vad_convt2x2(const float* in, long long in_fs, const float* w, co
     }
     if (act == VAD_ACT_RELU) CT_LAUNCH(VAD_ACT_RELU)
     else if (act == VAD_ACT_LEAKY) CT_LAUNCH(VAD_ACT_LEAKY)
-    else CT_LAUNCH(VAD_ACT_NONE)
+    else if (with_stats) {       // the statistics epilogue is its own instantiation (un-activated launches only)
+        if (prec == VAD_PREC_SPLIT) CT_LAUNCH_ST(VAD_ACT_NONE, 2, 2, 1, 1)
+        else if (prec == VAD_PREC_BF16) CT_LAUNCH_ST(VAD_ACT_NONE, 2, 2, 2, 1)
+        else CT_LAUNCH_ST(VAD_ACT_NONE, 2, 4, 0, 1)
+    } else CT_LAUNCH(VAD_ACT_NONE)
+#undef CT_LAUNCH_ST
 #undef CT_LAUNCH_
 #undef CT_LAUNCH
     VAD_LAUNCH_CHECK();

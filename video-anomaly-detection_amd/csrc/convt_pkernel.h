@@ -23,11 +23,19 @@ struct ConvTP2 {
     int tiles_x, tiles_y;     // M-tile groups per frame: tiles_x = ceil(W/16), tiles_y = ceil(H/(2*MT))
     int ngroups;              // column groups of NT*32 columns: 4*cout / (NT*32)
     unsigned nitems;          // n * tiles_y * tiles_x * ngroups
+    float* stats;             // nullable (WITH_STATS instantiations, un-activated = training forward, cout <= 128): BatchNorm partial
+                              // sums [wave of the grid][2][cout], shifted by the bias
 };
 
-template <int MT, int NT, int ACT, int PREC>
+template <int MT, int NT, int ACT, int PREC, int WITH_STATS = 0>
 __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) void convt2x2_pkernel(ConvTP2 p) {
     constexpr int KS = PREC ? 16 : 8;
+    // BatchNorm statistics from the accumulators (as in conv_pkernel.h): a wave's items change their channel tile, so one
+    // accumulator pair per channel tile (at most 4: cout <= 128), picked by a wave-uniform branch; two levels (item, wave)
+    constexpr bool STATS = WITH_STATS && ACT == VAD_ACT_NONE;
+    float st_s[STATS ? 4 : 1], st_q[STATS ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < (STATS ? 4 : 1); ++i) st_s[i] = st_q[i] = 0.f;
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const unsigned gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int H = p.h, W = p.w_, ctiles = p.cout / 32;
@@ -59,6 +67,7 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
         }
         unsigned bo[NT];
         int qd[NT], co[NT];
+        float bvv[NT];
         f32x16 acc[MT][NT], corr[PREC == 1 ? MT : 1][PREC == 1 ? NT : 1];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -67,6 +76,7 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
             co[nt] = (g % ctiles) * 32 + li;
             bo[nt] = (unsigned)qd[nt] * wq + (unsigned)co[nt] * (PREC ? 64u : 32u) + (PREC ? 32u : 16u) * lh;
             const float bv = p.bias[co[nt]];
+            bvv[nt] = bv;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
             constexpr int sc = 2;
             const unsigned vlane = (unsigned)(__mul24(sc * 4 * lh, p.cout) + co[nt]) * 4u;
             const unsigned ubase = ((unsigned)__mul24(sc * y0 + qa, ow) + (unsigned)(sc * x0 + qb)) * ecol;
+            float ts = 0.f, tq = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -179,6 +190,32 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
                     const bool ok = full || ((y0 + dy) < H && (x0 + dx + 4 * lh) < W);
                     const unsigned so = ubase + (unsigned)(sc * dy) * erow + (unsigned)(sc * dx) * ecol;
                     vad_bstore1(vad_act(acc[mt][nt][r], ACT), ro, ok ? vlane : VAD_OOB, so);
+                    if constexpr (STATS) {
+                        if (p.stats) {   // (uniform)
+                            const float d = ok ? acc[mt][nt][r] - bvv[nt] : 0.f;
+                            ts += d;
+                            tq = fmaf(d, d, tq);
+                        }
+                    }
+                }
+            }
+            if constexpr (STATS) {
+                const int ct = (ng * NT + nt) % ctiles;                                   // wave-uniform
+                if (ct == 0) { st_s[0] += ts; st_q[0] += tq; }
+                else if (ct == 1) { st_s[1] += ts; st_q[1] += tq; }
+                else if (ct == 2) { st_s[2] += ts; st_q[2] += tq; }
+                else { st_s[3] += ts; st_q[3] += tq; }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        if (p.stats) {           // one row per wave of the grid (waves without items write zeros); lane halves hold different pixels
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const float a = st_s[ct] + __shfl_xor(st_s[ct], 32), q = st_q[ct] + __shfl_xor(st_q[ct], 32);
+                if (lh == 0 && ct < ctiles) {
+                    p.stats[((size_t)gw * 2 + 0) * p.cout + ct * 32 + li] = a;
+                    p.stats[((size_t)gw * 2 + 1) * p.cout + ct * 32 + li] = q;
                 }
             }
         }

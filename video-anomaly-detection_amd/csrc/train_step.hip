@@ -159,6 +159,7 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     // the first layer writes its BatchNorm partial sums itself: one [2][32] row per work-group, at most one per 32x16 tile
     { const size_t v = N * (size_t)((W + 15) / 16) * (size_t)((H + 31) / 32) * 64; if (v > max_chan) max_chan = v; }
     for (int k = 1; k < 4; ++k) { const size_t v = vad_conv3x3_stats_floats(p.encC[k + 1]); if (v > max_chan) max_chan = v; }   // so do the other encoder convolutions
+    for (int j = 0; j < 3; ++j) { const size_t v = vad_convt2x2_stats_floats(p.decC[j + 1]); if (v > max_chan) max_chan = v; }  // and the decoder's transposed ones
     p.chan_ws = take(max_chan);
     p.wgrad_ws = take(max_wgrad);
     p.to3_ws = take(vad_convt_to3_mse_ws_floats(p.N, H / 2, W / 2));
@@ -297,9 +298,11 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
         const float* in = j == 0 ? dec_in : ws + p.r[j - 1];
         float* u = ws + p.u[j];
-        TRY(vad_convt2x2(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, precision, s));
+        int srows = 0;        // > 0: the transposed convolution wrote the BatchNorm partial sums itself
+        TRY(vad_convt2x2_stats(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, precision, ws + p.chan_ws, &srows, s));
         float* rs = running ? running + p.d_rs[j] : nullptr;
-        TRY(vad_bn_stats(u, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
+        if (srows > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, srows, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, P + p.d_b[j], s));
+        else TRY(vad_bn_stats(u, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
         TRY(vad_bn_act_pool_fwd(u, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], ws + p.r[j], 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
     }
     // last layer + loss, forward and backward (models/video_autoencoder.py:259-260, train_video.py:55)

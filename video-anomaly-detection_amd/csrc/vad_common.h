@@ -110,6 +110,9 @@ int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bi
 int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs, int n, int h,
                       int wd, int cin, int cout, int act, int pool, int precision, float* stats, int* stats_rows, void* stream);
 size_t vad_conv3x3_stats_floats(int cout);
+int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs, int n, int h,
+                       int wd, int cin, int cout, int act, int precision, float* stats, int* stats_rows, void* stream);
+size_t vad_convt2x2_stats_floats(int cout);
 int vad_bn_stats_from_partials(const float* partials, int nblocks, long long npix, int c, float eps, float momentum, float* stats,
                                float* running_mean, float* running_var, const float* pivot, void* stream);
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1, const float* b1,
