@@ -505,12 +505,20 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                     if ((tid >> 3) + 32 * i < NPIX) {
                         if constexpr (PREC) {   // channels 4*c4..4*c4+3 = half (c4&1) of 8-channel block c4>>1
                             const f32x4 v = pf_get_v(pf[i]);
-                            f16x4 hi, lo;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { _Float16 h_, l_; vad_split_p<PREC>(v[e], h_, l_); hi[e] = h_; lo[e] = l_; }
                             float* blk = &tile[(tid >> 3) * PS + i * 32 * PS + (c4 >> 1) * 8 + (c4 & 1) * 2];
-                            *(f16x4*)blk = hi;
-                            *(f16x4*)(blk + 4) = lo;
+                            if constexpr (PREC == 2) {
+                                // bf16: two packed conversions and ONE 8-byte write; the lo half of the block is never read
+                                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                                const bf16x2_t p0 = {(__bf16)v[0], (__bf16)v[1]}, p1 = {(__bf16)v[2], (__bf16)v[3]};
+                                *(u32x2_t*)blk = u32x2_t{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+                            } else {
+                                f16x4 hi, lo;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { _Float16 h_, l_; vad_split_p<PREC>(v[e], h_, l_); hi[e] = h_; lo[e] = l_; }
+                                *(f16x4*)blk = hi;
+                                *(f16x4*)(blk + 4) = lo;
+                            }
                         } else {
                             *(f32x4*)&tile[slds0 + i * 32 * PS] = pf_get_v(pf[i]);
                         }
