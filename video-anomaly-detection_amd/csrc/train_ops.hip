@@ -633,6 +633,102 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
     }
 }
 
+// The same GEMM with the A operand (the 27 taps of a pixel) read from LDS instead of gathered from global memory: a lane's
+// tap of 8 consecutive pixels touches 9 different input rows (3 planes x 3 rows), i.e. every gather instruction of the
+// kernel above spreads over ~9-18 cache lines and each input value is fetched ~9 times per pixel pair - the texture path,
+// not the matrix pipe (0.24 busy) or the memory round trips (deeper prefetch and more waves changed nothing), was its limit.
+// Here every wave keeps the 9 rows (c, y-1..y+1) of ITS current output row in its own LDS region (coalesced 16-byte loads,
+// requested one row ahead, column 0 of the data at float 4 so that the writes stay 16-byte aligned, zero columns at 3 and
+// 4 + W, rows outside the image written as zeros); an A value is then one ds_read_b32 at lane constant + column.  LDS
+// operations of one wave execute in order, and no other wave touches the region: no barrier.  W % 8 == 0 (host-selected).
+template <int MAXQ>      // 16-byte chunks per lane and staged row: W <= 256 * MAXQ (the staging registers set the occupancy)
+__global__ __launch_bounds__(256) void conv_c3_wgrad_lds_kernel(WgradC3P p) {
+    extern __shared__ __attribute__((aligned(16))) float dyn_xs[];
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
+    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (item >= p.nitems) return;
+    const int ctiles = p.cout / 32;
+    const int cgp = item % ctiles;
+    const int split = item / ctiles;
+    const int H = p.h, W = p.w, total_rows = p.n * H, RS = W + 8, W4 = W / 4;
+    float* xs = dyn_xs + (size_t)wave * 9 * RS;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const int c = li < 27 ? li / 9 : 0, tap = li < 27 ? li - (li / 9) * 9 : 0, dy = tap / 3 - 1, dx = tap % 3 - 1;   // rows k >= 27 of the
+    const int lb = (c * 3 + dy + 1) * RS + 4 + dx + lh;          // result are dropped by the reduction: they may read anything finite
+    const unsigned g_bytes = (unsigned)(H * W) * (unsigned)p.cout * 4u;
+    const unsigned gl = (unsigned)(lh * p.cout + cgp * 32 + li) * 4u;
+    constexpr int U = 4;
+    f32x16 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    if (lane < 18) xs[(lane >> 1) * RS + ((lane & 1) ? 4 + W : 3)] = 0.f;     // the zero columns left and right of every row
+
+    // staging: row slot s = c*3 + d holds input row (c, y - 1 + d); chunk q of a slot = its floats [4q, 4q+4)
+    f32x4 st[9][MAXQ];
+    auto fetch_row = [&](int row) {
+        const int n = row / H, y = row - n * H;
+        const float* fx = p.x + (size_t)n * 3 * H * W;
+#pragma unroll
+        for (int s9 = 0; s9 < 9; ++s9) {
+            const int yy = y - 1 + s9 % 3;
+            const bool rok = yy >= 0 && yy < H;                  // (uniform)
+            const float* src = fx + ((size_t)(s9 / 3) * H + (rok ? yy : 0)) * W;
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) {
+                const int q = lane + 64 * j;
+                st[s9][j] = (rok && q < W4) ? *(const f32x4*)(src + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_row = [&]() {
+#pragma unroll
+        for (int s9 = 0; s9 < 9; ++s9)
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) {
+                const int q = lane + 64 * j;
+                if (q < W4) *(f32x4*)&xs[s9 * RS + 4 + 4 * q] = st[s9][j];
+            }
+    };
+    if (r0 < r1) fetch_row(r0);
+    for (int row = r0; row < r1; ++row) {
+        store_row();                                             // (behind every read of the previous row: in order)
+        if (row + 1 < r1) fetch_row(row + 1);                    // in flight during this row's groups
+        const int n = row / H, y = row - n * H;
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n * H * W * p.cout, g_bytes);
+        const unsigned grow = (unsigned)(y * W) * (unsigned)p.cout * 4u;
+        // g values one group ahead, in two alternating register sets (unconditional: behind the row's last group the request
+        // goes to that group again - a load under `if` would make hipcc wait for it in front of the MFMAs)
+        float bva[U], bvb[U];
+        auto load_g = [&](int x, float (&b_)[U]) {
+            const int xc = __builtin_amdgcn_readfirstlane(x < W ? x : W - 2 * U);
+#pragma unroll
+            for (int u = 0; u < U; ++u) b_[u] = vad_bload1(rg, gl, grow + (unsigned)((xc + 2 * u) * p.cout) * 4u);
+        };
+        auto mma = [&](int x, const float (&b_)[U]) {
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) av[u] = xs[lb + x + 2 * u];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = MFMA32(av[u], b_[u], acc[u]);
+        };
+        load_g(0, bva);
+        for (int x = 0; x < W; x += 4 * U) {
+            load_g(x + 2 * U, bvb);
+            mma(x, bva);
+            load_g(x + 4 * U, bva);
+            if (x + 2 * U < W) mma(x + 2 * U, bvb);      // (uniform)
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        p.ws[((size_t)split * 32 + k) * p.cout + cgp * 32 + li] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+    }
+}
+
 // Fixed-order sum of the split-K partials, written in the torch parameter layout.
 //   layout 0: Conv2d OIHW            dst[(col*cin + ci)*9 + tap]                       (taps 9)
 //   layout 1: ConvTranspose2d IOHW   col = q*cout + co -> dst[(ci*cout + co)*4 + q]    (taps 1, ncols = 4*cout)
@@ -1126,7 +1222,13 @@ extern "C" int vad_conv_c3_wgrad(const float* x_nchw, const float* g, float* dw,
     const long long items = (long long)(cout / 32) * p.splits;
     p.nitems = (unsigned)items;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
+    const size_t lds = (size_t)4 * 9 * (w + 8) * sizeof(float);
+    if (w % 8 == 0 && w <= 1024 && lds <= 64 * 1024) {
+        if (w <= 256) hipLaunchKernelGGL(conv_c3_wgrad_lds_kernel<1>, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(conv_c3_wgrad_lds_kernel<4>, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, s, p);
+    } else {
+        hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
+    }
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((32ll * cout + 63) / 64)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
     VAD_LAUNCH_CHECK();
