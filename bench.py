@@ -64,8 +64,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["image", "video", "dense"], default="image")
-    ap.add_argument("--stream-frames", type=int, default=0,
-                    help="configs[3] on the side: also time scoring.score_stream over this many frames (image workload, reported as `stream`)")
+    ap.add_argument("--stream-frames", type=int, default=-1,
+                    help="configs[3]: also time scoring.score_stream over this many frames (image workload, reported as `stream`); "
+                         "-1 = 100000 in the default line (image, fp32, default batch / size), 0 = skip")
+    ap.add_argument("--no-video", action="store_true", help="skip the secondary configs[2] measurement of the default line")
     ap.add_argument("--stride", type=int, default=1, help="dense workload: window stride")
     ap.add_argument("--precision", choices=["fp32", "split"], default="fp32",
                     help="fp32 = exact fp32 MFMA (headline); split = opt-in 3 x fp16 MFMA with fp32 accumulate")
@@ -231,54 +233,9 @@ def main():
 
     layers, roofline = None, None
     if events:
-        import ctypes as C
-        ms = (C.c_float * hip.PROF_SLOTS)()
-        cnt = (C.c_int * hip.PROF_SLOTS)()
-        hip.check(lib.vad_prof_read(ms, cnt), "vad_prof_read")
-        model_id = 0 if args.workload == "image" else 1
-        layers = {lib.vad_prof_slot_name(model_id, i).decode(): {"ms": round(ms[i], 4), "launches": cnt[i]}
-                  for i in range(hip.PROF_SLOTS) if cnt[i]}
-        frames_rank = frames_per_step * args.steps
-        if args.workload == "image":
-            lf = image_mfma_layer_flops(hw, hw, 256)
-            mf_ms = sum(ms[i] for i in lf)
-            mf_launch = sum(cnt[i] for i in lf)
-            mf_flop = sum(lf.values()) * frames_rank
-            for i, fl in lf.items():
-                nm = lib.vad_prof_slot_name(0, i).decode()
-                layers[nm]["tflops"] = round(fl * frames_rank / (ms[i] * 1e-3) / 1e12, 2) if ms[i] > 0 else None
-        else:
-            # dominant kernel of the video path: the same conv3x3 MFMA kernel in its ConvLSTM form
-            h16 = hw // 16
-            step_flop = conv3x3_flops(h16, h16, 256, 512)          # per clip per (layer, t) launch
-            enc = [conv3x3_flops(hw // 2, hw // 2, 32, 64), conv3x3_flops(hw // 4, hw // 4, 64, 128),
-                   conv3x3_flops(hw // 8, hw // 8, 128, 128)]
-            mf_ms = ms[4] + ms[1] + ms[2] + ms[3]
-            mf_launch = cnt[4] + cnt[1] + cnt[2] + cnt[3]
-            # ConvLSTM FLOPs actually executed: at t = 0 the state is exactly zero and the h half of K is skipped
-            # (the reference multiplies by zeros there), so a clip costs 2 layers x (T - 1/2) full steps.
-            clips_rank = per_gpu * args.steps
-            lstm_flop = step_flop * 2 * (t - 0.5) * clips_rank
-            # frames that pass through the encoder: every (clip, t) frame, or each source frame once for dense windows
-            enc_frames = ((per_gpu - 1) * args.stride + t) * args.steps if args.workload == "dense" else frames_rank
-            mf_flop = lstm_flop + sum(enc) * enc_frames
-            layers["convlstm"]["tflops"] = round(lstm_flop / (ms[4] * 1e-3) / 1e12, 2) if ms[4] > 0 else None
-        ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-        # (tools/pmc_traffic.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); only valid for the default shape.
-        traffic, traffic_source = None, None
-        pmcs = sorted((REPO / "profiles").glob(f"r*_pmc_traffic_{args.workload}.json"))     # newest round last
-        if pmcs and hw == 256 and not args.batch and int(model.chunk) == (512 if args.workload == "image" else 64) and (args.workload != "video" or t == 10):
-            traffic = round(json.loads(pmcs[-1].read_text())["traffic_bytes_per_launch"])
-            traffic_source = f"profiles/{pmcs[-1].name} (separate rocprofv3 --pmc passes of this command, not this run)"
-        roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_pkernel (fp32 32x32x2 MFMA; all launches)",
-                    "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "algorithmic_flop_per_launch": round(mf_flop / max(mf_launch, 1)),
-                    "avg_launch_ms": round(mf_ms / max(mf_launch, 1), 4), "launches": mf_launch,
-                    "whole_path_tflops": round(fps / world * flop_per_frame / 1e12, 2),
-                    "whole_path_hbm_gbs": round(fps / world * bytes_per_frame / 1e9, 1),
-                    "whole_path_hbm_frac": round(fps / world * bytes_per_frame / 1e9 / PEAK_HBM_GBS, 4)}
+        default_shape = hw == 256 and not args.batch and int(model.chunk) == (512 if args.workload == "image" else 64) and (args.workload != "video" or t == 10)
+        layers, roofline = layers_and_roofline(hip, lib, args.workload, hw, per_gpu, args.steps, t if args.workload != "image" else 0,
+                                               args.stride, default_shape, fps / world, flop_per_frame, bytes_per_frame)
 
     out = {
         "metric": "frames/sec/GPU (256x256 autoencoder scoring) + AUROC parity vs reference",
@@ -320,20 +277,29 @@ def main():
                                   "arithmetic": "a*b = ah*bh + (ah*bl + al*bh)*2^-11, fp16 hi/lo operands, fp32 accumulate"}
         model.precision = "fp32"
         scores = exact_scores
-    # configs[3] (opt-in: --stream-frames 100000): the frame stream generated on the device in chunks of 512, block-partitioned
-    # over the ranks, ONE all_gather at the end; generation is inside the timed region
-    if args.stream_frames > 0 and args.workload == "image" and args.precision == "fp32":
+    # configs[3]: the frame stream generated on the device in chunks of 512, block-partitioned over the ranks, ONE all_gather
+    # at the end; generation is inside the timed region.  Part of the default line (image, fp32, default batch and size: the
+    # driver's `bench.py --gpus N` run); 100,000 frames in total whatever the rank count (strong scaling, its own object).
+    default_line = args.workload == "image" and args.precision == "fp32" and not args.batch and hw == 256 and args.ingest == "f32" and not args.graph
+    stream_frames = args.stream_frames if args.stream_frames >= 0 else (100000 if default_line else 0)
+    if stream_frames > 0 and args.workload == "image" and args.precision == "fp32":
         fence()
         t1 = time.perf_counter()
-        sv = vad.scoring.score_stream(model, seed + 2, args.stream_frames, chunk=512, h=hw, w=hw, rank=rank, world=world, device=dev)
+        sv = vad.scoring.score_stream(model, seed + 2, stream_frames, chunk=512, h=hw, w=hw, rank=rank, world=world, device=dev)
         fence()
         el3 = time.perf_counter() - t1
         if dist is not None:
             tt = torch.tensor([el3], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el3 = float(tt.item())
-        out["stream"] = {"frames": args.stream_frames, "seconds": round(el3, 4), "value": round(args.stream_frames / el3, 1), "unit": "frames/s",
+        out["stream"] = {"frames": stream_frames, "seconds": round(el3, 4), "value": round(stream_frames / el3, 1), "unit": "frames/s",
+                         "scaling": "strong", "frames_per_rank": -(-stream_frames // world),
+                         "config": {"workload": f"configs[3]: {stream_frames}-frame synthetic {hw}x{hw}x3 stream, block-partitioned over {world} rank(s), "
+                                                "generated on the device in chunks of 512, one all_gather of the score vector at the end"},
                          "includes": "on-device frame generation, scoring, one all_gather", "checksum": float(sv.double().sum())}
+    # configs[2] beside it (1 GPU: the driver's N = 1 line then carries every single-GPU configuration)
+    if rank == 0 and world == 1 and default_line and not args.no_video:
+        out["video"] = video_config2(vad, hip, lib, dev, hw, args.steps, args.warmup, not args.no_cpu_baseline)
     # Secondary measurement (row f-1): the native training step of the ConvLSTM video autoencoder (train_video.py:44-65),
     # exact fp32, 32 clips x 10 frames at the bench resolution.  Never part of `value` / `roofline`.
     if rank == 0 and world == 1 and not args.no_train and args.workload == "image" and args.precision == "fp32":
@@ -341,13 +307,70 @@ def main():
     if args.workload == "dense":
         out["unique_frames_per_sec"] = round(((per_gpu - 1) * args.stride + t) * world * args.steps / elapsed, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "dense":
-        out["cpu_baseline"] = cpu_baseline(vad, state, args, scores, seed, hw)
+        out["cpu_baseline"] = cpu_baseline(vad, state, args.workload, args.clip_len, scores, seed, hw)
     if world > 1:
         out["multi_gpu"] = multi_gpu_evidence(vad, dist, args, state, scores, seed, hw, per_gpu, width, rank, world, dev, local_rank)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def layers_and_roofline(hip, lib, kind, hw, per_gpu, steps, t, stride, default_shape, fps_per_gpu, flop_per_frame, bytes_per_frame):
+    """Per-layer hipEvent times recorded by the library on the launch stream during the timed region (vad_prof_*), and the
+    `roofline` object of the dominant kernel: achieved = sum of the algorithmic FLOP of its launches / sum of their durations."""
+    import ctypes as C
+    ms = (C.c_float * hip.PROF_SLOTS)()
+    cnt = (C.c_int * hip.PROF_SLOTS)()
+    hip.check(lib.vad_prof_read(ms, cnt), "vad_prof_read")
+    model_id = 0 if kind == "image" else 1
+    layers = {lib.vad_prof_slot_name(model_id, i).decode(): {"ms": round(ms[i], 4), "launches": cnt[i]}
+              for i in range(hip.PROF_SLOTS) if cnt[i]}
+    frames_step = per_gpu * (t if kind != "image" else 1)
+    frames_rank = frames_step * steps
+    if kind == "image":
+        lf = image_mfma_layer_flops(hw, hw, 256)
+        mf_ms = sum(ms[i] for i in lf)
+        mf_launch = sum(cnt[i] for i in lf)
+        mf_flop = sum(lf.values()) * frames_rank
+        for i, fl in lf.items():
+            nm = lib.vad_prof_slot_name(0, i).decode()
+            layers[nm]["tflops"] = round(fl * frames_rank / (ms[i] * 1e-3) / 1e12, 2) if ms[i] > 0 else None
+    else:
+        # dominant kernel of the video path: the same conv3x3 MFMA kernel in its ConvLSTM form
+        h16 = hw // 16
+        step_flop = conv3x3_flops(h16, h16, 256, 512)          # per clip per (layer, t) launch
+        enc = [conv3x3_flops(hw // 2, hw // 2, 32, 64), conv3x3_flops(hw // 4, hw // 4, 64, 128),
+               conv3x3_flops(hw // 8, hw // 8, 128, 128)]
+        mf_ms = ms[4] + ms[1] + ms[2] + ms[3]
+        mf_launch = cnt[4] + cnt[1] + cnt[2] + cnt[3]
+        # ConvLSTM FLOPs actually executed: at t = 0 the state is exactly zero and the h half of K is skipped
+        # (the reference multiplies by zeros there), so a clip costs 2 layers x (T - 1/2) full steps.
+        clips_rank = per_gpu * steps
+        lstm_flop = step_flop * 2 * (t - 0.5) * clips_rank
+        # frames that pass through the encoder: every (clip, t) frame, or each source frame once for dense windows
+        enc_frames = ((per_gpu - 1) * stride + t) * steps if kind == "dense" else frames_rank
+        mf_flop = lstm_flop + sum(enc) * enc_frames
+        layers["convlstm"]["tflops"] = round(lstm_flop / (ms[4] * 1e-3) / 1e12, 2) if ms[4] > 0 else None
+        # the same figure for the whole path (review of round 2: the frame constant counts the h half at t = 0 too)
+        flop_per_frame = flop_per_frame - step_flop * 2 * 0.5 / t
+    ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    # (tools/pmc_traffic.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); only valid for the default shape.
+    traffic, traffic_source = None, None
+    pmcs = sorted((REPO / "profiles").glob(f"r*_pmc_traffic_{kind}.json"))     # newest round last
+    if pmcs and default_shape:
+        traffic = round(json.loads(pmcs[-1].read_text())["traffic_bytes_per_launch"])
+        traffic_source = f"profiles/{pmcs[-1].name} (separate rocprofv3 --pmc passes of this command, not this run)"
+    roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_pkernel (fp32 32x32x2 MFMA; all launches)",
+                "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_flop_per_launch": round(mf_flop / max(mf_launch, 1)),
+                "avg_launch_ms": round(mf_ms / max(mf_launch, 1), 4), "launches": mf_launch,
+                "whole_path_tflops": round(fps_per_gpu * flop_per_frame / 1e12, 2),
+                "whole_path_hbm_gbs": round(fps_per_gpu * bytes_per_frame / 1e9, 1),
+                "whole_path_hbm_frac": round(fps_per_gpu * bytes_per_frame / 1e9 / PEAK_HBM_GBS, 4)}
+    return layers, roofline
 
 
 def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
@@ -452,34 +475,77 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(vad, state, args, gpu_scores, seed, hw):
+def cpu_baseline(vad, state, kind, clip_len, gpu_scores, seed, hw):
     """The CPU restatement (oracle/torch_oracle.py — the reference itself cannot travel) on the host cores, on a
-    bounded sample of the same workload, plus the GPU-vs-CPU score parity on that sample."""
+    bounded sample of the same workload (1 warm-up + 2 timed passes), plus the GPU-vs-CPU score
+    parity on that sample."""
     from oracle import torch_oracle
     cores = host_cores()
     torch.set_num_threads(cores)
+    passes = 2
     with torch.no_grad():
-        if args.workload == "image":
+        if kind == "image":
             n, bs = 64, 16                                   # configs[0]: 64 frames, batches of 16 (evaluate.py:240)
             xs = torch.from_numpy(vad.synth.frames(seed, 0, n, 3, hw, hw))
             torch_oracle.img_scores(state, xs[:bs])          # warm-up
             t0 = time.perf_counter()
-            ref = torch.cat([torch_oracle.img_scores(state, xs[i:i + bs])["scores"] for i in range(0, n, bs)])
-            dt = time.perf_counter() - t0
+            for _ in range(passes):
+                ref = torch.cat([torch_oracle.img_scores(state, xs[i:i + bs])["scores"] for i in range(0, n, bs)])
+            dt = (time.perf_counter() - t0) / passes
             got = gpu_scores[:n].cpu()
-            frames, sample = n, f"{n} of the step's frames, batches of {bs}, 1 warm-up batch + 1 timed pass"
+            frames, sample = n, f"{n} of the step's frames, batches of {bs}, 1 warm-up batch + {passes} timed passes (mean)"
         else:
-            nclips, t = 4, args.clip_len
+            nclips, t = 4, clip_len
             xs = torch.from_numpy(vad.synth.clips(seed, 0, nclips, t, 3, hw, hw))
             torch_oracle.vid_scores(state, xs[:1], 128, 2)
             t0 = time.perf_counter()
-            ref = torch_oracle.vid_scores(state, xs, 128, 2)["frame"]
-            dt = time.perf_counter() - t0
+            for _ in range(passes):
+                ref = torch_oracle.vid_scores(state, xs, 128, 2)["frame"]
+            dt = (time.perf_counter() - t0) / passes
             got = gpu_scores[:nclips].cpu()
-            frames, sample = nclips * t, f"{nclips} clips x {t} frames in one batch, 1 warm-up clip + 1 timed pass"
+            frames, sample = nclips * t, f"{nclips} clips x {t} frames in one batch, 1 warm-up clip + {passes} timed passes (mean)"
     rel = float(((got - ref).abs() / ref.abs()).max())
     return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
             "gpu_vs_cpu_max_rel_score_err": rel}
+
+
+def video_config2(vad, hip, lib, dev, hw, steps, warmup, with_cpu, clips=64, t=10):
+    """BASELINE configs[2] beside the headline in the default line: ConvLSTM video autoencoder scoring, 64 clips x 10 frames
+    resident in HBM, same step / warm-up counts, with its own `roofline` (dominant kernel: the conv3x3 MFMA kernel in its
+    encoder and ConvLSTM forms) and `cpu_baseline`.  Never part of `value`."""
+    seed = 0xC0FFEE + 2
+    model = vad.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    state = {k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, 8).items()}
+    model.load_state_dict(state, strict=True)
+    model = model.to(dev).eval()
+    x = vad.scoring.synth_frames_device(seed, 0, clips * t, hw, hw, device=dev).view(clips, t, 3, hw, hw)
+    with torch.no_grad():
+        for _ in range(warmup):
+            scores = model.get_reconstruction_error(x, per_frame=True)
+        torch.cuda.synchronize(dev)
+        lib.vad_prof_reset()
+        lib.vad_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            scores = model.get_reconstruction_error(x, per_frame=True)
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        lib.vad_prof_enable(0)
+    fps = clips * t * steps / elapsed
+    scale = (hw * hw) / 65536.0
+    layers, roofline = layers_and_roofline(hip, lib, "video", hw, clips, steps, t, 1, hw == 256 and int(model.chunk) == 64, fps,
+                                           VID_FLOP_PER_FRAME * scale, VID_BYTES_PER_FRAME * scale)
+    out = {"value": round(fps, 1), "unit": "frames/s", "clips_per_sec": round(fps / t, 1), "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "dtype": "f32",
+           "config": {"workload": f"configs[2]: ConvLSTM video autoencoder scoring, {clips} clips x {t} frames of {hw}x{hw}x3 per GPU",
+                      "frames_per_gpu_per_step": clips * t, "chunk": int(model.chunk)},
+           "roofline": roofline, "layers": layers}
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(vad, state, "video", t, scores, seed, hw)
+    del model, x
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

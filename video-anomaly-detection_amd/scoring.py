@@ -106,20 +106,21 @@ def block_partition(n_items: int, world: int, rank: int) -> Tuple[int, int, int]
 
 
 def sharded_scores(score_block: Callable[[int, int], torch.Tensor], n_items: int, width: int = 1,
-                   rank: int = 0, world: int = 1, device="cpu", group=None) -> torch.Tensor:
+                   rank: int = 0, world: int = 1, device="cpu", group=None, force_collective: bool = False) -> torch.Tensor:
     """Score items [0, n_items) across `world` ranks and return float32[n_items, width] (squeezed to
     [n_items] when width == 1) in the original order on EVERY rank.
 
     `score_block(first, count)` returns this rank's scores for items [first, first+count) as a float32
     tensor [count] or [count, width] on `device`.  The only communication is one all_gather of
     `per * width` floats per rank; the tail of the last block is zero padding that is cut off after the
-    gather, so rank-major order == original order.
+    gather, so rank-major order == original order.  `force_collective` runs the all_gather for world == 1 too (a
+    one-rank process group: how the RCCL branch is exercised on a one-GPU box).
     """
     start, count, per = block_partition(n_items, world, rank)
     local = torch.zeros(per, width, dtype=torch.float32, device=device)
     if count:
         local[:count] = score_block(start, count).reshape(count, width).to(torch.float32)
-    if world > 1:
+    if world > 1 or force_collective:
         import torch.distributed as dist
         gathered = torch.empty(world * per, width, dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(gathered, local, group=group)
@@ -130,7 +131,7 @@ def sharded_scores(score_block: Callable[[int, int], torch.Tensor], n_items: int
 
 
 def score_stream(model, seed: int, n_frames: int, chunk: int = 512, h: int = 256, w: int = 256, rank: int = 0,
-                 world: int = 1, device="cuda", anomalies: bool = False, group=None) -> torch.Tensor:
+                 world: int = 1, device="cuda", anomalies: bool = False, group=None, force_collective: bool = False) -> torch.Tensor:
     """BASELINE configs[3]: score a long synthetic frame stream without ever materialising it.  The stream is
     block-partitioned over ranks; each rank regenerates its frames on the device `chunk` at a time (the counter-based
     generator makes any sub-range reproducible, on any rank and on the CPU), scores them with
@@ -147,4 +148,4 @@ def score_stream(model, seed: int, n_frames: int, chunk: int = 512, h: int = 256
                 out[s:s + k] = model.get_reconstruction_error(buf[:k])
         return out
 
-    return sharded_scores(score_block, n_frames, 1, rank, world, dev, group)
+    return sharded_scores(score_block, n_frames, 1, rank, world, dev, group, force_collective)

@@ -24,10 +24,11 @@ from . import hip
 from .video_autoencoder import VideoAutoencoder
 
 
-def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> None:
-    """Overwrite `flat` on every rank with rank `src`'s copy (same gloo host-copy route as `allreduce_sum_`)."""
+def broadcast_(flat: torch.Tensor, src: int = 0, group=None, force_collective: bool = False) -> None:
+    """Overwrite `flat` on every rank with rank `src`'s copy (same gloo host-copy route as `allreduce_sum_`).
+    `force_collective`: issue the collective in a one-rank group too (exercises the RCCL call on a one-GPU box)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         return
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         host = flat.detach().cpu()
@@ -37,7 +38,7 @@ def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> None:
         dist.broadcast(flat, src=src, group=group)
 
 
-def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
+def allreduce_sum_(flat: torch.Tensor, group=None, force_collective: bool = False) -> int:
     """Sum `flat` over the ranks of `group`, in place; returns the world size (1 when no process group is initialised).
     Backend "nccl" is RCCL on ROCm: one collective over the flat gradient buffer on the device.  With gloo (the CPU tests,
     single-GPU rehearsals with several ranks sharing one device) a GPU tensor goes through a host copy."""
@@ -45,7 +46,7 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective:
         return 1
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         host = flat.detach().cpu()
@@ -59,6 +60,9 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> int:
 class _FlatTrainer:
     """Shared host logic of the native trainers: the module's parameters / BatchNorm buffers become views of flat device
     buffers (one optimiser launch, one gradient all-reduce), torch.optim.Adam semantics and state-dict format."""
+
+    #: issue the gradient all-reduce in a one-rank process group too (tests: the RCCL call path on a one-GPU box)
+    force_collective = False
 
     def __init__(self, model: nn.Module, nparams: int, nstats: int, lr, weight_decay, betas, eps, process_group):
         params = list(model.parameters())
@@ -195,7 +199,7 @@ class _FlatTrainer:
         all-reduce of the flat buffer and averaged inside the optimiser kernel (DistributedDataParallel semantics)."""
         self._check_aliasing()
         loss, _ = self.forward_backward(batch)
-        world = allreduce_sum_(self.grad, self.group)
+        world = allreduce_sum_(self.grad, self.group, self.force_collective)
         self.optimizer_step(1.0 / world)
         return loss
 
