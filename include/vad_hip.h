@@ -117,7 +117,9 @@ int vad_convlstm_step(const float* x, long long x_fs, const float* h_prev, long 
  * recon_nchw (NCHW [N,3,H2,W2]) and errmap ([N,H2,W2], channel mean) may be NULL.
  * Replaces models/autoencoder.py:211-221 and models/video_autoencoder.py:368-384. */
 int vad_score_partials(int kind /*0: conv3x3 tail, 1: convT tail*/, int h2, int w2);
-/* Conv2d(cin->3) weight OIHW (3,cin,3,3) -> [cin/4][9 taps][4 channels][3 outputs] (per-lane weight rows). */
+/* Conv2d(cin->3) weight OIHW (3,cin,3,3) -> [cin/4][9 taps][4 channels][3 outputs] (per-lane weight rows), followed for
+ * cin == 32 by the GEMM form the fused kernel below reads (1024 floats at offset (cin/4)*108: [m = tap*3+co, 32 rows][lane
+ * half][16 channel steps]). */
 size_t vad_pack_conv3x3_to3_floats(int cin);
 int vad_pack_conv3x3_to3(const float* w_oihw, int cin, float* w_packed);
 /* Conv2d(32->3) k3 p1 + Tanh (models/autoencoder.py:134-135) on NHWC [N,H2,W2,32]. */
@@ -125,6 +127,15 @@ int vad_conv3x3_to3_score(const float* in_nhwc, const float* w_packed /*vad_pack
                           const float* bias3, const float* x_nchw, float* partials,
                           float* recon_nchw, float* errmap, int n, int h2, int w2, int cin,
                           void* stream);
+/* dec4 block + scoring in ONE launch: ConvTranspose2d(32->32, k2 s2) + BatchNorm + ReLU, Conv2d(32->3, k3 p1) + Tanh,
+ * squared error, channel mean, per-row partial sums (models/autoencoder.py:131-139, 211-221).  in_nhwc [N,H,W,32] is the
+ * dec3.3 output; the frame is 2H x 2W; the 32-channel full-resolution map between the two layers is never stored.
+ * wt_packed / bt: vad_pack_convt2x2(..., VAD_PREC_FP32) of dec4.0 with dec4.1 folded; w2_gemm: vad_pack_conv3x3_to3's
+ * second form; partials: [N][vad_dec4_score_partials(2H, 2W)].  Exact fp32 only. */
+int vad_dec4_score_partials(int h2, int w2);
+int vad_dec4_score(const float* in_nhwc, const float* wt_packed, const float* bt, const float* w2_gemm,
+                   const float* bias3, const float* x_nchw, float* partials, float* recon_nchw, float* errmap,
+                   int n, int h, int w, void* stream);
 /* ConvTranspose2d(32->3) k2 s2 + Tanh (models/video_autoencoder.py:259-260) on NHWC [N,H,W,32]. */
 /* t, clip_stride: activation frame n is scored against x frame (n / t) * clip_stride + n % t (sliding windows
  * over one video); t == 0 or t == clip_stride means frame n (independent clips). */
@@ -331,6 +342,10 @@ int vad_debug_set_conv_variant(int variant);
 int vad_debug_set_lstm_wavefront(int on);
 /* Frames per dec4.0 -> scoring-tail sub-group inside vad_img_score (0 = whole launch group). */
 int vad_debug_set_tail_group(int frames);
+/* A/B: 0 = dec4.0 and the scoring tail of the image model as two launches (round-2 path), 1 = the fused kernel (default) */
+int vad_debug_set_dec4_fused(int on);
+/* rows of the dec3.3 map per work-group band of the fused kernel (0 = chosen from the batch size); results do not depend on it */
+int vad_debug_set_dec4_band(int rows);
 
 /* Row f-3 — raw-frame ingest.  The *_x forms take the original frames in either format:
  *   VAD_X_F32_NCHW (0): float32 [N,3,H,W] already normalised to [-1,1] (same as the plain entry points);

@@ -207,3 +207,76 @@ def test_bad_arguments_are_rejected():
     assert l.vad_conv3x3(t.data_ptr(), 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 1, 5, 4, 32, 32, 0, 1, 0, None) == -1
     assert l.vad_img_score(t.data_ptr(), 1, 30, 32, 256, t.data_ptr(), t.data_ptr(), 64, 1, t.data_ptr(), None, None, None, None) == -1
     assert l.vad_img_score(t.data_ptr(), 1, 32, 32, 256, t.data_ptr(), t.data_ptr(), 64, 1, t.data_ptr(), None, None, None, None) == -3
+
+
+def _dec4_case(rng, n, h, w):
+    x_in = np.maximum(rng.standard_normal((n, 32, h, w)), 0).astype(np.float32)            # dec3.3 output (post-ReLU)
+    wt = (rng.standard_normal((32, 32, 2, 2)) * np.sqrt(1.0 / 32)).astype(np.float32)
+    bt = (rng.standard_normal(32) * 0.1).astype(np.float32)
+    bn = [a.astype(np.float32) for a in (rng.uniform(0.5, 1.5, 32), rng.standard_normal(32) * 0.1,
+                                         rng.standard_normal(32) * 0.1, rng.uniform(0.25, 1.75, 32))]
+    w3 = (rng.standard_normal((3, 32, 3, 3)) * np.sqrt(1.0 / (32 * 9))).astype(np.float32)
+    b3 = (rng.standard_normal(3) * 0.1).astype(np.float32)
+    frames = rng.uniform(-1, 1, (n, 3, 2 * h, 2 * w)).astype(np.float32)
+    return x_in, wt, bt, bn, w3, b3, frames
+
+
+def _dec4_run(H, case, fused, band=0, u8=None):
+    """dec4 block + scoring through the C ABI: fused kernel, or the two launches it replaces.  -> (recon, errmap, scores)"""
+    import ctypes as C
+    x_in, wt, bt, bn, w3, b3, frames = case
+    l = H.hip.lib()
+    n, _, h, w = x_in.shape
+    h2, w2 = 2 * h, 2 * w
+    wtp, btp = H.pack_convt(wt, bt, bn)
+    w3p = np.empty(l.vad_pack_conv3x3_to3_floats(32), np.float32)
+    H.hip.check(l.vad_pack_conv3x3_to3(np.ascontiguousarray(w3).ctypes.data, 32, w3p.ctypes.data))
+    w3d, b3d = H.dev(w3p), H.dev(b3)
+    xin, xf = H.nhwc(x_in), H.dev(frames)
+    recon = torch.full((n, 3, h2, w2), float("nan"), device="cuda")
+    emap = torch.full((n, h2, w2), float("nan"), device="cuda")
+    scores = torch.full((n,), float("nan"), device="cuda")
+    if fused:
+        nparts = l.vad_dec4_score_partials(h2, w2)
+        parts = torch.full((n, nparts), float("nan"), device="cuda")
+        l.vad_debug_set_dec4_band(band)
+        try:
+            H.hip.check(l.vad_dec4_score(xin.data_ptr(), wtp.data_ptr(), btp.data_ptr(), w3d.data_ptr() + 4 * 8 * 108, b3d.data_ptr(),
+                                         xf.data_ptr(), parts.data_ptr(), recon.data_ptr(), emap.data_ptr(), n, h, w, H.stream()))
+        finally:
+            l.vad_debug_set_dec4_band(0)
+    else:
+        nparts = l.vad_score_partials(0, h2, w2)
+        parts = torch.full((n, nparts), float("nan"), device="cuda")
+        act = torch.full((n, h2, w2, 32), float("nan"), device="cuda")
+        H.hip.check(l.vad_convt2x2(xin.data_ptr(), 0, wtp.data_ptr(), btp.data_ptr(), act.data_ptr(), 0, n, h, w, 32, 32, 2, 0, H.stream()))
+        H.hip.check(l.vad_conv3x3_to3_score(act.data_ptr(), w3d.data_ptr(), b3d.data_ptr(), xf.data_ptr(), parts.data_ptr(),
+                                            recon.data_ptr(), emap.data_ptr(), n, h2, w2, 32, H.stream()))
+    H.hip.check(l.vad_score_finalize(parts.data_ptr(), nparts, n, h2, w2, scores.data_ptr(), None, 1, H.stream()))
+    torch.cuda.synchronize()
+    return recon.cpu().numpy(), emap.cpu().numpy(), scores.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 8, 24), (1, 5, 72), (2, 33, 128), (1, 7, 136), (1, 4, 264), (2, 128, 128)])
+def test_dec4_fused_kernel(n, h, w):
+    """dec4.0 + dec4.3 + score in one kernel (csrc/dec4_fused.hip) against the CPU oracle's ConvTranspose2d + BatchNorm +
+    ReLU + Conv2d + Tanh + squared error, against the two launches it replaces (same activations bit for bit; the 3x3 sum is
+    ordered differently, so recon agrees to rounding), and against itself under every band height (torch.equal: the order of
+    every sum depends on the pixel only).  Widths above 128 exercise the strips, 5 / 7 / 33 rows the ragged bands."""
+    import hip_helpers as H
+    rng = _rng(n * 1000 + h * 10 + w)
+    case = _dec4_case(rng, n, h, w)
+    x_in, wt, bt, bn, w3, b3, frames = case
+    act = np.maximum(c_oracle.batchnorm_eval(c_oracle.convt2x2(x_in, wt, bt), *bn), 0)
+    ref_recon = np.tanh(c_oracle.conv2d(act, w3, b3, 3).astype(np.float64))
+    ref_emap = ((frames.astype(np.float64) - ref_recon) ** 2).mean(axis=1)
+    ref_scores = ref_emap.mean(axis=(1, 2))
+    recon, emap, scores = _dec4_run(H, case, fused=True)
+    assert np.isfinite(recon).all() and np.isfinite(emap).all() and np.isfinite(scores).all()
+    assert max_abs(recon, ref_recon) < ATOL and max_abs(emap, ref_emap) < ATOL
+    assert np.max(np.abs(scores - ref_scores) / ref_scores) < 1e-5
+    r2, e2, s2 = _dec4_run(H, case, fused=False)
+    assert max_abs(recon, r2) < 2e-6 and np.max(np.abs(scores - s2) / s2) < 1e-6
+    for band in (1, 2, 3, 16, 1000):
+        rb, eb, sb = _dec4_run(H, case, fused=True, band=band)
+        assert np.array_equal(recon, rb) and np.array_equal(emap, eb) and np.array_equal(scores, sb), band

@@ -150,7 +150,10 @@ extern "C" int vad_pack_conv1x1(const float* w, const float* bias, int cout, int
     return VAD_OK;
 }
 
-extern "C" size_t vad_pack_conv3x3_to3_floats(int cin) { return (size_t)(cin / 4) * 108; }
+// two forms of the same weights: the per-lane rows of the VALU tail kernel, then (cin == 32 only) the A operand of the fused
+// dec4 kernel's second GEMM (csrc/dec4_fused.hip): [m 32][lane half 2][r 16], m = tap * 3 + co (rows 27..31 zero),
+// element = W[co][ci = (r & 3) + 8 (r >> 2) + 4 half][tap]
+extern "C" size_t vad_pack_conv3x3_to3_floats(int cin) { return (size_t)(cin / 4) * 108 + (cin == 32 ? 1024 : 0); }
 
 // [cin/4][9 taps][4 channels][3 outputs]: lane cg of the tail kernel reads its 108 weights contiguously
 extern "C" int vad_pack_conv3x3_to3(const float* w, int cin, float* out) {
@@ -159,6 +162,15 @@ extern "C" int vad_pack_conv3x3_to3(const float* w, int cin, float* out) {
         for (int tap = 0; tap < 9; ++tap)
             for (int co = 0; co < 3; ++co)
                 out[(size_t)(ci / 4) * 108 + tap * 12 + (ci & 3) * 3 + co] = w[((size_t)co * cin + ci) * 9 + tap];
+    if (cin == 32) {
+        float* g = out + (size_t)(cin / 4) * 108;
+        for (int m = 0; m < 32; ++m)
+            for (int half = 0; half < 2; ++half)
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = (r & 3) + 8 * (r >> 2) + 4 * half, tap = m / 3, co = m % 3;
+                    g[(m * 2 + half) * 16 + r] = m < 27 ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f;
+                }
+    }
     return VAD_OK;
 }
 

@@ -71,7 +71,7 @@ extern "C" int vad_prof_read(float* ms, int* launches) {
 
 static const char* kImgSlots[] = {"enc1.0", "enc1.0+enc1.3+pool", "enc2.0", "enc2.3+pool", "enc3.0", "enc3.3+pool",
                                   "enc4.0", "enc4.3+pool", "dec1.0", "dec1.3", "dec2.0", "dec2.3", "dec3.0",
-                                  "dec3.3", "dec4.0", "dec4.3+score", "finalize", "latent_nchw"};
+                                  "dec3.3", "dec4.0", "dec4.3+score", "finalize", "latent_nchw", "dec4.0+dec4.3+score"};
 static const char* kVidSlots[] = {"enc.0+pool", "enc.4+pool", "enc.8+pool", "enc.12+pool", "convlstm", "proj",
                                   "dec.0", "dec.3", "dec.6", "dec.9+score", "finalize"};
 extern "C" const char* vad_prof_slot_name(int model, int slot) {
@@ -127,10 +127,19 @@ static size_t img_act_floats(int h, int w, int latent) {
     return e4 > m ? e4 : m;
 }
 
+// per-frame partial sums: the larger of the two tails' counts (unfused 32x32 tiles; fused: one per output row, strip and wave)
+static size_t img_partials(int h, int w) {
+    const size_t a = (size_t)vad_score_partials(0, h, w), b = (size_t)vad_dec4_score_partials(h, w);
+    return a > b ? a : b;
+}
+
+static std::atomic<int> g_vad_dec4_fused{1};   // debug / A-B: 0 = dec4.0 and the scoring tail as two launches (the round-2 path)
+extern "C" int vad_debug_set_dec4_fused(int on) { g_vad_dec4_fused = on; return VAD_OK; }
+
 extern "C" size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent) {
     if (chunk <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16 || latent <= 0 || latent % 32) return 0;
     const size_t act = up256(sizeof(float) * chunk * img_act_floats(h, w, latent));
-    const size_t parts = up256(sizeof(float) * chunk * (size_t)vad_score_partials(0, h, w));
+    const size_t parts = up256(sizeof(float) * chunk * img_partials(h, w));
     return 2 * act + parts;
 }
 
@@ -164,7 +173,7 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
     float* A = (float*)ws;
     float* B = (float*)((char*)ws + act);
     float* parts = (float*)((char*)ws + 2 * act);
-    const int nparts = vad_score_partials(0, h, w);
+    const int nparts_tail = vad_score_partials(0, h, w);
     const bool need_decoder = scores || errmap || recon;
     const int ch[5] = {3, 32, 64, 128, latent};
     const int dch[5] = {latent, 128, 64, 32, 32};
@@ -198,10 +207,19 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
             { VadProfScope ps(9 + 2 * blk, s);
               TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, precision, s)); }
         }
-        // dec4.0 (convT 32->32, writes 8.4 MB per 256x256 frame) and the scoring tail that reads it back can run in
-        // sub-groups (vad_debug_set_tail_group) so that map stays in the 256 MiB Infinity Cache; measured on MI355X
-        // this does NOT pay (15.2 k frames/s whole group vs 14.9 k at 16 frames), so the default is the whole group.
+        // dec4.0 + dec4.3 + score.  Exact fp32: ONE kernel, the 8.4 MB per frame map between the two layers never exists in
+        // memory (dec4_fused.hip).  Split precision (and the A/B switch): two launches, convT 32->32 then the VALU tail; those
+        // can run in sub-groups (vad_debug_set_tail_group) so that the map stays in the 256 MiB Infinity Cache - measured
+        // on MI355X this does NOT pay (15.2 k frames/s whole group vs 14.9 k at 16 frames), so the default is the whole group.
         const size_t in_f = (size_t)hh * ww * 32;
+        int nparts = nparts_tail;
+        if (precision == VAD_PREC_FP32 && g_vad_dec4_fused.load(std::memory_order_relaxed)) {
+            nparts = vad_dec4_score_partials(h, w);
+            VadProfScope ps(18, s);
+            TRY(vad_dec4_score_fmt(B, W_(14), B_(14), W_(15) + 8 * 108, B_(15), xin, x_format, parts,
+                                   recon ? recon + (size_t)f0 * 3 * h * w : nullptr, errmap ? errmap + (size_t)f0 * h * w : nullptr,
+                                   n, hh, ww, s));
+        } else {
         const int tg = g_vad_tail_group.load(std::memory_order_relaxed);
         const int sub = tg > 0 ? tg : n;
         for (int f1 = 0; f1 < n; f1 += sub) {
@@ -213,6 +231,7 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
               TRY(vad_conv3x3_to3_score_fmt(A, W_(15), B_(15), xin + (size_t)f1 * 3 * h * w * xelem, x_format, parts + (size_t)f1 * nparts,
                                         recon ? recon + fo * 3 * h * w : nullptr,
                                         errmap ? errmap + fo * h * w : nullptr, m, h, w, 32, s)); }
+        }
         }
         if (scores) {
             VadProfScope ps(16, s);

@@ -126,6 +126,10 @@ int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float
                                float* partials, float* recon, float* errmap, int n, int h, int w, int cin, int t,
                                int clip_stride, void* stream);
 
+// dec4.0 + dec4.3 + score fused (dec4_fused.hip); w2_gemm = the second form written by vad_pack_conv3x3_to3 (cin 32)
+int vad_dec4_score_fmt(const float* in, const float* wt_packed, const float* bt, const float* w2_gemm, const float* bias3,
+                       const void* x, int fmt, float* partials, float* recon, float* errmap, int n, int h, int w, void* stream);
+
 // per-layer profiling hooks (vad_api.hip)
 struct VadProfScope {
     int slot;

@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
-SOURCES = ["conv_mfma.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
+SOURCES = ["conv_mfma.hip", "dec4_fused.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
 
 VAD_OK = 0
 ABI_VERSION = 2
@@ -150,6 +150,10 @@ SIGNATURES = {
     "vad_vid_score": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_debug_set_conv_variant": (_i, [_i]),
     "vad_debug_set_tail_group": (_i, [_i]),
+    "vad_debug_set_dec4_fused": (_i, [_i]),
+    "vad_debug_set_dec4_band": (_i, [_i]),
+    "vad_dec4_score_partials": (_i, [_i, _i]),
+    "vad_dec4_score": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "vad_debug_set_lstm_wavefront": (_i, [_i]),
     "vad_img_score_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_score_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
