@@ -299,6 +299,12 @@ int vad_synth_frames(float* out_nchw, unsigned long long seed, long long first_f
  * (models/autoencoder.py:181-221) as driven by evaluate.compute_auroc (evaluate.py:56-64).
  * params: VAD_IMG_NPARAMS host pointers in state_dict order with num_batches_tracked removed. */
 #define VAD_IMG_NPARAMS 92
+/* latent_dim / lstm_hidden_dim: ANY value in [1, VAD_MAX_WIDTH], as the reference's constructors take
+ * (models/autoencoder.py:161, models/video_autoencoder.py:290-296; train_video.py:304-326 exposes them as flags).  The
+ * kernels tile channels by 32 (64 hidden channels per ConvLSTM block); the packers zero-pad other widths (zero weights and
+ * bias in, zero weights out: a padded channel stays exactly 0 through every layer, results are those of the unpadded
+ * network).  Every entry point takes the REAL dimensions. */
+#define VAD_MAX_WIDTH 4096
 /* The packed blob starts with a 16-byte header {magic "VADB", tag = abi<<16 | precision<<8 | model kind, dims}; the
  * layers follow.  Pack with the precision the blob will be launched with: the kernel that finalises the scores compares
  * the tag with the launch's `precision` on the device and returns NaN scores on a mismatch (never a silent wrong number).

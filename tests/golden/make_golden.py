@@ -62,10 +62,10 @@ def _save(name: str, **arrays):
     print(f"{name}: {path.stat().st_size / 1024:.0f} KiB")
 
 
-def image_fixture(name, latent, wseed, xseed, n, hw, intermediates=False, subsample=None):
+def image_fixture(name, latent, wseed, xseed, n, hw, intermediates=False, subsample=None, in_ch=3):
     torch.manual_seed(0)
-    model = _load_synth(ref_ae.ConvAutoencoder(in_channels=3, latent_dim=latent), wseed)
-    x = torch.from_numpy(synth.frames(xseed, 0, n, 3, hw, hw))
+    model = _load_synth(ref_ae.ConvAutoencoder(in_channels=in_ch, latent_dim=latent), wseed)
+    x = torch.from_numpy(synth.frames(xseed, 0, n, in_ch, hw, hw))
     out = {}
     hooks = []
     if intermediates:
@@ -89,15 +89,15 @@ def image_fixture(name, latent, wseed, xseed, n, hw, intermediates=False, subsam
         out["errmap"] = emap.numpy()
     out["latent"] = latent_t.numpy()
     out["scores"] = scores.numpy()
-    _save(name, latent_dim=np.array(latent), wseed=np.array(wseed), xseed=np.array(xseed), n=np.array(n),
-          hw=np.array(hw), **_contract(model), **out)
+    _save(name, latent_dim=np.array(latent), in_channels=np.array(in_ch), wseed=np.array(wseed), xseed=np.array(xseed),
+          n=np.array(n), hw=np.array(hw), **_contract(model), **out)
 
 
-def video_fixture(name, latent, hid, layers, wseed, xseed, b, t, hw):
+def video_fixture(name, latent, hid, layers, wseed, xseed, b, t, hw, in_ch=3):
     torch.manual_seed(0)
-    model = _load_synth(ref_vae.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid,
+    model = _load_synth(ref_vae.VideoAutoencoder(in_channels=in_ch, latent_dim=latent, lstm_hidden_dim=hid,
                                                  lstm_num_layers=layers), wseed)
-    x = torch.from_numpy(synth.clips(xseed, 0, b, t, 3, hw, hw))
+    x = torch.from_numpy(synth.clips(xseed, 0, b, t, in_ch, hw, hw))
     with torch.no_grad():
         recon = model(x)
         seq = model.get_reconstruction_error(x)
@@ -105,8 +105,8 @@ def video_fixture(name, latent, hid, layers, wseed, xseed, b, t, hw):
         emap = model.get_reconstruction_error(x, per_pixel=True)
         both = model.get_reconstruction_error(x, per_frame=True, per_pixel=True)
     assert both.shape == emap.shape   # per_pixel wins when both flags are set
-    _save(name, latent_dim=np.array(latent), hid=np.array(hid), layers=np.array(layers), wseed=np.array(wseed),
-          xseed=np.array(xseed), b=np.array(b), t=np.array(t), hw=np.array(hw), **_contract(model),
+    _save(name, latent_dim=np.array(latent), hid=np.array(hid), layers=np.array(layers), in_channels=np.array(in_ch),
+          wseed=np.array(wseed), xseed=np.array(xseed), b=np.array(b), t=np.array(t), hw=np.array(hw), **_contract(model),
           recon=recon.numpy(), seq=seq.numpy(), frame=frame.numpy(), errmap=emap.numpy())
 
 
@@ -320,6 +320,13 @@ FIXTURES = {
     "img_l32_32.npz": lambda n: image_fixture(n, latent=32, wseed=11, xseed=101, n=3, hw=32, intermediates=True),
     "img_l256_64.npz": lambda n: image_fixture(n, latent=256, wseed=12, xseed=102, n=2, hw=64),
     "img_l256_256.npz": lambda n: image_fixture(n, latent=256, wseed=13, xseed=103, n=1, hw=256, subsample=8),
+    # constructor arguments the kernels' channel tiling does not divide (zero-padded by the packers) and fewer than 3 planes:
+    # the reference takes any positive width (models/autoencoder.py:161, models/video_autoencoder.py:290-296)
+    "img_l100_32.npz": lambda n: image_fixture(n, latent=100, wseed=14, xseed=104, n=2, hw=32),
+    "img_c1_l24_32.npz": lambda n: image_fixture(n, latent=24, wseed=15, xseed=105, n=2, hw=32, in_ch=1),
+    "vid_l48_h96_32.npz": lambda n: video_fixture(n, latent=48, hid=96, layers=2, wseed=25, xseed=205, b=2, t=3, hw=32),
+    "vid_l100_32.npz": lambda n: video_fixture(n, latent=100, hid=100, layers=1, wseed=26, xseed=206, b=1, t=3, hw=32),
+    "vid_c2_l32_h40_32.npz": lambda n: video_fixture(n, latent=32, hid=40, layers=1, wseed=27, xseed=207, b=1, t=2, hw=32, in_ch=2),
     "vid_default_64.npz": lambda n: video_fixture(n, latent=128, hid=128, layers=2, wseed=21, xseed=201, b=2, t=3, hw=64),
     "vid_proj_32.npz": lambda n: video_fixture(n, latent=32, hid=64, layers=1, wseed=22, xseed=202, b=1, t=4, hw=32),
     "vid_l3_32.npz": lambda n: video_fixture(n, latent=64, hid=64, layers=3, wseed=23, xseed=203, b=2, t=2, hw=32),

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, load_synthetic, rel_err
+from conftest import IMG_GOLDENS, REPO, VID_GOLDENS, in_channels_of, load_synthetic, rel_err
 
 
 def test_import_surface_matches_reference():
@@ -24,14 +24,49 @@ def test_import_surface_matches_reference():
     assert utils.SSIMLoss and utils.CombinedLoss
 
 
+def test_option_a_layout_imports(tmp_path):
+    """INTEGRATION.md option A: the reference's tree with `models/` replaced, `utils/losses.py` replaced and the reference's
+    own `utils/__init__.py` / `dataset.py` / `download_data.py` kept.  The kept files are stood in for by stubs written
+    here (the reference never travels): an `__init__.py` with the reference's three import lines (utils/__init__.py:5-7)
+    and modules defining the names it imports.  The scripts' import lines (evaluate.py:22-23, train.py:23-24,
+    evaluate_video.py:25) must resolve, in this layout and with this repository's own `utils/__init__.py` instead."""
+    import shutil
+    import subprocess
+    import sys
+    for own_init in (False, True):
+        root = tmp_path / ("own" if own_init else "kept")
+        (root / "utils").mkdir(parents=True)
+        shutil.copytree(REPO / "models", root / "models")
+        (root / "video-anomaly-detection_amd").symlink_to(REPO / "video-anomaly-detection_amd")
+        shutil.copy(REPO / "utils" / "losses.py", root / "utils" / "losses.py")
+        (root / "utils" / "dataset.py").write_text("class MVTecDataset:\n    pass\n\ndef get_dataloaders(*a, **k):\n    return None\n")
+        (root / "utils" / "download_data.py").write_text(
+            "def create_synthetic_test_data(*a, **k):\n    return None\n\ndef download_with_kagglehub(*a, **k):\n    return None\n")
+        if own_init:
+            shutil.copy(REPO / "utils" / "__init__.py", root / "utils" / "__init__.py")
+        else:
+            (root / "utils" / "__init__.py").write_text(
+                "from .dataset import MVTecDataset, get_dataloaders\n"
+                "from .download_data import create_synthetic_test_data, download_with_kagglehub\n"
+                "from .losses import SSIMLoss, CombinedLoss\n")
+        code = ("from models import ConvAutoencoder\nfrom utils import MVTecDataset, CombinedLoss\n"
+                "from utils import SSIMLoss, get_dataloaders, create_synthetic_test_data\n"
+                "from models.video_autoencoder import VideoAutoencoder\nimport utils.losses\n"
+                "assert ConvAutoencoder.__module__.startswith('video-anomaly-detection_amd')\n"
+                "assert CombinedLoss.__module__.startswith('video-anomaly-detection_amd')\nprint('ok')\n")
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                           env={"PATH": "/usr/bin:/bin", "PYTHONPATH": str(root)})
+        assert r.returncode == 0 and r.stdout.strip() == "ok", (own_init, r.stderr[-2000:])
+
+
 def test_state_dict_contract_image(vad, golden):
     g = golden("init.npz")
     m = vad.ConvAutoencoder()
     assert list(m.state_dict().keys()) == list(g["img_keys"])
     assert sum(p.numel() for p in m.parameters()) == int(g["img_nparams"]) == 1_546_147
-    for name in ("img_l32_32.npz", "img_l256_64.npz"):
+    for name in IMG_GOLDENS:
         f = golden(name)
-        mm = vad.ConvAutoencoder(in_channels=3, latent_dim=int(f["latent_dim"]))
+        mm = vad.ConvAutoencoder(in_channels=in_channels_of(f), latent_dim=int(f["latent_dim"]))
         sd = mm.state_dict()
         assert list(sd.keys()) == list(f["keys"])
         assert [",".join(map(str, v.shape)) for v in sd.values()] == list(f["shapes"])
@@ -43,9 +78,9 @@ def test_state_dict_contract_video(vad, golden):
     m = vad.VideoAutoencoder()
     assert list(m.state_dict().keys()) == list(g["vid_keys"])
     assert sum(p.numel() for p in m.parameters()) == int(g["vid_nparams"]) == 2_709_411
-    for name in ("vid_default_64.npz", "vid_proj_32.npz", "vid_l3_32.npz"):
+    for name in VID_GOLDENS:
         f = golden(name)
-        mm = vad.VideoAutoencoder(in_channels=3, latent_dim=int(f["latent_dim"]), lstm_hidden_dim=int(f["hid"]),
+        mm = vad.VideoAutoencoder(in_channels=in_channels_of(f), latent_dim=int(f["latent_dim"]), lstm_hidden_dim=int(f["hid"]),
                                   lstm_num_layers=int(f["layers"]))
         sd = mm.state_dict()
         assert list(sd.keys()) == list(f["keys"])
@@ -123,14 +158,49 @@ def test_library_exports_every_declared_symbol(vad):
 def test_argument_errors_without_gpu(vad):
     lib = vad.hip.lib()
     assert lib.vad_img_packed_floats(3, 256) > 1_500_000
-    assert lib.vad_img_packed_floats(1, 256) == 0 and lib.vad_img_packed_floats(3, 100) == 0
+    assert lib.vad_img_packed_floats(1, 256) == 0          # the C ABI is 3-plane; the modules widen 1- / 2-channel models
+    # any positive width is taken (models/autoencoder.py:161): slots are zero-padded to the kernels' channel tiling
+    assert lib.vad_img_packed_floats(3, 100) == lib.vad_img_packed_floats(3, 128) > lib.vad_img_packed_floats(3, 96)
+    assert lib.vad_img_packed_floats(3, 0) == 0 and lib.vad_img_packed_floats(3, vad.hip.MAX_WIDTH + 1) == 0
     assert lib.vad_vid_packed_floats(128, 128, 2) > 2_600_000
-    assert lib.vad_vid_packed_floats(128, 100, 2) == 0
+    assert lib.vad_vid_packed_floats(128, 100, 2) == lib.vad_vid_packed_floats(128, 128, 2) + lib.vad_pack_conv1x1_floats(128, 128) + 128
+    assert lib.vad_vid_packed_floats(100, 100, 2) == lib.vad_vid_packed_floats(128, 128, 2)      # no proj: one common width
+    assert lib.vad_vid_packed_floats(128, 0, 2) == 0 and lib.vad_vid_packed_floats(128, 128, 9) == 0
     assert lib.vad_img_workspace_bytes(16, 250, 256, 256) == 0
     assert lib.vad_img_workspace_bytes(16, 256, 256, 256) >= 2 * 16 * 256 * 256 * 32 * 4
     assert lib.vad_vid_nparams(2, 0) == 48 and lib.vad_vid_nparams(1, 1) == 48
     assert lib.vad_score_partials(0, 256, 256) == 64 and lib.vad_score_partials(1, 256, 256) == 256   # 32x32 tiles; 128 rows x 2 segments
     assert lib.vad_score_partials(7, 256, 256) < 0 and b"kind" in lib.vad_last_error()
+
+
+def test_odd_widths_are_zero_padded_by_the_packer(vad):
+    """latent_dim 40 (image): the blob equals the blob of the latent-64 model whose extra channels have zero weights, zero
+    bias and identity-free BatchNorm (scale 0) - i.e. padding happens in the packer and nowhere else."""
+    lib = vad.hip.lib()
+    m = vad.ConvAutoencoder(latent_dim=40)
+    st = load_synthetic(vad, m, 5)
+    big = vad.ConvAutoencoder(latent_dim=64)
+    sd = {k: torch.zeros_like(v) for k, v in big.state_dict().items()}
+    for k, v in st.items():
+        t = torch.from_numpy(np.asarray(v))
+        if t.dim() == 0:
+            sd[k] = t
+            continue
+        sd[k][tuple(slice(0, d) for d in t.shape)] = t
+        if k.endswith("running_var"):
+            sd[k][t.shape[0]:] = 1.0
+    big.load_state_dict(sd)
+
+    def blob(model, latent):
+        params = [np.ascontiguousarray(v.detach().numpy(), dtype=np.float32) for k, v in model.state_dict().items()
+                  if not k.endswith("num_batches_tracked")]
+        out = np.empty(lib.vad_img_packed_floats(3, latent), np.float32)
+        vad.hip.check(lib.vad_img_pack(vad.hip.pointer_array(params), len(params), 3, latent, 0, out.ctypes.data), "pack")
+        return out
+    a, b = blob(m, 40), blob(big, 64)
+    assert a.shape == b.shape
+    assert np.array_equal(a[4:].view(np.uint32), b[4:].view(np.uint32))        # header word 2 holds the real latent_dim
+    assert a[:4].view(np.uint32)[2] == 40 and b[:4].view(np.uint32)[2] == 64
 
 
 def test_bn_folding_and_packing_layout(vad):

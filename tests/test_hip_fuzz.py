@@ -16,10 +16,10 @@ def _state(st):
     return {k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(14))
 def test_image_random_configuration(vad, seed):
     rng = np.random.default_rng(1000 + seed)
-    latent = int(rng.choice([32, 64, 96, 128, 256]))
+    latent = int(rng.choice([32, 64, 96, 128, 256, 24, 48, 100]))      # any positive width (models/autoencoder.py:161)
     h, w = (int(16 * rng.integers(1, 9)) for _ in range(2))
     b = int(rng.integers(1, 12))
     chunk = int(rng.integers(1, 9))
@@ -44,17 +44,15 @@ def test_image_random_configuration(vad, seed):
     assert torch.equal(from_u8, as_f32), tag                             # uint8 ingest == the same frames as fp32
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(14))
 def test_video_random_configuration(vad, seed):
     rng = np.random.default_rng(5000 + seed)
-    latent = int(rng.choice([32, 64, 128]))
-    hid = int(rng.choice([64, 128])) if seed % 2 else latent
-    if hid % 64:
-        hid = 64
+    latent = int(rng.choice([32, 64, 128, 24, 48, 100]))               # any positive widths (models/video_autoencoder.py:290-296)
+    hid = int(rng.choice([64, 128, 32, 96])) if seed % 2 else latent
     layers = int(rng.integers(1, 4))
     h, w = (int(16 * rng.integers(1, 6)) for _ in range(2))
     b, t = int(rng.integers(1, 5)), int(rng.integers(1, 7))
-    precision = "split" if (seed % 3 == 2 and hid == latent) else "fp32"
+    precision = "split" if (seed % 3 == 2 and hid == latent) else "fp32"     # split ConvLSTM step: x and h halves of equal width
     m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid, lstm_num_layers=layers)
     st = load_synthetic(vad, m, 700 + seed)
     m = m.cuda().eval()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import auroc_slack, load_synthetic, max_abs, rel_err
+from conftest import IMG_GOLDENS, VID_GOLDENS, auroc_slack, in_channels_of, load_synthetic, max_abs, rel_err
 from oracle import torch_oracle
 
 pytestmark = pytest.mark.gpu
@@ -16,23 +16,26 @@ SCORE_RTOL = 1e-5
 ACT_ATOL = 5e-5
 
 
-def _img_model(vad, latent, wseed):
-    m = vad.ConvAutoencoder(in_channels=3, latent_dim=latent)
+def _img_model(vad, latent, wseed, in_ch=3):
+    m = vad.ConvAutoencoder(in_channels=in_ch, latent_dim=latent)
     st = load_synthetic(vad, m, wseed)
     return m.cuda().eval(), st
 
 
-def _vid_model(vad, latent, hid, layers, wseed):
-    m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid, lstm_num_layers=layers)
+def _vid_model(vad, latent, hid, layers, wseed, in_ch=3):
+    m = vad.VideoAutoencoder(in_channels=in_ch, latent_dim=latent, lstm_hidden_dim=hid, lstm_num_layers=layers)
     st = load_synthetic(vad, m, wseed)
     return m.cuda().eval(), st
 
 
-@pytest.mark.parametrize("name", ["img_l32_32.npz", "img_l256_64.npz"])
+@pytest.mark.parametrize("name", IMG_GOLDENS)
 def test_image_matches_reference_golden(vad, golden, name):
+    """The reference's own outputs, including a latent_dim the channel tiling does not divide (100: zero-padded by the
+    packer) and a 1-channel model (models/autoencoder.py:161 takes any in_channels / latent_dim)."""
     g = golden(name)
-    m, _ = _img_model(vad, int(g["latent_dim"]), int(g["wseed"]))
-    x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), 3, int(g["hw"]), int(g["hw"]))).cuda()
+    cin = in_channels_of(g)
+    m, _ = _img_model(vad, int(g["latent_dim"]), int(g["wseed"]), cin)
+    x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), cin, int(g["hw"]), int(g["hw"]))).cuda()
     before = vad.hip.calls["img_score"]
     with torch.no_grad():
         recon = m(x)
@@ -42,6 +45,7 @@ def test_image_matches_reference_golden(vad, golden, name):
         allo = m.score_all(x)
     assert vad.hip.calls["img_score"] == before + 5          # the native path really ran
     assert recon.shape == x.shape and emap.shape == (x.shape[0], 1, *x.shape[2:]) and scores.shape == (x.shape[0],)
+    assert lat.shape == g["latent"].shape
     assert rel_err(scores.cpu().numpy(), g["scores"]) < SCORE_RTOL
     assert max_abs(recon.cpu().numpy(), g["recon"]) < ACT_ATOL
     assert max_abs(emap.cpu().numpy(), g["errmap"]) < ACT_ATOL
@@ -128,11 +132,14 @@ def test_inference_requires_gpu_tensor_and_train_mode_uses_autograd(vad):
     assert m.encoder.enc1[0].weight.grad is not None
 
 
-@pytest.mark.parametrize("name", ["vid_default_64.npz", "vid_proj_32.npz", "vid_l3_32.npz"])
+@pytest.mark.parametrize("name", VID_GOLDENS)
 def test_video_matches_reference_golden(vad, golden, name):
+    """The reference's own outputs for the default model, `proj` variants, three ConvLSTM layers, widths the channel
+    tiling does not divide (latent 48 / hidden 96 with proj; latent = hidden = 100 without) and a 2-channel model."""
     g = golden(name)
-    m, _ = _vid_model(vad, int(g["latent_dim"]), int(g["hid"]), int(g["layers"]), int(g["wseed"]))
-    x = torch.from_numpy(vad.synth.clips(int(g["xseed"]), 0, int(g["b"]), int(g["t"]), 3, int(g["hw"]), int(g["hw"]))).cuda()
+    cin = in_channels_of(g)
+    m, _ = _vid_model(vad, int(g["latent_dim"]), int(g["hid"]), int(g["layers"]), int(g["wseed"]), cin)
+    x = torch.from_numpy(vad.synth.clips(int(g["xseed"]), 0, int(g["b"]), int(g["t"]), cin, int(g["hw"]), int(g["hw"]))).cuda()
     before = vad.hip.calls["vid_score"]
     with torch.no_grad():
         recon = m(x)

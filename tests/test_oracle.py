@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import max_abs, rel_err
+from conftest import IMG_GOLDENS, VID_GOLDENS, in_channels_of, max_abs, rel_err
 from oracle import c_oracle, torch_oracle
 
 SCORE_RTOL = 2e-6     # fp32 summation-order noise only (the reference is fp32 oneDNN)
@@ -20,13 +20,18 @@ def _tstate(st):
     return {k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}
 
 
-@pytest.mark.parametrize("name", ["img_l32_32.npz", "img_l256_64.npz"])
+@pytest.mark.parametrize("name", IMG_GOLDENS)
 def test_image_oracles_match_reference(vad, golden, name):
     g = golden(name)
     st = _state(vad, g, "img")
-    x = vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), 3, int(g["hw"]), int(g["hw"]))
-    for label, out in (("c", c_oracle.img_scores(st, int(g["latent_dim"]), x)),
-                       ("torch", {k: v.numpy() for k, v in torch_oracle.img_scores(_tstate(st), torch.from_numpy(x)).items()})):
+    cin = in_channels_of(g)
+    x = vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), cin, int(g["hw"]), int(g["hw"]))
+    outs = [("torch", {k: v.numpy() for k, v in torch_oracle.img_scores(_tstate(st), torch.from_numpy(x)).items()})]
+    if cin != 3:          # the C restatement is written for the 3-plane models every reference call site builds
+        for label, out in outs:
+            assert rel_err(out["scores"], g["scores"]) < SCORE_RTOL and max_abs(out["recon"], g["recon"]) < ACT_ATOL, label
+        return
+    for label, out in [("c", c_oracle.img_scores(st, int(g["latent_dim"]), x))] + outs:
         assert rel_err(out["scores"], g["scores"]) < SCORE_RTOL, label
         assert max_abs(out["recon"], g["recon"]) < ACT_ATOL, label
         assert max_abs(out["errmap"], g["errmap"]) < ACT_ATOL, label
@@ -52,14 +57,15 @@ def test_image_intermediates(vad, golden):
     assert max_abs(g["latent"], g["act.encoder.enc4"]) == 0.0
 
 
-@pytest.mark.parametrize("name", ["vid_default_64.npz", "vid_proj_32.npz", "vid_l3_32.npz"])
+@pytest.mark.parametrize("name", VID_GOLDENS)
 def test_video_oracles_match_reference(vad, golden, name):
     g = golden(name)
     st = _state(vad, g, "vid")
     lat, hid, layers = int(g["latent_dim"]), int(g["hid"]), int(g["layers"])
-    x = vad.synth.clips(int(g["xseed"]), 0, int(g["b"]), int(g["t"]), 3, int(g["hw"]), int(g["hw"]))
+    cin = in_channels_of(g)
+    x = vad.synth.clips(int(g["xseed"]), 0, int(g["b"]), int(g["t"]), cin, int(g["hw"]), int(g["hw"]))
     outs = [("torch", {k: v.numpy() for k, v in torch_oracle.vid_scores(_tstate(st), torch.from_numpy(x), hid, layers).items()})]
-    if int(g["hw"]) <= 32 or name == "vid_default_64.npz":
+    if cin == 3 and (int(g["hw"]) <= 32 or name == "vid_default_64.npz"):
         outs.append(("c", c_oracle.vid_scores(st, lat, hid, layers, x)))
     for label, out in outs:
         assert rel_err(out["seq"], g["seq"]) < SCORE_RTOL, label

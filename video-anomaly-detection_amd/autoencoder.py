@@ -108,6 +108,41 @@ class _HipScorer:
             out.append(np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy()))
         return out
 
+    @staticmethod
+    def widen_to_rgb(params: list, in_channels: int, last_transposed: bool) -> list:
+        """The kernels read and reconstruct 3 planes (every reference call site passes in_channels=3, evaluate.py:35,
+        evaluate_video.py:99).  A model built with 1 or 2 input channels is scored as the 3-channel model whose extra
+        input taps and extra output channels are zero: first conv weight (32,C,3,3) -> (32,3,3,3), last layer (Conv2d
+        weight (C,32,3,3) or ConvTranspose2d weight (32,C,2,2), bias (C)) -> 3 outputs.  The extra planes reconstruct
+        tanh(0) = 0 against a zero input plane, so they add nothing to the squared error (the callers rescale the mean)."""
+        if in_channels == 3:
+            return params
+        params = list(params)
+        w0 = params[0]
+        params[0] = np.ascontiguousarray(np.concatenate([w0, np.zeros((w0.shape[0], 3 - in_channels, 3, 3), np.float32)], axis=1))
+        wl, bl = params[-2], params[-1]
+        if last_transposed:
+            wl = np.concatenate([wl, np.zeros((wl.shape[0], 3 - in_channels) + wl.shape[2:], np.float32)], axis=1)
+        else:
+            wl = np.concatenate([wl, np.zeros((3 - in_channels,) + wl.shape[1:], np.float32)], axis=0)
+        params[-2] = np.ascontiguousarray(wl)
+        params[-1] = np.ascontiguousarray(np.concatenate([bl, np.zeros(3 - in_channels, np.float32)]))
+        return params
+
+    @staticmethod
+    def widen_input(x: torch.Tensor, in_channels: int, u8: bool) -> torch.Tensor:
+        """Zero planes appended to a 1- or 2-channel input (channel axis: last for uint8 NHWC, -3 for float NCHW)."""
+        if in_channels == 3:
+            return x
+        shape = list(x.shape)
+        axis = x.dim() - 1 if u8 else x.dim() - 3
+        shape[axis] = 3 - in_channels
+        # uint8 frames are normalised as (u/255 - 0.5)/0.5 inside the kernels: the byte that maps closest to 0 does not
+        # map to 0 exactly, so raw-byte input is offered for 3-channel models only
+        if u8:
+            raise hip.VadError("uint8 input needs in_channels == 3")
+        return torch.cat([x, x.new_zeros(shape)], dim=axis)
+
     def workspace(self, nbytes: int, device) -> torch.Tensor:
         if self.ws is None or self.ws.numel() < nbytes or self.ws.device != device:
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -145,14 +180,14 @@ class ConvAutoencoder(nn.Module):
             raise hip.VadError("precision 'bf16' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32' or 'split'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
-            n = l.vad_img_packed_floats(self.in_channels, self.latent_dim)
+            n = l.vad_img_packed_floats(3, self.latent_dim) if 1 <= self.in_channels <= 3 else 0
             if n == 0:
                 raise hip.VadError(
                     f"ConvAutoencoder(in_channels={self.in_channels}, latent_dim={self.latent_dim}) is not "
-                    "supported by the HIP path (needs in_channels == 3 and latent_dim % 32 == 0)")
-            params = _HipScorer.float_params(self)
+                    f"supported by the HIP path (needs 1 <= in_channels <= 3 and 1 <= latent_dim <= {hip.MAX_WIDTH})")
+            params = _HipScorer.widen_to_rgb(_HipScorer.float_params(self), self.in_channels, last_transposed=False)
             blob = np.empty(n, dtype=np.float32)
-            hip.check(l.vad_img_pack(hip.pointer_array(params), len(params), self.in_channels,
+            hip.check(l.vad_img_pack(hip.pointer_array(params), len(params), 3,
                                      self.latent_dim, mode, blob.ctypes.data), "vad_img_pack")
             self._hip.packed = torch.from_numpy(blob).to(device)
             self._hip.key = key
@@ -187,8 +222,9 @@ class ConvAutoencoder(nn.Module):
 
     def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False, out=None):
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,H,W,3]: normalised inside the kernels (row f-3)
-        if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != 3:
-            raise hip.VadError(f"expected float input [B,3,H,W] or uint8 input [B,H,W,3], got {x.dtype} {tuple(x.shape)}")
+        cin = self.in_channels
+        if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != cin:
+            raise hip.VadError(f"expected float input [B,{cin},H,W] or uint8 input [B,H,W,{cin}], got {x.dtype} {tuple(x.shape)}")
         if not x.is_cuda:
             raise hip.VadError(
                 "ConvAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
@@ -202,6 +238,7 @@ class ConvAutoencoder(nn.Module):
         l = hip.lib()
         dev = x.device
         packed = self._packed(dev)
+        x = _HipScorer.widen_input(x, cin, u8)
         chunk = max(1, min(int(self.chunk), b))
         nbytes = l.vad_img_workspace_bytes(chunk, h, w, self.latent_dim)
         if nbytes == 0:
@@ -226,6 +263,13 @@ class ConvAutoencoder(nn.Module):
                                         hip.ptr(out.get("recon")), hip.ptr(out.get("latent")), hip.current_stream()),
                       "vad_img_score")
         hip.calls["img_score"] += 1
+        if cin != 3:          # the kernels averaged over 3 planes of which 3 - cin are exactly zero
+            out = dict(out)
+            for k in ("scores", "errmap"):
+                if k in out:
+                    out[k] = out[k] * (3.0 / cin)
+            if "recon" in out:
+                out["recon"] = out["recon"][:, :cin].contiguous()
         return out
 
     # ------------------------------------------------------------------ reference API

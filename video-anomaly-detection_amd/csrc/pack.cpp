@@ -174,6 +174,58 @@ extern "C" int vad_pack_conv3x3_to3(const float* w, int cin, float* out) {
     return VAD_OK;
 }
 
+// --------------------------------------------------------------------------- zero-padded channel dimensions
+// (vad_layout.h: why padding is exact.)  A torch-layout copy of one layer's parameters with its channel dimensions
+// zero-padded; `co_at(co)` / `ci_at(ci)` give the padded position of a real channel (the ConvLSTM cell pads each of its
+// four gate blocks and its x / h input halves separately).  Padded BatchNorm channels get gamma = beta = mean = 0,
+// var = 1: scale 0, shift 0.
+namespace {
+struct PaddedLayer {
+    std::vector<float> w, bias, bnv[4];
+    const float* bn[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+template <class CoAt, class CiAt>
+void pad_layer(const float* w, const float* bias, const float* const* bn, int cout, int cin, int kk, bool transposed,
+               int cout_p, int cin_p, CoAt co_at, CiAt ci_at, PaddedLayer& o) {
+    o.w.assign((size_t)cout_p * cin_p * kk, 0.f);
+    o.bias.assign(cout_p, 0.f);
+    for (int co = 0; co < cout; ++co) {
+        const int cop = co_at(co);
+        if (bias) o.bias[cop] = bias[co];
+        for (int ci = 0; ci < cin; ++ci) {
+            const int cip = ci_at(ci);
+            const float* src = transposed ? w + ((size_t)ci * cout + co) * kk : w + ((size_t)co * cin + ci) * kk;
+            float* dst = transposed ? o.w.data() + ((size_t)cip * cout_p + cop) * kk : o.w.data() + ((size_t)cop * cin_p + cip) * kk;
+            for (int k = 0; k < kk; ++k) dst[k] = src[k];
+        }
+    }
+    if (bn) {
+        for (int i = 0; i < 4; ++i) {
+            o.bnv[i].assign(cout_p, i == 3 ? 1.f : 0.f);
+            for (int co = 0; co < cout; ++co) o.bnv[i][co_at(co)] = bn[i][co];
+            o.bn[i] = o.bnv[i].data();
+        }
+    }
+}
+const auto same = [](int c) { return c; };
+}  // namespace
+
+// conv3x3 / convT / conv1x1 whose real widths (cout, cin) sit in slots of (s.cout, s.cin) channels
+static int pack_conv3x3_slot(const float* w, const float* b, const float* const* bn, int cout, int cin, const LayerSlot& s,
+                             int precision, float* out) {
+    if (cout == s.cout && cin == s.cin) return vad_pack_conv3x3(w, b, bn, cout, cin, precision, out + s.w, out + s.b);
+    PaddedLayer P;
+    pad_layer(w, b, bn, cout, cin, 9, false, s.cout, s.cin, same, same, P);
+    return vad_pack_conv3x3(P.w.data(), P.bias.data(), bn ? P.bn : nullptr, s.cout, s.cin, precision, out + s.w, out + s.b);
+}
+static int pack_convt2x2_slot(const float* w, const float* b, const float* const* bn, int cin, int cout, const LayerSlot& s,
+                              int precision, float* out) {
+    if (cout == s.cout && cin == s.cin) return vad_pack_convt2x2(w, b, bn, cin, cout, precision, out + s.w, out + s.b);
+    PaddedLayer P;
+    pad_layer(w, b, bn, cout, cin, 4, true, s.cout, s.cin, same, same, P);
+    return vad_pack_convt2x2(P.w.data(), P.bias.data(), bn ? P.bn : nullptr, s.cin, s.cout, precision, out + s.w, out + s.b);
+}
+
 // --------------------------------------------------------------------------- image autoencoder
 static size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
 
@@ -194,8 +246,9 @@ extern "C" int vad_blob_precision(const float* packed_host) {
     return (int)((h[1] >> 8) & 0xff);
 }
 
-ImgLayout img_layout(int latent) {
+ImgLayout img_layout(int latent_real) {
     ImgLayout L{};
+    const int latent = L.latent_p = vad_img_latent_p(latent_real);
     const int ch[5] = {3, 32, 64, 128, latent};
     size_t off = VAD_BLOB_HEADER_FLOATS;
     int li = 0;
@@ -222,7 +275,7 @@ ImgLayout img_layout(int latent) {
 }
 
 extern "C" size_t vad_img_packed_floats(int in_ch, int latent) {
-    if (in_ch != 3 || latent <= 0 || latent % 32) return 0;
+    if (in_ch != 3 || latent <= 0 || latent > VAD_MAX_WIDTH) return 0;
     return img_layout(latent).total;
 }
 
@@ -230,7 +283,7 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
     REQ(P && out, "img_pack: null pointer");
     REQ_PREC("img_pack");
     REQ(in_ch == 3, "img_pack: in_channels=%d unsupported (every reference call site uses 3)", in_ch);
-    REQ(latent > 0 && latent % 32 == 0, "img_pack: latent_dim=%d must be a positive multiple of 32", latent);
+    REQ(latent > 0 && latent <= VAD_MAX_WIDTH, "img_pack: latent_dim=%d out of range [1,%d]", latent, VAD_MAX_WIDTH);
     REQ(nparams == VAD_IMG_NPARAMS, "img_pack: expected %d parameter tensors, got %d", VAD_IMG_NPARAMS, nparams);
     for (int i = 0; i < nparams; ++i) REQ(P[i], "img_pack: parameter %d is NULL", i);
     const ImgLayout L = img_layout(latent);
@@ -247,9 +300,12 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
             continue;
         }
         const float* bn[4] = {P[pi + 2], P[pi + 3], P[pi + 4], P[pi + 5]};
+        // real widths of this layer: only enc4.0 (cout), enc4.3 (both) and dec1.0 (cin) carry latent_dim
+        const int cin = s.cin == L.latent_p && (li == 7 || li == 8) ? latent : s.cin;
+        const int cout = s.cout == L.latent_p && (li == 6 || li == 7) ? latent : s.cout;
         if (s.kind == LK_CONV_C3) rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b);
-        else if (s.kind == LK_CONV) rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, precision, out + s.w, out + s.b);
-        else rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, precision, out + s.w, out + s.b);
+        else if (s.kind == LK_CONV) rc = pack_conv3x3_slot(w, b, bn, cout, cin, s, precision, out);
+        else rc = pack_convt2x2_slot(w, b, bn, cin, cout, s, precision, out);
         pi += 6;
     }
     if (rc == VAD_OK && pi != nparams) return vad_fail(VAD_ERR_ARG, "img_pack: consumed %d of %d parameters", pi, nparams);
@@ -257,8 +313,10 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
 }
 
 // --------------------------------------------------------------------------- video autoencoder
-VidLayout vid_layout(int latent, int hid, int layers) {
+VidLayout vid_layout(int latent_real, int hid_real, int layers) {
     VidLayout L{};
+    const int latent = L.latent_p = vad_vid_latent_p(latent_real, hid_real);
+    const int hid = L.hid_p = vad_vid_hid_p(latent_real, hid_real);
     size_t off = VAD_BLOB_HEADER_FLOATS;
     int li = 0;
     auto add = [&](int kind, int cin, int cout, size_t wfloats) {
@@ -276,7 +334,7 @@ VidLayout vid_layout(int latent, int hid, int layers) {
         const int cin = (l == 0 ? latent : hid) + hid;
         add(LK_LSTM, cin, 4 * hid, vad_pack_conv3x3_floats(4 * hid, cin));
     }
-    L.has_proj = hid != latent;          // models/video_autoencoder.py:311-312
+    L.has_proj = hid_real != latent_real;          // models/video_autoencoder.py:311-312
     if (L.has_proj) add(LK_PROJ, hid, latent, vad_pack_conv1x1_floats(latent, hid));
     const int dch[4] = {latent, 128, 64, 32};
     for (int b = 0; b < 3; ++b) add(LK_CONVT, dch[b], dch[b + 1], vad_pack_convt2x2_floats(dch[b], dch[b + 1]));
@@ -289,8 +347,8 @@ VidLayout vid_layout(int latent, int hid, int layers) {
 extern "C" int vad_vid_nparams(int layers, int has_proj) { return 24 + 2 * layers + (has_proj ? 2 : 0) + 18 + 2; }
 
 static int vid_dims_ok(int latent, int hid, int layers) {
-    REQ(latent > 0 && latent % 32 == 0, "vid: latent_dim=%d must be a positive multiple of 32", latent);
-    REQ(hid > 0 && hid % 64 == 0, "vid: lstm_hidden_dim=%d must be a positive multiple of 64", hid);
+    REQ(latent > 0 && latent <= VAD_MAX_WIDTH, "vid: latent_dim=%d out of range [1,%d]", latent, VAD_MAX_WIDTH);
+    REQ(hid > 0 && hid <= VAD_MAX_WIDTH, "vid: lstm_hidden_dim=%d out of range [1,%d]", hid, VAD_MAX_WIDTH);
     REQ(layers >= 1 && layers <= 8, "vid: lstm_num_layers=%d out of range [1,8]", layers);
     return VAD_OK;
 }
@@ -311,6 +369,7 @@ extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int 
     for (int i = 0; i < nparams; ++i) REQ(P[i], "vid_pack: parameter %d is NULL", i);
     memset(out, 0, L.total * sizeof(float));
     put_header(out, VAD_BLOB_VID, precision, latent, hid | (layers << 16));
+    const int first_convt = 4 + layers + (L.has_proj ? 1 : 0);
     int pi = 0;
     for (int li = 0; li < L.nlayers && rc == VAD_OK; ++li) {
         const LayerSlot& s = L.layer[li];
@@ -319,12 +378,22 @@ extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int 
         switch (s.kind) {
         case LK_CONV_C3: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
             rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b); pi += 6; break;
-        case LK_CONV: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
-            rc = vad_pack_conv3x3(w, b, bn, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 6; break;
-        case LK_CONVT: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
-            rc = vad_pack_convt2x2(w, b, bn, s.cin, s.cout, precision, out + s.w, out + s.b); pi += 6; break;
-        case LK_LSTM: rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 2; break;
-        case LK_PROJ: rc = vad_pack_conv1x1(w, b, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break;
+        case LK_CONV: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];     // encoder.12 is the one whose cout is latent_dim
+            rc = pack_conv3x3_slot(w, b, bn, li == 3 ? latent : s.cout, s.cin, s, precision, out); pi += 6; break;
+        case LK_CONVT: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];    // decoder.0 is the one whose cin is latent_dim
+            rc = pack_convt2x2_slot(w, b, bn, li == first_convt ? latent : s.cin, s.cout, s, precision, out); pi += 6; break;
+        case LK_LSTM: {   // weight (4*hid, x + hid, 3, 3): gate blocks i,f,g,o and the x / h input halves are padded separately
+            const int xr = (li == 4) ? latent : hid, xp = (li == 4) ? L.latent_p : L.hid_p, hp = L.hid_p;
+            if (xr == xp && hid == hp) { rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 2; break; }
+            PaddedLayer Q;
+            pad_layer(w, b, nullptr, 4 * hid, xr + hid, 9, false, s.cout, s.cin,
+                      [=](int co) { return (co / hid) * hp + co % hid; }, [=](int ci) { return ci < xr ? ci : xp + (ci - xr); }, Q);
+            rc = vad_pack_conv3x3(Q.w.data(), Q.bias.data(), nullptr, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 2; break; }
+        case LK_PROJ: {
+            if (latent == s.cout && hid == s.cin) { rc = vad_pack_conv1x1(w, b, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break; }
+            PaddedLayer Q;
+            pad_layer(w, b, nullptr, latent, hid, 1, false, s.cout, s.cin, same, same, Q);
+            rc = vad_pack_conv1x1(Q.w.data(), Q.bias.data(), s.cout, s.cin, out + s.w, out + s.b); pi += 2; break; }
         case LK_TAIL_CONVT:
             memcpy(out + s.w, w, (size_t)32 * 12 * sizeof(float));
             for (int c = 0; c < 3; ++c) out[s.b + c] = b[c];

@@ -441,14 +441,15 @@ int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, 
 
 // --------------------------------------------------------------------------------- transposes
 // Per frame [P][C] <-> [C][P] through a 32x33 LDS tile (both sides coalesced).
-__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int rows, int cols) {
+// in_ld: row pitch of the source (>= cols; the latent code of a zero-padded latent_dim keeps its padded pitch)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int rows, int cols, int in_ld) {
     __shared__ float t[32][33];
-    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const size_t base = (size_t)blockIdx.z * rows * cols, ibase = (size_t)blockIdx.z * rows * in_ld;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     for (int j = ly; j < 32; j += 8) {
         const int r = r0 + j, c = c0 + lx;
-        if (r < rows && c < cols) t[j][lx] = in[base + (size_t)r * cols + c];
+        if (r < rows && c < cols) t[j][lx] = in[ibase + (size_t)r * in_ld + c];
     }
     __syncthreads();
     for (int j = ly; j < 32; j += 8) {
@@ -457,15 +458,20 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* 
     }
 }
 
-static int launch_transpose(const float* in, float* out, int n, int rows, int cols, void* stream) {
-    VAD_REQUIRE(in && out && n > 0 && rows > 0 && cols > 0 && n < 65536, "transpose: bad arguments");
+static int launch_transpose(const float* in, float* out, int n, int rows, int cols, void* stream, int in_ld = 0) {
+    if (in_ld == 0) in_ld = cols;
+    VAD_REQUIRE(in && out && n > 0 && rows > 0 && cols > 0 && n < 65536 && in_ld >= cols, "transpose: bad arguments");
     dim3 g((cols + 31) / 32, (rows + 31) / 32, n);
     VAD_REQUIRE(g.y < 65536, "transpose: too many row tiles");
-    hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+    hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, in_ld);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
 
+// the first `c` channels of an NHWC tensor whose pixels are `in_c` floats apart
+int vad_nhwc_to_nchw_ld(const float* in, int in_c, float* out, int n, int h, int w, int c, void* stream) {
+    return launch_transpose(in, out, n, h * w, c, stream, in_c);
+}
 extern "C" int vad_nhwc_to_nchw(const float* in, float* out, int n, int h, int w, int c, void* stream) {
     return launch_transpose(in, out, n, h * w, c, stream);
 }

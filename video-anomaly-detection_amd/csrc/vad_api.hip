@@ -137,7 +137,8 @@ static std::atomic<int> g_vad_dec4_fused{1};   // debug / A-B: 0 = dec4.0 and th
 extern "C" int vad_debug_set_dec4_fused(int on) { g_vad_dec4_fused = on; return VAD_OK; }
 
 extern "C" size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent) {
-    if (chunk <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16 || latent <= 0 || latent % 32) return 0;
+    if (chunk <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16 || latent <= 0 || latent > VAD_MAX_WIDTH) return 0;
+    latent = vad_img_latent_p(latent);
     const size_t act = up256(sizeof(float) * chunk * img_act_floats(h, w, latent));
     const size_t parts = up256(sizeof(float) * chunk * img_partials(h, w));
     return 2 * act + parts;
@@ -150,7 +151,7 @@ extern "C" int vad_img_score(const float* x, long long b, int h, int w, int late
                            latent_out, stream);
 }
 
-extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long long b, int h, int w, int latent,
+extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long long b, int h, int w, int latent_real,
                                const float* packed, void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
                                float* recon, float* latent_out, void* stream) {
     VAD_REQUIRE(xv && packed && ws, "img_score: null pointer");
@@ -161,14 +162,15 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
     VAD_REQUIRE(b > 0 && chunk > 0, "img_score: batch=%lld chunk=%d must be positive", b, chunk);
     VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
                 "img_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
-    VAD_REQUIRE(latent > 0 && latent % 32 == 0, "img_score: latent_dim=%d must be a positive multiple of 32", latent);
+    VAD_REQUIRE(latent_real > 0 && latent_real <= VAD_MAX_WIDTH, "img_score: latent_dim=%d out of range [1,%d]", latent_real, VAD_MAX_WIDTH);
     VAD_REQUIRE(scores || errmap || recon || latent_out, "img_score: no output requested");
-    const size_t need = vad_img_workspace_bytes(chunk, h, w, latent);
+    const size_t need = vad_img_workspace_bytes(chunk, h, w, latent_real);
     if (ws_bytes < need) return vad_fail(VAD_ERR_WS, "img_score: workspace %zu B < required %zu B", ws_bytes, need);
     VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "img_score: workspace must be 256-B and weights 16-B aligned");
 
     hipStream_t s = (hipStream_t)stream;
-    const ImgLayout L = img_layout(latent);
+    const ImgLayout L = img_layout(latent_real);
+    const int latent = L.latent_p;                  // the width the kernels see (zero-padded to a multiple of 32, vad_layout.h)
     const size_t act = up256(sizeof(float) * chunk * img_act_floats(h, w, latent));
     float* A = (float*)ws;
     float* B = (float*)((char*)ws + act);
@@ -196,7 +198,7 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
         hh /= 2; ww /= 2;   // B = latent code [n, H/16, W/16, latent]
         if (latent_out) {
             VadProfScope ps(17, s);
-            TRY(vad_nhwc_to_nchw(B, latent_out + (size_t)f0 * latent * hh * ww, n, hh, ww, latent, s));
+            TRY(vad_nhwc_to_nchw_ld(B, latent, latent_out + (size_t)f0 * latent_real * hh * ww, n, hh, ww, latent_real, s));
         }
         if (!need_decoder) continue;
         // decoder: 3 x [convT-BN-ReLU, conv-BN-ReLU] + [convT-BN-ReLU, conv-Tanh] (models/autoencoder.py:103-139)
@@ -255,15 +257,16 @@ namespace {
 struct VidWs {
     size_t act, enc, hseq, cst, proj, parts, total;
 };
-VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent, int hid, int layers) {
+VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_real, int layers) {
     VidWs z{};
+    const int latent = vad_vid_latent_p(latent_real, hid_real), hid = vad_vid_hid_p(latent_real, hid_real);
     const size_t n = (size_t)chunk * t, nf = (size_t)(chunk - 1) * cs + t, p16 = (size_t)(h / 16) * (w / 16);
     const size_t nmax = n > nf ? n : nf;
     z.act = up256(sizeof(float) * nmax * (size_t)h * w * 8);       // [frames, H/2, W/2, 32]
     z.enc = up256(sizeof(float) * nf * p16 * latent);
     z.hseq = up256(sizeof(float) * n * p16 * hid);
     z.cst = up256(sizeof(float) * (size_t)chunk * p16 * hid);
-    z.proj = (hid != latent) ? up256(sizeof(float) * n * p16 * latent) : 0;
+    z.proj = (hid_real != latent_real) ? up256(sizeof(float) * n * p16 * latent) : 0;
     z.parts = up256(sizeof(float) * n * (size_t)vad_score_partials(1, h, w));
     z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst) + z.proj + z.parts;   // h sequence + cell state per layer
     return z;
@@ -304,17 +307,18 @@ static std::atomic<int> g_vad_lstm_wavefront{1};   // debug: 0 = always the sequ
 extern "C" int vad_debug_set_lstm_wavefront(int on) { g_vad_lstm_wavefront = on; return VAD_OK; }
 
 // clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
-int vid_run(const void* xv, int x_format, int precision, long long nclips, int t, int cs, int h, int w, int latent, int hid, int layers,
+int vid_run(const void* xv, int x_format, int precision, long long nclips, int t, int cs, int h, int w, int latent_real, int hid_real, int layers,
             const float* packed, void* ws, size_t ws_bytes, int chunk, float* seq_scores, float* frame_scores,
             float* errmap, float* recon, hipStream_t s, const char* who) {
     VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "%s: unknown input format %d", who, x_format);
     VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "%s: precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", who, precision);
     const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
     const char* x = (const char*)xv;
-    const VidWs Z = vid_ws(chunk, t, cs, h, w, latent, hid, layers);
+    const VidWs Z = vid_ws(chunk, t, cs, h, w, latent_real, hid_real, layers);
     if (ws_bytes < Z.total) return vad_fail(VAD_ERR_WS, "%s: workspace %zu B < required %zu B", who, ws_bytes, Z.total);
     VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "%s: workspace must be 256-B and weights 16-B aligned", who);
-    const VidLayout L = vid_layout(latent, hid, layers);
+    const VidLayout L = vid_layout(latent_real, hid_real, layers);
+    const int latent = L.latent_p, hid = L.hid_p;   // the widths the kernels see (zero-padded, vad_layout.h)
     char* base = (char*)ws;
     float* A = (float*)base; base += Z.act;
     float* Bf = (float*)base; base += Z.act;

@@ -117,6 +117,7 @@ int vad_bn_stats_from_partials(const float* partials, int nblocks, long long npi
                                float* running_mean, float* running_var, const float* pivot, void* stream);
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1, const float* b1,
                              float* out, int n, int h, int wd, int precision, void* stream);
+int vad_nhwc_to_nchw_ld(const float* in, int in_c, float* out, int n, int h, int w, int c, void* stream);   // first c of in_c channels
 // vad_score_finalize + the device-side blob check: when hdr != NULL and hdr[1] != want_tag every score becomes NaN
 int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, float* frame_scores,
                               float* seq_scores, int t, const unsigned* hdr, unsigned want_tag, void* stream);

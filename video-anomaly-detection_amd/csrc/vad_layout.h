@@ -19,16 +19,30 @@ struct LayerSlot {
     int kind, cin, cout;
     size_t w, b;   // float offsets into the blob
 };
+// The reference's constructors take ANY positive latent_dim / lstm_hidden_dim (models/autoencoder.py:161,
+// models/video_autoencoder.py:290-296); the kernels tile channels in blocks of 32 (64 hidden channels per ConvLSTM block).
+// The packers therefore zero-pad those dimensions: a padded channel has zero weights, zero bias and zero outgoing weights, so
+// it carries exactly 0 through LeakyReLU / ReLU / MaxPool and through the ConvLSTM cell (gates 0 -> c' = 0.5*0 + 0.5*0, h' = 0)
+// and adds `+ 0*w` terms to the sums it feeds: the results are those of the unpadded network.  Entry points take the REAL
+// dimensions; layouts, workspaces and launches use the padded ones below.
+inline int vad_pad_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int vad_img_latent_p(int latent) { return vad_pad_up(latent, 32); }
+// without `proj` (hid == latent) the decoder reads the ConvLSTM output directly: one common padded width
+inline int vad_vid_hid_p(int latent, int hid) { (void)latent; return vad_pad_up(hid, 64); }
+inline int vad_vid_latent_p(int latent, int hid) { return hid == latent ? vad_pad_up(hid, 64) : vad_pad_up(latent, 32); }
+
 struct ImgLayout {
     LayerSlot layer[16];
     int nlayers;
+    int latent_p;          // padded latent width (layer[].cin / cout hold padded widths too)
     size_t total;
 };
 struct VidLayout {
     LayerSlot layer[4 + 8 + 1 + 4];
     int nlayers;
-    int has_proj;
+    int has_proj;          // from the REAL dimensions: lstm_hidden_dim != latent_dim (models/video_autoencoder.py:311-312)
+    int latent_p, hid_p;
     size_t total;
 };
-ImgLayout img_layout(int latent);
+ImgLayout img_layout(int latent);                       // real dimensions in, padded slots out
 VidLayout vid_layout(int latent, int hid, int layers);

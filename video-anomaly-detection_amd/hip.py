@@ -25,6 +25,7 @@ PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16}     # b
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 X_F32_NCHW, X_U8_NHWC = 0, 1
 PROF_SLOTS = 32
+MAX_WIDTH = 4096          # VAD_MAX_WIDTH: largest latent_dim / lstm_hidden_dim
 
 _lock = threading.Lock()
 _lib = None

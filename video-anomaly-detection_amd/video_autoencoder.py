@@ -157,13 +157,13 @@ class VideoAutoencoder(nn.Module):
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
-            if n == 0 or self.in_channels != 3:
+            if n == 0 or not 1 <= self.in_channels <= 3:
                 raise hip.VadError(
                     f"VideoAutoencoder(in_channels={self.in_channels}, latent_dim={self.latent_dim}, "
                     f"lstm_hidden_dim={self.lstm_hidden_dim}, lstm_num_layers={self.lstm_num_layers}) is not "
-                    "supported by the HIP path (needs in_channels == 3, latent_dim % 32 == 0, "
-                    "lstm_hidden_dim % 64 == 0, 1 <= layers <= 8)")
-            params = _HipScorer.float_params(self)
+                    f"supported by the HIP path (needs 1 <= in_channels <= 3, latent_dim and lstm_hidden_dim in "
+                    f"[1, {hip.MAX_WIDTH}], 1 <= layers <= 8)")
+            params = _HipScorer.widen_to_rgb(_HipScorer.float_params(self), self.in_channels, last_transposed=True)
             blob = np.empty(n, dtype=np.float32)
             hip.check(l.vad_vid_pack(hip.pointer_array(params), len(params), self.latent_dim,
                                      self.lstm_hidden_dim, self.lstm_num_layers, mode, blob.ctypes.data), "vad_vid_pack")
@@ -196,8 +196,9 @@ class VideoAutoencoder(nn.Module):
 
     def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False, out=None):
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,T,H,W,3]: normalised inside the kernels (row f-3)
-        if x.dim() != 5 or (x.shape[4] if u8 else x.shape[2]) != 3:
-            raise hip.VadError(f"expected float input [B,T,3,H,W] or uint8 input [B,T,H,W,3], got {x.dtype} {tuple(x.shape)}")
+        cin = self.in_channels
+        if x.dim() != 5 or (x.shape[4] if u8 else x.shape[2]) != cin:
+            raise hip.VadError(f"expected float input [B,T,{cin},H,W] or uint8 input [B,T,H,W,{cin}], got {x.dtype} {tuple(x.shape)}")
         if not x.is_cuda:
             raise hip.VadError(
                 "VideoAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
@@ -211,6 +212,7 @@ class VideoAutoencoder(nn.Module):
         l = hip.lib()
         dev = x.device
         packed = self._packed(dev)
+        x = _HipScorer.widen_input(x, cin, u8)
         chunk = max(1, min(int(self.chunk), b))
         dims = (self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
         nbytes = l.vad_vid_workspace_bytes(chunk, t, h, w, *dims)
@@ -236,6 +238,20 @@ class VideoAutoencoder(nn.Module):
                                       hip.ptr(out.get("errmap")), hip.ptr(out.get("recon")), hip.current_stream()),
                       "vad_vid_score")
         hip.calls["vid_score"] += 1
+        return self._narrow_outputs(out)
+
+    def _narrow_outputs(self, out: dict) -> dict:
+        """Undo the 3-plane view of a 1- / 2-channel model (`_HipScorer.widen_to_rgb`): the kernels averaged over 3
+        planes of which 3 - in_channels are exactly zero."""
+        cin = self.in_channels
+        if cin == 3:
+            return out
+        out = dict(out)
+        for k in ("seq", "frame", "errmap"):
+            if k in out:
+                out[k] = out[k] * (3.0 / cin)
+        if "recon" in out:
+            out["recon"] = out["recon"][:, :, :cin].contiguous()
         return out
 
     # ------------------------------------------------------------------ reference API
@@ -281,8 +297,9 @@ class VideoAutoencoder(nn.Module):
         if not self._use_hip():
             raise hip.VadError("score_windows is an inference entry point: call under eval() and torch.no_grad()")
         u8 = frames.dtype == torch.uint8
-        if frames.dim() != 4 or (frames.shape[3] if u8 else frames.shape[1]) != 3:
-            raise hip.VadError(f"expected float frames [F,3,H,W] or uint8 frames [F,H,W,3], got {tuple(frames.shape)}")
+        cin = self.in_channels
+        if frames.dim() != 4 or (frames.shape[3] if u8 else frames.shape[1]) != cin:
+            raise hip.VadError(f"expected float frames [F,{cin},H,W] or uint8 frames [F,H,W,{cin}], got {tuple(frames.shape)}")
         if not frames.is_cuda:
             raise hip.VadError("score_windows runs only on the MI355X HIP path (there is no CPU fallback)")
         if u8:
@@ -297,6 +314,7 @@ class VideoAutoencoder(nn.Module):
         frames = frames.contiguous() if u8 else frames.contiguous().float()
         dev = frames.device
         packed = self._packed(dev)
+        frames = _HipScorer.widen_input(frames, cin, u8)
         chunk = max(1, min(int(self.window_chunk), nw))
         dims = (self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
         nbytes = l.vad_vid_windows_workspace_bytes(chunk, t, int(stride), h, w, *dims)
@@ -316,7 +334,7 @@ class VideoAutoencoder(nn.Module):
                                               out["frame"].data_ptr(), hip.ptr(out.get("errmap")),
                                               hip.ptr(out.get("recon")), hip.current_stream()), "vad_vid_score_windows")
         hip.calls["vid_score"] += 1
-        return out
+        return self._narrow_outputs(out)
 
     def score_seq_and_frames(self, x):
         """One pass returning {'seq': [B], 'frame': [B,T]} and nothing else (the reference's clip loop runs two forwards
