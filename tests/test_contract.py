@@ -59,6 +59,23 @@ def test_option_a_layout_imports(tmp_path):
         assert r.returncode == 0 and r.stdout.strip() == "ok", (own_init, r.stderr[-2000:])
 
 
+def test_eval_with_autograd_enabled_warns_once(vad):
+    """eval() + grad enabled leaves the HIP path for the torch composition: a RuntimeWarning says so, once per model."""
+    import warnings
+    m = vad.ConvAutoencoder(latent_dim=32).eval()
+    x = torch.zeros(1, 3, 16, 16)
+    with pytest.warns(RuntimeWarning, match="no_grad"):
+        m.get_reconstruction_error(x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m(x)                                  # second call: silent
+        m.train()
+        m(torch.zeros(2, 3, 16, 16))          # train mode is the documented autograd path: never warns
+    v = vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32, lstm_num_layers=1).eval()
+    with pytest.warns(RuntimeWarning, match="no_grad"):
+        v(torch.zeros(1, 2, 3, 16, 16))
+
+
 def test_state_dict_contract_image(vad, golden):
     g = golden("init.npz")
     m = vad.ConvAutoencoder()

@@ -143,6 +143,20 @@ class _HipScorer:
             raise hip.VadError("uint8 input needs in_channels == 3")
         return torch.cat([x, x.new_zeros(shape)], dim=axis)
 
+    @staticmethod
+    def warn_eval_with_grad(module: nn.Module) -> None:
+        """An `eval()` model called with autograd enabled runs the stock torch.nn composition (a differentiable graph is
+        what such a call asks for) - the one way to leave the HIP path without an error.  Every scoring call site of the
+        reference is under `torch.no_grad()` (evaluate.py:56, evaluate_video.py:138,346, main.py:273,348); say so once per
+        model instead of being silently slow."""
+        if getattr(module, "_warned_eval_grad", False):
+            return
+        module._warned_eval_grad = True
+        import warnings
+        warnings.warn(f"{type(module).__name__} is in eval() mode but autograd is enabled: this call runs the torch.nn "
+                      "composition, not the MI355X HIP path.  Wrap scoring in `torch.no_grad()` (as evaluate.py:56 does) "
+                      "to use the HIP kernels.", RuntimeWarning, stacklevel=4)
+
     def workspace(self, nbytes: int, device) -> torch.Tensor:
         if self.ws is None or self.ws.numel() < nbytes or self.ws.device != device:
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -171,6 +185,8 @@ class ConvAutoencoder(nn.Module):
 
     # ------------------------------------------------------------------ HIP path
     def _use_hip(self) -> bool:
+        if not self.training and torch.is_grad_enabled():
+            _HipScorer.warn_eval_with_grad(self)
         return not self.training and not torch.is_grad_enabled()
 
     def _packed(self, device) -> torch.Tensor:

@@ -147,6 +147,8 @@ class VideoAutoencoder(nn.Module):
 
     # ------------------------------------------------------------------ HIP path
     def _use_hip(self) -> bool:
+        if not self.training and torch.is_grad_enabled():
+            _HipScorer.warn_eval_with_grad(self)
         return not self.training and not torch.is_grad_enabled()
 
     def _packed(self, device) -> torch.Tensor:
