@@ -42,6 +42,13 @@ extern "C" {
  *      last layer and Adam stay fp32 (weight gradients: bf16 operands, fp32 accumulation).
  *      8 significant bits: the scoring entry points and host packers reject it (scores would miss the 1e-4 bar by 60x). */
 #define VAD_PREC_BF16 2
+/*   VAD_PREC_BF16S bf16 STORAGE as well (training only, the mode `VideoTrainer(precision="bf16")` runs): every activation and
+ *      activation-gradient tensor between the kernels - conv outputs before BatchNorm, pooled activations, ConvLSTM operand
+ *      and gate buffers, gradient scratch - is bf16 in HBM (half the bytes of the HBM-bound BatchNorm passes, MFMA operands
+ *      staged without conversion); arithmetic inside every kernel, BatchNorm statistics (from the fp32 accumulators), cell
+ *      states, parameters, parameter gradients, loss and Adam stay fp32.  Layer entry points that take `precision` read /
+ *      write bf16 tensors through their `float*` arguments in this mode (element strides stay in elements). */
+#define VAD_PREC_BF16S 3
 
 int vad_abi_version(void);
 const char* vad_last_error(void);   /* per thread */
@@ -252,6 +259,37 @@ int vad_conv3x3_to3_tanh_bwd(const float* in_nhwc, const float* recon, const flo
                              int n, int h, int w, int cin, void* stream);
 /* Conv2d k1 (cout, cin, 1, 1): fwd = vad_pack_conv1x1 layout; dgrad = the transposed 1x1 weight (K = cout, N = cin). */
 int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
+
+/* bf16-tensor forms of the kernels above (VAD_PREC_BF16S, `VideoTrainer(precision="bf16")`): io16 != 0 means every
+ * activation / activation-gradient tensor argument (y, out, dout, dy, z, h1, h2, gates, dh1, dh2, dz, g, in, din, dpre32) is
+ * bf16 in memory - strides stay in ELEMENTS - while statistics, cell states, parameters, their gradients and the loss stay
+ * fp32; io16 == 0 is the fp32 entry point of the same name without `_t`.  The arithmetic inside is the same fp32 arithmetic
+ * on the widened values, results rounded to bf16 (nearest even) where they are stored.  vad_conv3x3 / vad_convt2x2 /
+ * vad_conv_wgrad / vad_train_pack_* take precision VAD_PREC_BF16S for the same tensors. */
+int vad_chan_sum_t(const void* g, int io16, long long npix, int c, float* out, float* ws, void* stream);
+int vad_bn_act_pool_fwd_t(const void* y, int io16, const float* stats, const float* gamma, const float* beta, void* out,
+                          long long out_fs, int out_ps, int remap_t, int remap_b, int n, int h, int w, int c, int act, int pool,
+                          void* stream);
+int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const float* gamma, const float* beta, const void* dout,
+                          long long dout_fs, int dout_ps, int remap_t, int remap_b, void* dy, int s2d, float* dgamma, float* dbeta,
+                          float* ksums, float* ws, int n, int h, int w, int c, int act, int pool, void* stream);
+int vad_lstm_gates_fwd_t(void* z, int io16, const float* c_prev, float* c_out, void* h1, long long h1_fs, int h1_ps,
+                         void* h2, long long h2_fs, int h2_ps, int nb, int hw, int hid, void* stream);
+int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const float* c, const void* dh1, long long dh1_fs,
+                         int dh1_ps, const void* dh2, long long dh2_fs, int dh2_ps, const float* dc_next, void* dz,
+                         float* dc_prev, int nb, int hw, int hid, void* stream);
+int vad_conv_c3_wgrad_t(const float* x_nchw, const void* g, int io16, float* dw, float* ws, int n, int h, int w, int cout,
+                        void* stream);
+int vad_convt_to3_mse_t(const void* in_nhwc, int io16, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
+                        void* din, void* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w, void* stream);
+/* Conv2d k1 with `precision`: VAD_PREC_BF16S = bf16 tensors and bf16 operands (weights from vad_train_pack_conv1x1_p with the
+ * same precision), anything else = vad_conv1x1 / vad_train_pack_conv1x1. */
+int vad_train_pack_conv1x1_p(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream);
+int vad_conv1x1_p(const void* in, const float* w_packed, const float* bias, void* out, long long npix, int cin, int cout,
+                  int precision, void* stream);
+/* First layer (x NCHW fp32 [N,3,H,W]) -> conv3x3(3->Cout) + bias, un-activated, into a bf16 NHWC tensor. */
+int vad_conv3x3_c3_bf16(const float* x_nchw, const float* w_packed, const float* bias, void* out_bf16, int n, int h, int w,
+                        int cout, void* stream);
 
 /* ------------------------------------------------------------------ whole training step (row f-1)
  * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim,

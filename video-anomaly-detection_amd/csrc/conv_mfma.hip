@@ -280,7 +280,7 @@ struct ConvKnobs {
         variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; no_small = (b >> 3) & 1; all_small = (b >> 4) & 1;
     }
 };
-#define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT || precision == VAD_PREC_BF16, who ": precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1) or VAD_PREC_BF16 (2)", precision)
+#define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, who ": precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1), VAD_PREC_BF16 (2) or VAD_PREC_BF16S (3)", precision)
 
 static int vad_num_cus() {
     static std::atomic<int> ncu_cached{0};
@@ -321,19 +321,19 @@ static unsigned persistent_grid_for(const Conv3P& p, unsigned cap) {
 // `variant`: 1 = persistent kernel, 0 = one tile per work-group (exact fp32 only); grid caps are per instantiation and
 // written once with the same value by whichever thread gets there first.
 // one persistent launch; ST = 1: the instantiation that also writes the BatchNorm partial sums (p.stats)
-template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int PREC, int ST>
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int PREC, int ST, int IO16 = 0>
 static void launch_conv3_persistent(const Conv3P& p, const Conv3P& q, hipStream_t s) {
     static std::atomic<unsigned> grid_cap{0};
     unsigned cap = grid_cap.load(std::memory_order_relaxed);
-    if (!cap) grid_cap = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, PREC, ST>, ~0u);
-    hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, PREC, ST>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
+    if (!cap) grid_cap = cap = persistent_grid(conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, PREC, ST, IO16>, ~0u);
+    hipLaunchKernelGGL((conv3x3_mfma_pkernel<CK, MT, NT, WM, WN, MODE, ACT, 0, PREC, ST, IO16>), dim3(persistent_grid_for(p, cap)), dim3(256), 0, s, q);
 }
-template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int PREC>
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int PREC, int IO16 = 0>
 static void launch_conv3_p(const Conv3P& p, const Conv3P& q, hipStream_t s) {
     if constexpr (MODE == MODE_PLAIN && ACT == VAD_ACT_NONE) {
-        if (p.stats) { launch_conv3_persistent<CK, MT, NT, WM, WN, MODE, ACT, PREC, 1>(p, q, s); return; }
+        if (p.stats) { launch_conv3_persistent<CK, MT, NT, WM, WN, MODE, ACT, PREC, 1, IO16>(p, q, s); return; }
     }
-    launch_conv3_persistent<CK, MT, NT, WM, WN, MODE, ACT, PREC, 0>(p, q, s);
+    launch_conv3_persistent<CK, MT, NT, WM, WN, MODE, ACT, PREC, 0, IO16>(p, q, s);
 }
 
 template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT>
@@ -344,6 +344,14 @@ static void launch_conv3_act(const Conv3P& p, hipStream_t s, int precision, int 
         q.stagger = kn.stagger;   // debug (variant bit 1): zero-sized weight descriptor = price the weight traffic
         launch_conv3_p<CK, MT, NT, WM, WN, MODE, ACT, 1>(p, q, s);
         return;
+    }
+    if constexpr (MODE == MODE_PLAIN && ACT == VAD_ACT_NONE) {   // bf16 tensors (host-checked: plain un-activated launches only)
+        if (precision == VAD_PREC_BF16S) {
+            Conv3P q = p;
+            q.dbg = g_vad_dbg;
+            launch_conv3_p<CK, MT, NT, WM, WN, MODE, ACT, 2, 1>(p, q, s);
+            return;
+        }
     }
     if constexpr (MODE != MODE_LSTM) {   // bf16 operands (training convolutions; the ConvLSTM step is not offered in bf16)
         if (precision == VAD_PREC_BF16) {
@@ -415,6 +423,7 @@ int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const fl
                 "conv3x3: cin=%d cout=%d must be positive multiples of 32", cin, cout);
     VAD_REQUIRE(!pool || (h % 2 == 0 && wd % 2 == 0), "conv3x3: pooling needs even H,W (got %dx%d)", h, wd);
     VAD_REQUIRE(act >= 0 && act <= 2, "conv3x3: bad act %d", act);
+    VAD_REQUIRE(precision != VAD_PREC_BF16S || (act == VAD_ACT_NONE && !pool), "conv3x3: VAD_PREC_BF16S (bf16 tensors) is the training form: no activation, no pooling");
     Conv3P p{};
     p.in = in; p.in_fs = in_fs ? in_fs : (long long)h * wd * cin; p.cin_a = cin;
     p.in2 = nullptr; p.in2_fs = 0;
@@ -636,8 +645,12 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
 // the bias live in registers for its whole life, every wave runs FOUR independent accumulator chains (its 4 M-tiles of
 // 2 rows x 16 columns) interleaved k-step by k-step, and the input halo of the NEXT tile is fetched into registers while
 // the current one is computed (3 planes x 34 x 18 values = 8 per thread).
-template <int POOL, int ACT>
+// OUT16 (un-pooled, un-activated = the training forward of VAD_PREC_BF16S): the output tensor is bf16 in memory (the
+// arithmetic and the statistics are unchanged).
+template <int POOL, int ACT, int OUT16 = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
+    static_assert(!OUT16 || (!POOL && ACT == VAD_ACT_NONE), "bf16 output: training forward only");
+    constexpr unsigned OS = OUT16 ? 2u : 4u;
     constexpr int MTW = 4, TH = 2 * MTW * 4, LH = TH + 2, RS = 20, NE = 3 * LH * 18, NST = (NE + 255) / 256;
     __shared__ float tile[3 * LH * RS + 1];              // + one dummy slot: staging slots past the tile write there
     const int tid = threadIdx.x, lane = tid & 63;
@@ -722,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     // ~100 terms in a row; shifted by the bias (the channel's mean is close to it), as chan_sums_kernel shifts by a sample
     float st_s = 0.f, st_q = 0.f;
     const int oh = POOL ? p.h >> 1 : p.h, ow = POOL ? p.w_ >> 1 : p.w_;
-    const unsigned orow = (unsigned)(ow * p.cout) * 4u, ocol = (unsigned)p.cout * 4u;      // bytes per output row / pixel
+    const unsigned orow = (unsigned)(ow * p.cout) * OS, ocol = (unsigned)p.cout * OS;      // bytes per output row / pixel
     // XCD-aware walk: in every round of gridDim.x tiles, the work-groups of one XCD take a CONTIGUOUS run of tiles (four tile
     // rows at 256x256), so neighbours that share 128-byte input lines (a tile row is 18 floats of a line; a line spans two
     // tiles) share an L2.  Dealt round-robin, every XCD fetched the lines for itself: 1.91 GB per 640 frames for 0.50 GB of
@@ -745,14 +758,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
         const int ty = t_ % p.tiles_y;
         const int n = t_ / p.tiles_y;
         const int y0 = ty * TH, x0 = tx * 16;
-        const __amdgpu_buffer_rsrc_t rout = vad_rsrc(p.out + (size_t)n * (oh * ow) * p.cout, (unsigned)(oh * ow * p.cout) * 4u);
+        const __amdgpu_buffer_rsrc_t rout = vad_rsrc((const char*)p.out + (size_t)n * (oh * ow) * p.cout * OS, (unsigned)(oh * ow * p.cout) * OS);
         // this wave's first output row / the tile's first output column, as a byte offset inside the frame (scalar)
         const int oy0 = POOL ? (y0 >> 1) + wave * MTW : y0 + 2 * wave * MTW, ox0 = POOL ? x0 >> 1 : x0;
         const unsigned ubase = (unsigned)oy0 * orow + (unsigned)ox0 * ocol;
         const bool full = POOL ? (oy0 + MTW <= oh && ox0 + 8 <= ow) : (oy0 + 2 * MTW <= oh && ox0 + 16 <= ow);   // wave-uniform
         for (int nt = 0; nt < ctiles; ++nt) {
             const int co = nt * 32 + li;
-            const unsigned lanepart = (unsigned)((POOL ? lh : 2 * lh) * p.cout + co) * 4u;
+            const unsigned lanepart = (unsigned)((POOL ? lh : 2 * lh) * p.cout + co) * OS;
             if (have != nt) {
 #pragma unroll
                 for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
@@ -806,8 +819,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                         for (int pos = 0; pos < 4; ++pos) {
                             unsigned vo = lanepart;
                             if (!full) vo = ((oy0 + 2 * mt + (pos >> 1)) < oh && (ox0 + 4 * q + 2 * lh + (pos & 1)) < ow) ? lanepart : VAD_OOB;
-                            vad_bstore1(vad_act(acc[mt][4 * q + pos], ACT), rout, vo,
-                                        ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
+                            if constexpr (OUT16) vad_bstore_h(vad_f_bf16(acc[mt][4 * q + pos]), rout, vo,
+                                                              ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
+                            else vad_bstore1(vad_act(acc[mt][4 * q + pos], ACT), rout, vo,
+                                             ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
                             if (p.stats) {   // (uniform)
                                 const float d = (full || vo != VAD_OOB) ? acc[mt][4 * q + pos] - bv : 0.f;
                                 ts += d;
@@ -851,6 +866,17 @@ int vad_conv3x3_c3_fmt(const void* x, int fmt, const float* w, const float* bias
 // could not provide them (the caller then makes its own pass over `out`).
 int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bias, float* out,
                          int n, int h, int wd, int cout, int act, int pool, float* stats, int* stats_blocks, void* stream) {
+    return vad_conv3x3_c3_stats_t(x, fmt, w, bias, out, 0, n, h, wd, cout, act, pool, stats, stats_blocks, stream);
+}
+
+extern "C" int vad_conv3x3_c3_bf16(const float* x, const float* w, const float* bias, void* out, int n, int h, int wd, int cout, void* stream) {
+    return vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, w, bias, out, 1, n, h, wd, cout, VAD_ACT_NONE, 0, nullptr, nullptr, stream);
+}
+
+// out16 != 0: `out` is a bf16 tensor (VAD_PREC_BF16S; persistent un-pooled un-activated launches only)
+int vad_conv3x3_c3_stats_t(const void* x, int fmt, const float* w, const float* bias, void* outv, int out16,
+                           int n, int h, int wd, int cout, int act, int pool, float* stats, int* stats_blocks, void* stream) {
+    float* out = (float*)outv;
     if (stats_blocks) *stats_blocks = 0;
     VAD_REQUIRE((stats == nullptr) == (stats_blocks == nullptr), "conv3x3_c3: stats and stats_blocks come together");
     VAD_REQUIRE(x && w && bias && out, "conv3x3_c3: null pointer");
@@ -860,6 +886,7 @@ int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bi
     VAD_REQUIRE(act == VAD_ACT_LEAKY || act == VAD_ACT_RELU || act == VAD_ACT_NONE, "conv3x3_c3: bad act");
     hipStream_t s = (hipStream_t)stream;
     const ConvKnobs kn;
+    VAD_REQUIRE(!out16 || (kn.variant != 0 && !pool && act == VAD_ACT_NONE), "conv3x3_c3: bf16 output is offered by the persistent un-pooled un-activated kernel only");
     // persistent kernel (tiles of 32 rows x 16 columns) for both forms.  The un-pooled one (training forward) writes 8.4 MB per
     // 256x256 frame: 2.6 us/frame = 3.5 TB/s with the scalar-offset buffer stores (the one-tile-per-work-group kernel, with a
     // 64-bit address computed per store, needs 3.8 us; an earlier persistent form with the same address arithmetic 6.5 us).
@@ -887,6 +914,13 @@ int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bi
         } else {
             if (act == VAD_ACT_LEAKY) C3P_LAUNCH(0, VAD_ACT_LEAKY)
             else if (act == VAD_ACT_RELU) C3P_LAUNCH(0, VAD_ACT_RELU)
+            else if (out16) {
+                static std::atomic<unsigned> cap_{0};
+                unsigned cap = cap_.load(std::memory_order_relaxed);
+                if (!cap) cap_ = cap = persistent_grid(conv3x3_c3_pkernel<0, VAD_ACT_NONE, 1>, ~0u);
+                hipLaunchKernelGGL((conv3x3_c3_pkernel<0, VAD_ACT_NONE, 1>), dim3(p.nblocks < cap ? p.nblocks : cap), dim3(256), 0, s, p);
+                if (with_stats) *stats_blocks = (int)(p.nblocks < cap ? p.nblocks : cap);
+            }
             else C3P_LAUNCH(0, VAD_ACT_NONE)
         }
 #undef C3P_LAUNCH
@@ -1073,6 +1107,7 @@ int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const f
     VAD_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0,
                 "convt2x2: cin=%d cout=%d must be positive multiples of 32", cin, cout);
     VAD_REQUIRE(act >= 0 && act <= 2, "convt2x2: bad act");
+    VAD_REQUIRE(precision != VAD_PREC_BF16S || act == VAD_ACT_NONE, "convt2x2: VAD_PREC_BF16S (bf16 tensors) is the training form: no activation");
     ConvTP p{};
     p.in = in; p.in_fs = in_fs ? in_fs : (long long)h * wd * cin;
     p.w = w; p.bias = bias; p.out = out;
@@ -1090,6 +1125,28 @@ int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const f
     const int mt = 2, nt = prec ? 2 : 4;
     q.tiles_x = (wd + 15) / 16; q.tiles_y = (h + 2 * mt - 1) / (2 * mt);
     q.ngroups = 4 * cout / (32 * nt);
+    if (prec == VAD_PREC_BF16S) {          // bf16 tensors in, bf16 tensors out (un-activated: host-checked above)
+        const long long items16 = (long long)n * q.tiles_x * q.tiles_y * q.ngroups;
+        VAD_REQUIRE(items16 > 0 && items16 < (1ll << 31), "convt2x2: %lld work items out of range", items16);
+        q.nitems = (unsigned)items16;
+        const unsigned want16 = (unsigned)((items16 + 3) / 4);
+        const bool st16 = stats && cout <= 128;
+        q.stats = st16 ? stats : nullptr;
+        if (st16) {
+            static std::atomic<unsigned> cap_{0};
+            unsigned cap = cap_.load(std::memory_order_relaxed);
+            if (!cap) cap_ = cap = persistent_grid(convt2x2_pkernel<2, 2, VAD_ACT_NONE, 2, 1, 1, 1>, ~0u);
+            hipLaunchKernelGGL((convt2x2_pkernel<2, 2, VAD_ACT_NONE, 2, 1, 1, 1>), dim3(want16 < cap ? want16 : cap), dim3(256), 0, (hipStream_t)stream, q);
+            *stats_rows = (int)((want16 < cap ? want16 : cap) * 4);
+        } else {
+            static std::atomic<unsigned> cap_{0};
+            unsigned cap = cap_.load(std::memory_order_relaxed);
+            if (!cap) cap_ = cap = persistent_grid(convt2x2_pkernel<2, 2, VAD_ACT_NONE, 2, 0, 1, 1>, ~0u);
+            hipLaunchKernelGGL((convt2x2_pkernel<2, 2, VAD_ACT_NONE, 2, 0, 1, 1>), dim3(want16 < cap ? want16 : cap), dim3(256), 0, (hipStream_t)stream, q);
+        }
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
     const long long items = (long long)n * q.tiles_x * q.tiles_y * q.ngroups;
     VAD_REQUIRE(items > 0 && items < (1ll << 31), "convt2x2: %lld work items out of range", items);
     q.nitems = (unsigned)items;
@@ -1121,6 +1178,55 @@ int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const f
 #undef CT_LAUNCH_ST
 #undef CT_LAUNCH_
 #undef CT_LAUNCH
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// 1x1 convolution on bf16 tensors with bf16 operands (VAD_PREC_BF16S; weights from vad_train_pack_conv1x1_p): the UPS 0 form
+// of the wave-persistent transposed-convolution kernel.  The pixel list is presented as frames of h x w pixels (w a
+// multiple of 16) so that its 2-row x 16-column M-tiles are full.  Any other precision: the fp32 kernel below.
+int vad_conv1x1_p(const void* in, const float* w, const float* bias, void* out, long long npix, int cin, int cout, int precision, void* stream) {
+    if (precision != VAD_PREC_BF16S) return vad_conv1x1((const float*)in, w, bias, (float*)out, npix, cin, cout, stream);
+    VAD_REQUIRE(in && w && bias && out, "conv1x1: null pointer");
+    VAD_REQUIRE(npix > 0 && cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0, "conv1x1 (bf16): channels must be multiples of 32");
+    int wd = 16, h = 1;
+    long long n = 1;
+    int frame_pix = 0;
+    if (npix % 16 == 0) {
+        for (int c : {64, 32}) if (npix % c == 0) { wd = c; break; }
+        const long long rows = npix / wd;
+        for (int c : {256, 128, 64, 32, 16, 8, 4, 2}) if (rows % c == 0) { h = c; break; }
+        n = rows / h;
+    } else {                                   // ragged: one frame of ceil(npix / 16) rows whose last row is partly valid
+        const long long rows = (npix + 15) / 16;
+        VAD_REQUIRE(rows < (1 << 24), "conv1x1 (bf16): %lld pixels (not a multiple of 16) are too many for one ragged frame", npix);
+        h = (int)rows;
+        frame_pix = (int)npix;
+    }
+    VAD_REQUIRE(n < (1ll << 31) && (long long)h * wd * (cin > cout ? cin : cout) * 2 < (1ll << 31), "conv1x1 (bf16): shape out of range");
+    ConvTP2 q{};
+    q.frame_pix = frame_pix;
+    q.in = (const float*)in; q.in_fs = (long long)h * wd * cin; q.w = w; q.bias = bias; q.out = (float*)out; q.out_fs = (long long)h * wd * cout;
+    q.n = (int)n; q.h = h; q.w_ = wd; q.cin = cin; q.cout = cout;
+    q.tiles_x = wd / 16; q.tiles_y = (h + 3) / 4;
+    q.ngroups = cout / 64;
+    const bool narrow = cout % 64 != 0;        // 32 / 96 columns: one N-tile per item
+    if (narrow) q.ngroups = cout / 32;
+    const long long items = n * q.tiles_x * q.tiles_y * q.ngroups;
+    VAD_REQUIRE(items > 0 && items < (1ll << 31), "conv1x1 (bf16): %lld work items out of range", items);
+    q.nitems = (unsigned)items;
+    const unsigned want = (unsigned)((items + 3) / 4);
+    if (narrow) {
+        static std::atomic<unsigned> cap_{0};
+        unsigned cap = cap_.load(std::memory_order_relaxed);
+        if (!cap) cap_ = cap = persistent_grid(convt2x2_pkernel<2, 1, VAD_ACT_NONE, 2, 0, 1, 0>, ~0u);
+        hipLaunchKernelGGL((convt2x2_pkernel<2, 1, VAD_ACT_NONE, 2, 0, 1, 0>), dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, q);
+    } else {
+        static std::atomic<unsigned> cap_{0};
+        unsigned cap = cap_.load(std::memory_order_relaxed);
+        if (!cap) cap_ = cap = persistent_grid(convt2x2_pkernel<2, 2, VAD_ACT_NONE, 2, 0, 1, 0>, ~0u);
+        hipLaunchKernelGGL((convt2x2_pkernel<2, 2, VAD_ACT_NONE, 2, 0, 1, 0>), dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, q);
+    }
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

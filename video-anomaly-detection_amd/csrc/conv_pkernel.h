@@ -25,6 +25,17 @@ __device__ __forceinline__ float pf_get_f(float v) { return v; }
 __device__ __forceinline__ float pf_get_f(f32x4 v) { return v[0]; }
 __device__ __forceinline__ f32x4 pf_get_v(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 pf_get_v(float v) { return f32x4{v, v, v, v}; }
+// (bf16 tensors: a staging slot is 4 channels = 8 bytes, kept as the raw bit patterns)
+__device__ __forceinline__ void pf_set(u32x2& d, u32x2 v) { d = v; }
+__device__ __forceinline__ void pf_set(u32x2& d, float) {}
+__device__ __forceinline__ void pf_set(u32x2& d, f32x4) {}
+__device__ __forceinline__ void pf_set(float& d, u32x2) {}
+__device__ __forceinline__ void pf_set(f32x4& d, u32x2) {}
+__device__ __forceinline__ float pf_get_f(u32x2 v) { return __uint_as_float(v[0]); }
+__device__ __forceinline__ f32x4 pf_get_v(u32x2 v) { return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), 0.f, 0.f}; }
+__device__ __forceinline__ u32x2 pf_get_u(u32x2 v) { return v; }
+__device__ __forceinline__ u32x2 pf_get_u(float) { return u32x2{0u, 0u}; }
+__device__ __forceinline__ u32x2 pf_get_u(f32x4) { return u32x2{0u, 0u}; }
 
 #ifdef VAD_STAMPS
 #define STAMP(k)                                                                                      \
@@ -96,7 +107,10 @@ __device__ __forceinline__ void tile_put_t(float* tile, int pixoff_plus_ch, int 
     }
 }
 
-template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0, int WITH_STATS = 0>
+// IO16 (PREC 2, plain un-activated launches = the training convolutions of VAD_PREC_BF16S): input and output tensors are
+// bf16 in memory.  Staging is then a COPY - a thread's 4 channels are 8 bytes, written to the slot the conversion path
+// writes them to - and the epilogue rounds the fp32 accumulators to bf16 (the statistics still come from the accumulators).
+template <int CK, int MT, int NT, int WM, int WN, int MODE, int ACT, int FUSE_C3 = 0, int PREC = 0, int WITH_STATS = 0, int IO16 = 0>
 // Work-groups per CU: 3 for the exact-fp32 fused first layer (it fits 168 registers; its two barriers per tile need the
 // third resident group), else 2 (three groups measured no gain on the cout-32 tilings, and the deeper weight prefetch below
 // needs the registers).
@@ -105,6 +119,8 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     static_assert(MODE != MODE_LSTM || NT == 4, "LSTM mode: one N-tile per gate");
     static_assert(!FUSE_C3 || CK == 32, "fused first layer produces exactly one 32-channel chunk");
     static_assert(CK == 32, "staging slots assume 8 channel quads per pixel");
+    static_assert(!IO16 || (PREC == 2 && MODE == MODE_PLAIN && !FUSE_C3), "bf16 tensors: bf16 operands, plain convolution");
+    constexpr unsigned ES = IO16 ? 2u : 4u;         // bytes per activation element in memory
     constexpr int TH = 2 * MT * WM, LH = TH + 2, LW = 18, PS = CK + 4;
     // FUSE_C3: the staged data are the 3 NCHW input planes of the tile with a 2-pixel halo (scalar floats);
     // otherwise float4 channel quads of the NHWC tile with a 1-pixel halo.
@@ -194,16 +210,16 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
             const int ly = pix / LW, lx = pix - ly * LW;
             const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
             const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            svo[i] = ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, p.cin_a) + c4 * 4) * 4u : VAD_OOB;
+            svo[i] = ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, p.cin_a) + c4 * 4) * ES : VAD_OOB;
         }
     }
 
-    typedef typename std::conditional<FUSE_C3 != 0, float, f32x4>::type pf_t;
+    typedef typename std::conditional<FUSE_C3 != 0, float, typename std::conditional<IO16 != 0, u32x2, f32x4>::type>::type pf_t;
     pf_t pf[NPF];    // next stage's input, in flight
     float cpv[MODE == MODE_LSTM ? MT : 1][16];   // ConvLSTM: previous cell state of this lane's outputs, in flight during the last chunk
 
     // both sources of a two-source (ConvLSTM) launch have the same channel count (host-checked), so svo serves both
-    const unsigned in_bytes = FUSE_C3 ? (unsigned)(3 * H * W) * (p.xu8 ? 1u : 4u) : (unsigned)(H * W) * (unsigned)p.cin_a * 4u;
+    const unsigned in_bytes = FUSE_C3 ? (unsigned)(3 * H * W) * (p.xu8 ? 1u : 4u) : (unsigned)(H * W) * (unsigned)p.cin_a * ES;
 #define ISSUE(n_, ch_)                                                                                   \
     {                                                                                                    \
         if constexpr (FUSE_C3) {                                                                         \
@@ -217,11 +233,14 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf_set(pf[i_], vad_bload1(r_, svo[i_], 0)); \
             }                                                                                            \
         } else {                                                                                         \
-            const float* src_ = ((ch_) < nch_a) ? p.in + (size_t)(n_) * p.in_fs + (ch_) * CK             \
-                                                : p.in2 + (size_t)(n_) * p.in2_fs + ((ch_) - nch_a) * CK; \
-            const unsigned skip_ = (unsigned)(((ch_) < nch_a) ? (ch_) : (ch_) - nch_a) * CK * 4u;        \
+            const char* src_ = ((ch_) < nch_a) ? (const char*)p.in + ((size_t)(n_) * p.in_fs + (ch_) * CK) * ES            \
+                                               : (const char*)p.in2 + ((size_t)(n_) * p.in2_fs + ((ch_) - nch_a) * CK) * ES; \
+            const unsigned skip_ = (unsigned)(((ch_) < nch_a) ? (ch_) : (ch_) - nch_a) * CK * ES;        \
             const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(src_, in_bytes - skip_);                          \
-            _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf_set(pf[i_], vad_bload4(r_, svo[i_], 0)); \
+            _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                         \
+                if constexpr (IO16) pf_set(pf[i_], __builtin_bit_cast(u32x2, vad_bload2(r_, svo[i_], 0))); \
+                else pf_set(pf[i_], vad_bload4(r_, svo[i_], 0));                                         \
+            }                                                                                            \
         }                                                                                                \
     }
 
@@ -339,11 +358,11 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     const int ow = (MODE == MODE_POOL) ? (W >> 1) : W, oh = (MODE == MODE_POOL) ? (H >> 1) : H;
     const int ey0 = (MODE == MODE_POOL) ? (y0 >> 1) + wm * MT : y0 + 2 * wm * MT;      // first output row of this lane
     const int ex0 = (MODE == MODE_POOL) ? (x0 >> 1) + lh : x0 + 2 * lh;                // first output column
-    const unsigned erow = (unsigned)__mul24(ow, ech) * 4u, ecol = (unsigned)ech * 4u;  // bytes per output row / pixel
+    const unsigned erow = (unsigned)__mul24(ow, ech) * ES, ecol = (unsigned)ech * ES;  // bytes per output row / pixel
     unsigned eoff[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) eoff[nt] = (unsigned)(__mul24(__mul24(ey0, ow) + ex0, ech) + cofs[nt]) * 4u;
-    const unsigned out_bytes = (unsigned)__mul24(oh, ow) * (unsigned)ech * 4u;
+    for (int nt = 0; nt < NT; ++nt) eoff[nt] = (unsigned)(__mul24(__mul24(ey0, ow) + ex0, ech) + cofs[nt]) * ES;
+    const unsigned out_bytes = (unsigned)__mul24(oh, ow) * (unsigned)ech * ES;
 
     while (true) {
         f32x16 acc[MT][NT];
@@ -503,7 +522,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #pragma unroll
                 for (int i = 0; i < NPF; ++i)
                     if ((tid >> 3) + 32 * i < NPIX) {
-                        if constexpr (PREC) {   // channels 4*c4..4*c4+3 = half (c4&1) of 8-channel block c4>>1
+                        if constexpr (IO16) {   // already bf16: the 8 bytes go where the conversion path below puts them
+                            float* blk = &tile[(tid >> 3) * PS + i * 32 * PS + (c4 >> 1) * 8 + (c4 & 1) * 2];
+                            *(u32x2*)blk = pf_get_u(pf[i]);
+                        } else if constexpr (PREC) {   // channels 4*c4..4*c4+3 = half (c4&1) of 8-channel block c4>>1
                             const f32x4 v = pf_get_v(pf[i]);
                             float* blk = &tile[(tid >> 3) * PS + i * 32 * PS + (c4 >> 1) * 8 + (c4 & 1) * 2];
                             if constexpr (PREC == 2) {
@@ -631,7 +653,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 }
             }
         } else {
-            const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, (p.stagger & 2) ? 0u : out_bytes);   // stagger bit 1 (debug): zero-sized = every store dropped
+            const __amdgpu_buffer_rsrc_t ro = vad_rsrc((const char*)p.out + (size_t)n * p.out_fs * ES, (p.stagger & 2) ? 0u : out_bytes);   // stagger bit 1 (debug): zero-sized = every store dropped
             if (MODE == MODE_POOL) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -663,7 +685,8 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                             const unsigned so = dy * erow + dx * ecol;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
-                                vad_bstore1(vad_act(acc[mt][nt][4 * q + pos], ACT), ro, ok ? eoff[nt] : VAD_OOB, so);
+                                if constexpr (IO16) vad_bstore_h(vad_f_bf16(acc[mt][nt][4 * q + pos]), ro, ok ? eoff[nt] : VAD_OOB, so);
+                                else vad_bstore1(vad_act(acc[mt][nt][4 * q + pos], ACT), ro, ok ? eoff[nt] : VAD_OOB, so);
                                 if constexpr (STATS) {
                                     if (p.stats) {   // (uniform)
                                         const float d = ok ? acc[mt][nt][4 * q + pos] - bv[nt] : 0.f;

@@ -23,12 +23,21 @@ struct ConvTP2 {
     int tiles_x, tiles_y;     // M-tile groups per frame: tiles_x = ceil(W/16), tiles_y = ceil(H/(2*MT))
     int ngroups;              // column groups of NT*32 columns: 4*cout / (NT*32)
     unsigned nitems;          // n * tiles_y * tiles_x * ngroups
+    int frame_pix;            // UPS 0 only: valid pixels of a frame when its last row is ragged (0 = h*w); loads past them read 0,
+                              // stores past them are dropped (buffer range check)
     float* stats;             // nullable (WITH_STATS instantiations, un-activated = training forward, cout <= 128): BatchNorm partial
                               // sums [wave of the grid][2][cout], shifted by the bias
 };
 
-template <int MT, int NT, int ACT, int PREC, int WITH_STATS = 0>
+// IO16 (PREC 2 only, VAD_PREC_BF16S): input and output tensors are bf16 in memory - a lane's 8 channels of a k-step are ONE
+// 16-byte load that IS the MFMA fragment (no conversion), the epilogue rounds to bf16.  UPS 0: the same GEMM without the
+// 2x2 scatter = a 1x1 convolution (N index = co; the data gradient of a transposed convolution over the space-to-depth
+// gradient, and VideoAutoencoder.proj).
+template <int MT, int NT, int ACT, int PREC, int WITH_STATS = 0, int IO16 = 0, int UPS = 1>
 __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) void convt2x2_pkernel(ConvTP2 p) {
+    static_assert(!IO16 || PREC == 2, "bf16 tensors go with bf16 operands");
+    constexpr unsigned ES = IO16 ? 2u : 4u;
+    constexpr int NQ = UPS ? 4 : 1;
     constexpr int KS = PREC ? 16 : 8;
     // BatchNorm statistics from the accumulators (as in conv_pkernel.h): a wave's items change their channel tile, so one
     // accumulator pair per channel tile (at most 4: cout <= 128), picked by a wave-uniform branch; two levels (item, wave)
@@ -42,11 +51,12 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
     const int nk = p.cin / KS;
     const unsigned wstep = (unsigned)p.cout * (PREC ? 64u : 32u);      // bytes per (q, k-step) slab
     const unsigned wq = (unsigned)nk * wstep;                          // bytes per quadrant
-    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 4u * wq);
+    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, (unsigned)NQ * wq);
     const __amdgpu_buffer_rsrc_t rz = vad_rsrc(p.w, 0u);              // zero-sized: every load through it returns 0 at once
-    const unsigned in_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u;
-    const int oh = 2 * H, ow = 2 * W;
-    const unsigned out_bytes = (unsigned)(oh * ow) * (unsigned)p.cout * 4u;
+    const unsigned fpix = (!UPS && p.frame_pix) ? (unsigned)p.frame_pix : (unsigned)(H * W);
+    const unsigned in_bytes = fpix * (unsigned)p.cin * ES;
+    const int oh = UPS ? 2 * H : H, ow = UPS ? 2 * W : W;
+    const unsigned out_bytes = (UPS ? (unsigned)(oh * ow) : fpix) * (unsigned)p.cout * ES;
     const int prow = li >> 4, pcol = li & 15;                         // A-operand pixel of this lane inside an M-tile
 
     for (unsigned item = __builtin_amdgcn_readfirstlane(gw); item < p.nitems; item += nw) {
@@ -55,15 +65,15 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
         const int x0 = (r0 % p.tiles_x) * 16; r0 /= p.tiles_x;
         const int y0 = (r0 % p.tiles_y) * (2 * MT);
         const int n = r0 / p.tiles_y;
-        const __amdgpu_buffer_rsrc_t ra = vad_rsrc(p.in + (size_t)n * p.in_fs, in_bytes);
-        const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
+        const __amdgpu_buffer_rsrc_t ra = vad_rsrc((const char*)p.in + (size_t)n * p.in_fs * ES, in_bytes);
+        const __amdgpu_buffer_rsrc_t ro = vad_rsrc((const char*)p.out + (size_t)n * p.out_fs * ES, out_bytes);
 
         // per-lane offsets: A row of each M-tile (VAD_OOB outside the image -> zeros), B row / bias of each N-tile
         unsigned ao[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int y = y0 + 2 * mt + prow, x = x0 + pcol;
-            ao[mt] = (y < H && x < W) ? (unsigned)(__mul24(__mul24(y, W) + x, p.cin) + (PREC ? 8 : 4) * lh) * 4u : VAD_OOB;
+            ao[mt] = (y < H && x < W) ? (unsigned)(__mul24(__mul24(y, W) + x, p.cin) + (PREC ? 8 : 4) * lh) * ES : VAD_OOB;
         }
         unsigned bo[NT];
         int qd[NT], co[NT];
@@ -92,8 +102,8 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
 #define CT_LOAD(buf, ks)                                                                          \
     {                                                                                             \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                       \
-            a0[buf][mt] = vad_bload4(ra_, ao[mt], (unsigned)(ks) * 64u);                           \
-            a1[buf][mt] = vad_bload4(ra_, ao[mt], (unsigned)(ks) * 64u + 16u);                     \
+            a0[buf][mt] = vad_bload4(ra_, ao[mt], (unsigned)(ks) * 16u * ES);                      \
+            if constexpr (!IO16) a1[buf][mt] = vad_bload4(ra_, ao[mt], (unsigned)(ks) * 64u + 16u); \
         }                                                                                         \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                       \
             bh[buf][nt] = __builtin_bit_cast(f16x8, vad_bload4(rw_, bo[nt], (unsigned)(ks) * wstep)); \
@@ -116,11 +126,16 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             f16x8 ah, al;
+                            if constexpr (IO16) {
+                                ah = __builtin_bit_cast(f16x8, a0[u][mt]);       // 8 bf16 channels as loaded
+                                al = ah;                                          // (unused by the bf16 MFMA)
+                            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                _Float16 h_, l_;
-                                vad_split_p<PREC>(a0[u][mt][e], h_, l_); ah[e] = h_; al[e] = l_;
-                                vad_split_p<PREC>(a1[u][mt][e], h_, l_); ah[4 + e] = h_; al[4 + e] = l_;
+                                for (int e = 0; e < 4; ++e) {
+                                    _Float16 h_, l_;
+                                    vad_split_p<PREC>(a0[u][mt][e], h_, l_); ah[e] = h_; al[e] = l_;
+                                    vad_split_p<PREC>(a1[u][mt][e], h_, l_); ah[4 + e] = h_; al[4 + e] = l_;
+                                }
                             }
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
@@ -173,13 +188,13 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
 
         // epilogue: D row = (r&3) + 8*(r>>2) + 4*lh -> pixel (prow = row>>4, pcol = row&15) of the M-tile
         const bool full = (y0 + 2 * MT <= H) && (x0 + 16 <= W);
-        const unsigned erow = (unsigned)__mul24(ow, p.cout) * 4u, ecol = (unsigned)p.cout * 4u;
+        const unsigned erow = (unsigned)__mul24(ow, p.cout) * ES, ecol = (unsigned)p.cout * ES;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int qa = qd[nt] >> 1, qb = qd[nt] & 1;
+            const int qa = UPS ? qd[nt] >> 1 : 0, qb = UPS ? qd[nt] & 1 : 0;
             // lane part: column 4*lh of the tile, this lane's channel; uniform part added per element below
-            constexpr int sc = 2;
-            const unsigned vlane = (unsigned)(__mul24(sc * 4 * lh, p.cout) + co[nt]) * 4u;
+            constexpr int sc = UPS ? 2 : 1;
+            const unsigned vlane = (unsigned)(__mul24(sc * 4 * lh, p.cout) + co[nt]) * ES;
             const unsigned ubase = ((unsigned)__mul24(sc * y0 + qa, ow) + (unsigned)(sc * x0 + qb)) * ecol;
             float ts = 0.f, tq = 0.f;
 #pragma unroll
@@ -189,7 +204,8 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
                     const int dy = 2 * mt + (r >> 3), dx = (r & 3) + 8 * ((r >> 2) & 1);      // + 4*lh in the lane part
                     const bool ok = full || ((y0 + dy) < H && (x0 + dx + 4 * lh) < W);
                     const unsigned so = ubase + (unsigned)(sc * dy) * erow + (unsigned)(sc * dx) * ecol;
-                    vad_bstore1(vad_act(acc[mt][nt][r], ACT), ro, ok ? vlane : VAD_OOB, so);
+                    if constexpr (IO16) vad_bstore_h(vad_f_bf16(vad_act(acc[mt][nt][r], ACT)), ro, ok ? vlane : VAD_OOB, so);
+                    else vad_bstore1(vad_act(acc[mt][nt][r], ACT), ro, ok ? vlane : VAD_OOB, so);
                     if constexpr (STATS) {
                         if (p.stats) {   // (uniform)
                             const float d = ok ? acc[mt][nt][r] - bvv[nt] : 0.f;

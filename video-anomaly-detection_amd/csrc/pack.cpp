@@ -305,7 +305,9 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
         const int cout = s.cout == L.latent_p && (li == 6 || li == 7) ? latent : s.cout;
         if (s.kind == LK_CONV_C3) rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b);
         else if (s.kind == LK_CONV) rc = pack_conv3x3_slot(w, b, bn, cout, cin, s, precision, out);
-        else rc = pack_convt2x2_slot(w, b, bn, cin, cout, s, precision, out);
+        // dec4.0 (li 14) is always packed for - and run on - the exact-fp32 path: it shares ONE kernel with dec4.3 and the
+        // score (dec4_fused.hip), HBM-bound in either arithmetic, and that kernel's first GEMM is exact fp32
+        else rc = pack_convt2x2_slot(w, b, bn, cin, cout, s, li == 14 ? VAD_PREC_FP32 : precision, out);
         pi += 6;
     }
     if (rc == VAD_OK && pi != nparams) return vad_fail(VAD_ERR_ARG, "img_pack: consumed %d of %d parameters", pi, nparams);

@@ -43,7 +43,8 @@ __device__ __forceinline__ void block_chan_reduce(f32x4 s0, f32x4 s1, int c, flo
 // pivot (nullable = 0) is a per-channel shift applied BEFORE squaring: BatchNorm statistics pass the channel's first
 // sample, so the variance is not formed as E[x^2] - mean^2 of the raw values (that cancels catastrophically in fp32 when
 // |mean| >> std: measured 5e-5 relative error in 1/std, enough to flip ReLU decisions in the layers that follow).
-__global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long long npix, int c, long long chunk, const float* pivot,
+template <typename T>
+__global__ __launch_bounds__(256) void chan_sums_kernel(const T* y, long long npix, int c, long long chunk, const float* pivot,
                                                         float* ws) {
     const int tid = threadIdx.x, cg = c >> 2, rows = 256 / cg, row = tid / cg, c4 = tid - row * cg;
     const long long p0 = (long long)blockIdx.x * chunk, p1 = (p0 + chunk < npix) ? p0 + chunk : npix;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long lon
         for (; p + 3 * rows < p1; p += 4 * rows) {
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)&y[(p + (long long)u * rows) * c + 4 * c4];
+            for (int u = 0; u < 4; ++u) v[u] = vad_io4<T>::ld(&y[(p + (long long)u * rows) * c + 4 * c4]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const f32x4 d = v[u] - pv;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const float* y, long lon
             }
         }
         for (; p < p1; p += rows) {
-            const f32x4 v = *(const f32x4*)&y[p * c + 4 * c4] - pv;
+            const f32x4 v = vad_io4<T>::ld(&y[p * c + 4 * c4]) - pv;
             s0 += v;
             s1 += v * v;
         }
@@ -123,9 +124,9 @@ __global__ __launch_bounds__(256) void chan_finalize_kernel(const float* ws, int
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm forward
-struct BnFwdP {
-    const float* y; const float* stats; const float* gamma; const float* beta;
-    float* out; long long out_fs; int out_ps, t, b;
+struct BnFwdP {     // y / out: fp32 or bf16 (the kernel's storage type)
+    const void* y; const float* stats; const float* gamma; const float* beta;
+    void* out; long long out_fs; int out_ps, t, b;
     int n, h, w, c, act, pool;
     long long total;      // n * oh * ow * c/4
 };
@@ -142,7 +143,9 @@ __device__ __forceinline__ f32x4 bn_apply(f32x4 y, f32x4 mean, f32x4 invstd, f32
     return v;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
+    typedef vad_io4<T> io;
     const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
         const int c4 = (int)(idx % cg);
@@ -152,30 +155,30 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
         const int n = (int)(pix / oh);
         const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
         const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
-        const float* src = p.y + (size_t)n * p.h * p.w * p.c + 4 * c4;
+        const T* src = (const T*)p.y + (size_t)n * p.h * p.w * p.c + 4 * c4;
         f32x4 v;
         if (p.pool) {
             const size_t o = ((size_t)(2 * y) * p.w + 2 * x) * p.c;
-            v = bn_apply(*(const f32x4*)&src[o], mean, invstd, gamma, beta, p.act);
-            const f32x4 v1 = bn_apply(*(const f32x4*)&src[o + p.c], mean, invstd, gamma, beta, p.act);
-            const f32x4 v2 = bn_apply(*(const f32x4*)&src[o + (size_t)p.w * p.c], mean, invstd, gamma, beta, p.act);
-            const f32x4 v3 = bn_apply(*(const f32x4*)&src[o + (size_t)p.w * p.c + p.c], mean, invstd, gamma, beta, p.act);
+            v = bn_apply(io::ld(&src[o]), mean, invstd, gamma, beta, p.act);
+            const f32x4 v1 = bn_apply(io::ld(&src[o + p.c]), mean, invstd, gamma, beta, p.act);
+            const f32x4 v2 = bn_apply(io::ld(&src[o + (size_t)p.w * p.c]), mean, invstd, gamma, beta, p.act);
+            const f32x4 v3 = bn_apply(io::ld(&src[o + (size_t)p.w * p.c + p.c]), mean, invstd, gamma, beta, p.act);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(v[e], v1[e]), fmaxf(v2[e], v3[e]));
         } else {
-            v = bn_apply(*(const f32x4*)&src[((size_t)y * p.w + x) * p.c], mean, invstd, gamma, beta, p.act);
+            v = bn_apply(io::ld(&src[((size_t)y * p.w + x) * p.c]), mean, invstd, gamma, beta, p.act);
         }
-        *(f32x4*)&p.out[view_frame(n, p.t, p.b) * p.out_fs + ((size_t)y * ow + x) * p.out_ps + 4 * c4] = v;
+        io::st((T*)p.out + view_frame(n, p.t, p.b) * p.out_fs + ((size_t)y * ow + x) * p.out_ps + 4 * c4, v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm backward
-struct BnBwdP {
-    const float* y; const float* stats; const float* gamma; const float* beta;
-    const float* dout; long long dout_fs; int dout_ps, t, b;
+struct BnBwdP {     // y / dout / dy: fp32 or bf16 (the kernels' storage type)
+    const void* y; const float* stats; const float* gamma; const float* beta;
+    const void* dout; long long dout_fs; int dout_ps, t, b;
     float* ws;            // pass A: partial sums
     const float* k;       // pass B: {sum(dz)/M, sum(dz*xhat)/M}
-    float* dy;            // pass B: gradient of the conv output, dense NHWC or space-to-depth
+    void* dy;             // pass B: gradient of the conv output, dense NHWC or space-to-depth
     int s2d;
     int n, h, w, c, act, pool;
     long long opix, chunk;   // pooled-resolution pixels (n*oh*ow), per block
@@ -208,7 +211,11 @@ __device__ __forceinline__ Routed bn_route(const float y4[4], int nwin, float me
 }
 
 // pass A: per-channel partial sums of dz and dz*xhat (dz itself is never stored; pass B re-derives it)
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
+    typedef vad_io4<T> io;
+    const T* py = (const T*)p.y;
+    const T* pdout = (const T*)p.dout;
     const int tid = threadIdx.x, cg = p.c >> 2, rows = 256 / cg, row = tid / cg, c4 = tid - row * cg;
     const int oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w, nwin = p.pool ? 4 : 1;
     const long long p0 = (long long)blockIdx.x * p.chunk, p1 = (p0 + p.chunk < p.opix) ? p0 + p.chunk : p.opix;
@@ -218,11 +225,11 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
         const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
         for (long long q = p0 + row; q < p1; q += rows) {
             const int x = (int)(q % ow), y = (int)((q / ow) % oh), n = (int)(q / ((long long)ow * oh));
-            const f32x4 g = *(const f32x4*)&p.dout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4];
+            const f32x4 g = io::ld(&pdout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4]);
             const size_t o0 = (size_t)n * p.h * p.w * p.c + 4 * c4 + (p.pool ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
             f32x4 yv[4];
-            yv[0] = *(const f32x4*)&p.y[o0];
-            if (p.pool) { yv[1] = *(const f32x4*)&p.y[o0 + p.c]; yv[2] = *(const f32x4*)&p.y[o0 + (size_t)p.w * p.c]; yv[3] = *(const f32x4*)&p.y[o0 + (size_t)p.w * p.c + p.c]; }
+            yv[0] = io::ld(&py[o0]);
+            if (p.pool) { yv[1] = io::ld(&py[o0 + p.c]); yv[2] = io::ld(&py[o0 + (size_t)p.w * p.c]); yv[3] = io::ld(&py[o0 + (size_t)p.w * p.c + p.c]); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
@@ -238,7 +245,12 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
 
 // pass B: dy = gamma * invstd * (dz - k1 - xhat * k2) for every element of the window (dz = 0 off the routed element);
 // s2d writes the space-to-depth view [n][h/2][w/2][4][c] (the operand layout of the transposed convolution's gradients)
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
+    typedef vad_io4<T> io;
+    const T* py = (const T*)p.y;
+    const T* pdout = (const T*)p.dout;
+    T* pdy = (T*)p.dy;
     const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w, nwin = p.pool ? 4 : 1;
     const long long total = p.opix * cg;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -248,13 +260,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
         const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
         const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
         const f32x4 k1 = *(const f32x4*)&p.k[4 * c4], k2 = *(const f32x4*)&p.k[p.c + 4 * c4];
-        const f32x4 g = *(const f32x4*)&p.dout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4];
+        const f32x4 g = io::ld(&pdout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4]);
         const size_t fb = (size_t)n * p.h * p.w * p.c + 4 * c4;
         const size_t o0 = fb + (p.pool ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
         const size_t off[4] = {o0, o0 + p.c, o0 + (size_t)p.w * p.c, o0 + (size_t)p.w * p.c + p.c};
         f32x4 yv[4], out[4];
-        yv[0] = *(const f32x4*)&p.y[off[0]];
-        if (p.pool) { yv[1] = *(const f32x4*)&p.y[off[1]]; yv[2] = *(const f32x4*)&p.y[off[2]]; yv[3] = *(const f32x4*)&p.y[off[3]]; }
+        yv[0] = io::ld(&py[off[0]]);
+        if (p.pool) { yv[1] = io::ld(&py[off[1]]); yv[2] = io::ld(&py[off[2]]); yv[3] = io::ld(&py[off[3]]); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
@@ -269,75 +281,80 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
         }
         if (p.s2d) {          // no-pool layers only (checked on the host): pixel (y, x) of an h x w map
             const size_t o = (((size_t)n * (p.h / 2) + y / 2) * (p.w / 2) + x / 2) * 4 * p.c + ((y & 1) * 2 + (x & 1)) * p.c + 4 * c4;
-            *(f32x4*)&p.dy[o] = out[0];
+            io::st(&pdy[o], out[0]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k < nwin) *(f32x4*)&p.dy[off[k]] = out[k];
+                if (k < nwin) io::st(&pdy[off[k]], out[k]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ ConvLSTM pointwise
-struct LstmFwdP {
-    float* z;                 // [npix][4*hid]: pre-activations in, activated gates (i, f, g, o) out
+struct LstmFwdP {   // z / h1 / h2: fp32 or bf16 (the kernel's storage type); the cell state is always fp32
+    void* z;                  // [npix][4*hid]: pre-activations in, activated gates (i, f, g, o) out
     const float* c_prev;      // [npix][hid] or null (zeros)
     float* c_out;             // [npix][hid]
-    float* h1; long long h1_fs; int h1_ps;     // destination 1 of h (frame b, pixel, channel) or null
-    float* h2; long long h2_fs; int h2_ps;     // destination 2 or null
+    void* h1; long long h1_fs; int h1_ps;      // destination 1 of h (frame b, pixel, channel) or null
+    void* h2; long long h2_fs; int h2_ps;      // destination 2 or null
     int hw, hid;
     long long total;          // nb * hw * hid/4
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(LstmFwdP p) {
+    typedef vad_io4<T> io;
     const int hg = p.hid >> 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
         const int j4 = (int)(idx % hg);
         const long long pix = idx / hg;
-        float* zz = p.z + pix * 4 * p.hid + 4 * j4;
-        f32x4 gi = *(f32x4*)&zz[0], gf = *(f32x4*)&zz[p.hid], gg = *(f32x4*)&zz[2 * p.hid], go = *(f32x4*)&zz[3 * p.hid];
+        T* zz = (T*)p.z + pix * 4 * p.hid + 4 * j4;
+        f32x4 gi = io::ld(&zz[0]), gf = io::ld(&zz[p.hid]), gg = io::ld(&zz[2 * p.hid]), go = io::ld(&zz[3 * p.hid]);
         f32x4 cp = {0.f, 0.f, 0.f, 0.f};
         if (p.c_prev) cp = *(const f32x4*)&p.c_prev[pix * p.hid + 4 * j4];
         f32x4 cn, hn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            gi[e] = vad_sigmoid(gi[e]); gf[e] = vad_sigmoid(gf[e]); gg[e] = vad_tanh(gg[e]); go[e] = vad_sigmoid(go[e]);
+            // (bf16 storage: the state update uses the gate values AS STORED, the ones the backward will read)
+            gi[e] = io::round(vad_sigmoid(gi[e])); gf[e] = io::round(vad_sigmoid(gf[e])); gg[e] = io::round(vad_tanh(gg[e])); go[e] = io::round(vad_sigmoid(go[e]));
             cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
             hn[e] = go[e] * vad_tanh(cn[e]);
         }
-        *(f32x4*)&zz[0] = gi; *(f32x4*)&zz[p.hid] = gf; *(f32x4*)&zz[2 * p.hid] = gg; *(f32x4*)&zz[3 * p.hid] = go;
+        io::st(&zz[0], gi); io::st(&zz[p.hid], gf); io::st(&zz[2 * p.hid], gg); io::st(&zz[3 * p.hid], go);
         *(f32x4*)&p.c_out[pix * p.hid + 4 * j4] = cn;
         const long long b = pix / p.hw, q = pix - b * p.hw;
-        if (p.h1) *(f32x4*)&p.h1[b * p.h1_fs + q * p.h1_ps + 4 * j4] = hn;
-        if (p.h2) *(f32x4*)&p.h2[b * p.h2_fs + q * p.h2_ps + 4 * j4] = hn;
+        if (p.h1) io::st((T*)p.h1 + b * p.h1_fs + q * p.h1_ps + 4 * j4, hn);
+        if (p.h2) io::st((T*)p.h2 + b * p.h2_fs + q * p.h2_ps + 4 * j4, hn);
     }
 }
 
-struct LstmBwdP {
-    const float* gates;       // [npix][4*hid] activated
+struct LstmBwdP {   // gates / dh1 / dh2 / dz: fp32 or bf16 (the kernel's storage type); cell states and their gradients fp32
+    const void* gates;        // [npix][4*hid] activated
     const float* c_prev;      // null = zeros
     const float* c;           // [npix][hid]
-    const float* dh1; long long dh1_fs; int dh1_ps;   // gradient sources for h (either may be null)
-    const float* dh2; long long dh2_fs; int dh2_ps;
+    const void* dh1; long long dh1_fs; int dh1_ps;    // gradient sources for h (either may be null)
+    const void* dh2; long long dh2_fs; int dh2_ps;
     const float* dc_next;     // null = zeros
-    float* dz;                // [npix][4*hid]
+    void* dz;                 // [npix][4*hid]
     float* dc_prev;           // [npix][hid] (may alias dc_next)
     int hw, hid;
     long long total;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(LstmBwdP p) {
+    typedef vad_io4<T> io;
     const int hg = p.hid >> 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
         const int j4 = (int)(idx % hg);
         const long long pix = idx / hg, b = pix / p.hw, q = pix - b * p.hw;
-        const float* gz = p.gates + pix * 4 * p.hid + 4 * j4;
-        const f32x4 gi = *(const f32x4*)&gz[0], gf = *(const f32x4*)&gz[p.hid], gg = *(const f32x4*)&gz[2 * p.hid], go = *(const f32x4*)&gz[3 * p.hid];
+        const T* gz = (const T*)p.gates + pix * 4 * p.hid + 4 * j4;
+        const f32x4 gi = io::ld(&gz[0]), gf = io::ld(&gz[p.hid]), gg = io::ld(&gz[2 * p.hid]), go = io::ld(&gz[3 * p.hid]);
         const f32x4 c = *(const f32x4*)&p.c[pix * p.hid + 4 * j4];
         f32x4 cp = {0.f, 0.f, 0.f, 0.f}, dh = cp, dcn = cp;
         if (p.c_prev) cp = *(const f32x4*)&p.c_prev[pix * p.hid + 4 * j4];
-        if (p.dh1) dh += *(const f32x4*)&p.dh1[b * p.dh1_fs + q * p.dh1_ps + 4 * j4];
-        if (p.dh2) dh += *(const f32x4*)&p.dh2[b * p.dh2_fs + q * p.dh2_ps + 4 * j4];
+        if (p.dh1) dh += io::ld((const T*)p.dh1 + b * p.dh1_fs + q * p.dh1_ps + 4 * j4);
+        if (p.dh2) dh += io::ld((const T*)p.dh2 + b * p.dh2_fs + q * p.dh2_ps + 4 * j4);
         if (p.dc_next) dcn = *(const f32x4*)&p.dc_next[pix * p.hid + 4 * j4];
         f32x4 di, df, dg, dgo, dcp;
 #pragma unroll
@@ -350,8 +367,8 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(LstmBwdP p) {
             dg[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
             dcp[e] = dc * gf[e];
         }
-        float* dzp = p.dz + pix * 4 * p.hid + 4 * j4;
-        *(f32x4*)&dzp[0] = di; *(f32x4*)&dzp[p.hid] = df; *(f32x4*)&dzp[2 * p.hid] = dg; *(f32x4*)&dzp[3 * p.hid] = dgo;
+        T* dzp = (T*)p.dz + pix * 4 * p.hid + 4 * j4;
+        io::st(&dzp[0], di); io::st(&dzp[p.hid], df); io::st(&dzp[2 * p.hid], dg); io::st(&dzp[3 * p.hid], dgo);
         *(f32x4*)&p.dc_prev[pix * p.hid + 4 * j4] = dcp;
     }
 }
@@ -362,8 +379,8 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(LstmBwdP p) {
 // One wave owns a 32 (ci) x 32*NT (col) tile of every tap and a slice of the image rows (split-K); each
 // v_mfma_f32_32x32x2_f32 consumes two horizontally adjacent pixels: lane (li, lh) feeds A[pixel lh][ci li] and
 // G[pixel lh][col li], both 128-byte coalesced rows of the NHWC tensors.  Partials go to ws[split][tap][ci][col].
-struct WgradP {
-    const float* a; const float* g; float* ws;
+struct WgradP {       // a / g: fp32, or bf16 for the IO16 form of the bf16 kernel
+    const void* a; const void* g; float* ws;
     int n, h, w, cin, ncols;
     int ci_tiles, col_groups, splits, rows_per_split;
     unsigned nitems;
@@ -416,8 +433,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
         const bool valid = lrow < r1;                                                                                  \
         if (valid && lx == 0) {                                                                                        \
             const int n_ = lrow / H, ly = lrow - n_ * H;                                                               \
-            const float* fa = p.a + (size_t)n_ * H * W * p.cin;                                                        \
-            rg = vad_rsrc(p.g + (size_t)n_ * H * W * p.ncols, g_bytes);                                                \
+            const float* fa = (const float*)p.a + (size_t)n_ * H * W * p.cin;                                          \
+            rg = vad_rsrc((const float*)p.g + (size_t)n_ * H * W * p.ncols, g_bytes);                                  \
             _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                           \
                 const int yy = ly + (NR == 3 ? i - 1 : 0);                                                             \
                 const bool rok = yy >= 0 && yy < H;                                                                    \
@@ -487,8 +504,19 @@ typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned wg_pk(float a, float b) { return __builtin_bit_cast(unsigned, wg_bf16x2{(__bf16)a, (__bf16)b}); }
 __device__ __forceinline__ wg_bf16x8 wg_frag(unsigned a, unsigned b, unsigned c, unsigned d) { return __builtin_bit_cast(wg_bf16x8, u32x4{a, b, c, d}); }
 
-template <int TAPS, int NT>
+// IO16: both operands are ALREADY bf16 in memory (VAD_PREC_BF16S): the same access pattern with 16-bit loads (half the bytes
+// through L1) and a pair of values is packed with one v_perm / v_lshl_or instead of a conversion.
+template <int TAPS, int NT, int IO16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
+    constexpr unsigned ES = IO16 ? 2u : 4u;
+    auto LD = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) -> unsigned {     // raw element: fp32 bits or a zero-extended bf16
+        if constexpr (IO16) return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
+        else return __builtin_bit_cast(unsigned, vad_bload1(r, voff, soff));
+    };
+    auto PK = [](unsigned a, unsigned b) -> unsigned {
+        if constexpr (IO16) return a | (b << 16);
+        else return wg_pk(__uint_as_float(a), __uint_as_float(b));
+    };
     const int lane = threadIdx.x & 63, li = lane & 31, kb = lane >> 5;
     unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= p.nitems) return;
@@ -497,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
     const int split = item / p.col_groups;
     const int H = p.h, W = p.w, total_rows = p.n * H;
     const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
-    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * 4u;
+    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * ES, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * ES;
     f32x16 acc[TAPS][NT];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -506,13 +534,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.f;
     constexpr int NR = TAPS == 9 ? 3 : 1, HALO = TAPS == 9 ? 1 : 0, NE = 8 + 2 * HALO;
-    const unsigned pix_a = (unsigned)(p.cin * 4), pix_g = (unsigned)(p.ncols * 4);
-    const unsigned lane_a = (unsigned)((ct * 32 + li) * 4), lane_g = (unsigned)((cgp * NT * 32 + li) * 4);
+    const unsigned pix_a = (unsigned)p.cin * ES, pix_g = (unsigned)p.ncols * ES;
+    const unsigned lane_a = (unsigned)(ct * 32 + li) * ES, lane_g = (unsigned)(cgp * NT * 32 + li) * ES;
     const __amdgpu_buffer_rsrc_t rzero = vad_rsrc(p.a, 0);
     for (int row = r0; row < r1; ++row) {
         const int n_ = row / H, ly = row - n_ * H;
-        const float* fa = p.a + (size_t)n_ * H * W * p.cin;
-        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n_ * H * W * p.ncols, g_bytes);
+        const char* fa = (const char*)p.a + (size_t)n_ * H * W * p.cin * ES;
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const char*)p.g + (size_t)n_ * H * W * p.ncols * ES, g_bytes);
         const unsigned gbase = (unsigned)(ly * W) * pix_g;
         __amdgpu_buffer_rsrc_t rrow[NR];
         unsigned rbase[NR];
@@ -526,33 +554,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
         for (int lx = 0; lx < W; lx += 16) {
             const int px0 = lx + 8 * kb;
             // every load of the step first (38 in flight), then the conversions and the MFMAs
-            float gv[NT][8], av[NR][NE];
+            unsigned gv[NT][8], av[NR][NE];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int x = px0 + e;
                 const unsigned off = x < W ? lane_g + (unsigned)x * pix_g : VAD_OOB;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) gv[nt][e] = vad_bload1(rg, off, gbase + (unsigned)(nt * 128));
+                for (int nt = 0; nt < NT; ++nt) gv[nt][e] = LD(rg, off, gbase + (unsigned)nt * 32u * ES);
             }
 #pragma unroll
             for (int i = 0; i < NR; ++i)
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
                     const int x = px0 + e - HALO;
-                    av[i][e] = vad_bload1(rrow[i], (unsigned)x < (unsigned)W ? lane_a + (unsigned)x * pix_a : VAD_OOB, rbase[i]);
+                    av[i][e] = LD(rrow[i], (unsigned)x < (unsigned)W ? lane_a + (unsigned)x * pix_a : VAD_OOB, rbase[i]);
                 }
             wg_bf16x8 gb[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                gb[nt] = wg_frag(wg_pk(gv[nt][0], gv[nt][1]), wg_pk(gv[nt][2], gv[nt][3]), wg_pk(gv[nt][4], gv[nt][5]), wg_pk(gv[nt][6], gv[nt][7]));
+                gb[nt] = wg_frag(PK(gv[nt][0], gv[nt][1]), PK(gv[nt][2], gv[nt][3]), PK(gv[nt][4], gv[nt][5]), PK(gv[nt][6], gv[nt][7]));
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 if constexpr (TAPS == 9) {
                     unsigned pe[5], po[4];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) pe[k] = wg_pk(av[i][2 * k], av[i][2 * k + 1]);
+                    for (int k = 0; k < 5; ++k) pe[k] = PK(av[i][2 * k], av[i][2 * k + 1]);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) po[k] = wg_pk(av[i][2 * k + 1], av[i][2 * k + 2]);
+                    for (int k = 0; k < 4; ++k) po[k] = PK(av[i][2 * k + 1], av[i][2 * k + 2]);
                     const wg_bf16x8 f0 = wg_frag(pe[0], pe[1], pe[2], pe[3]);      // dx = 0: pixels x-1 .. x+6
                     const wg_bf16x8 f1 = wg_frag(po[0], po[1], po[2], po[3]);      // dx = 1: pixels x   .. x+7
                     const wg_bf16x8 f2 = wg_frag(pe[1], pe[2], pe[3], pe[4]);      // dx = 2: pixels x+1 .. x+8
@@ -563,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
                         acc[i * 3 + 2][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, gb[nt], acc[i * 3 + 2][nt], 0, 0, 0);
                     }
                 } else {
-                    const wg_bf16x8 f = wg_frag(wg_pk(av[0][0], av[0][1]), wg_pk(av[0][2], av[0][3]), wg_pk(av[0][4], av[0][5]), wg_pk(av[0][6], av[0][7]));
+                    const wg_bf16x8 f = wg_frag(PK(av[0][0], av[0][1]), PK(av[0][2], av[0][3]), PK(av[0][4], av[0][5]), PK(av[0][6], av[0][7]));
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, gb[nt], acc[0][nt], 0, 0, 0);
                 }
@@ -582,13 +610,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
 }
 
 // First layer (input NCHW, 3 channels): M index k = c*9 + tap (27, padded to 32), A gathered from the input planes.
-struct WgradC3P {
-    const float* x; const float* g; float* ws;
+struct WgradC3P {     // g: fp32 or bf16 (the kernels' storage type)
+    const float* x; const void* g; float* ws;
     int n, h, w, cout, splits, rows_per_split;
     unsigned nitems;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
+    constexpr unsigned ES = sizeof(T);
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= p.nitems) return;
@@ -598,7 +628,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
     const int H = p.h, W = p.w, total_rows = p.n * H;
     const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
     const int c = li / 9, tap = li - c * 9, dy = tap / 3 - 1, dx = tap % 3 - 1;
-    const unsigned x_bytes = (unsigned)(3 * H * W) * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.cout * 4u;
+    const unsigned x_bytes = (unsigned)(3 * H * W) * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.cout * ES;
     // four independent accumulator chains (one 32x32x2 MFMA each per 8 pixels) so the matrix pipe never waits on its own
     // result; the 8 operand loads of a group are issued before its MFMAs
     constexpr int U = 4;
@@ -610,7 +640,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
     for (int row = r0; row < r1; ++row) {
         const int n = row / H, y = row - n * H;
         const __amdgpu_buffer_rsrc_t rx = vad_rsrc(p.x + (size_t)n * 3 * H * W, x_bytes);
-        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n * H * W * p.cout, g_bytes);
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const T*)p.g + (size_t)n * H * W * p.cout, g_bytes);
         const int yy = y + dy;
         const bool rowok = li < 27 && yy >= 0 && yy < H;
         for (int x = 0; x < W; x += 2 * U) {
@@ -618,7 +648,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int px = x + 2 * u + lh, xx = px + dx;
-                bv[u] = vad_bload1(rg, px < W ? (unsigned)(((y * W + px) * p.cout + cgp * 32 + li) * 4) : VAD_OOB, 0);
+                bv[u] = vad_bload_e<T>(rg, px < W ? (unsigned)((y * W + px) * p.cout + cgp * 32 + li) * ES : VAD_OOB, 0);
                 av[u] = vad_bload1(rx, (rowok && xx >= 0 && xx < W && px < W) ? (unsigned)(((c * H + yy) * W + xx) * 4) : VAD_OOB, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -641,8 +671,9 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
 // requested one row ahead, column 0 of the data at float 4 so that the writes stay 16-byte aligned, zero columns at 3 and
 // 4 + W, rows outside the image written as zeros); an A value is then one ds_read_b32 at lane constant + column.  LDS
 // operations of one wave execute in order, and no other wave touches the region: no barrier.  W % 8 == 0 (host-selected).
-template <int MAXQ>      // 16-byte chunks per lane and staged row: W <= 256 * MAXQ (the staging registers set the occupancy)
+template <int MAXQ, typename T>      // 16-byte chunks per lane and staged row: W <= 256 * MAXQ (the staging registers set the occupancy)
 __global__ __launch_bounds__(256) void conv_c3_wgrad_lds_kernel(WgradC3P p) {
+    constexpr unsigned ES = sizeof(T);
     extern __shared__ __attribute__((aligned(16))) float dyn_xs[];
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
     unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
@@ -655,8 +686,8 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_lds_kernel(WgradC3P p) {
     const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
     const int c = li < 27 ? li / 9 : 0, tap = li < 27 ? li - (li / 9) * 9 : 0, dy = tap / 3 - 1, dx = tap % 3 - 1;   // rows k >= 27 of the
     const int lb = (c * 3 + dy + 1) * RS + 4 + dx + lh;          // result are dropped by the reduction: they may read anything finite
-    const unsigned g_bytes = (unsigned)(H * W) * (unsigned)p.cout * 4u;
-    const unsigned gl = (unsigned)(lh * p.cout + cgp * 32 + li) * 4u;
+    const unsigned g_bytes = (unsigned)(H * W) * (unsigned)p.cout * ES;
+    const unsigned gl = (unsigned)(lh * p.cout + cgp * 32 + li) * ES;
     constexpr int U = 4;
     f32x16 acc[U];
 #pragma unroll
@@ -696,15 +727,15 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_lds_kernel(WgradC3P p) {
         store_row();                                             // (behind every read of the previous row: in order)
         if (row + 1 < r1) fetch_row(row + 1);                    // in flight during this row's groups
         const int n = row / H, y = row - n * H;
-        const __amdgpu_buffer_rsrc_t rg = vad_rsrc(p.g + (size_t)n * H * W * p.cout, g_bytes);
-        const unsigned grow = (unsigned)(y * W) * (unsigned)p.cout * 4u;
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const T*)p.g + (size_t)n * H * W * p.cout, g_bytes);
+        const unsigned grow = (unsigned)(y * W) * (unsigned)p.cout * ES;
         // g values one group ahead, in two alternating register sets (unconditional: behind the row's last group the request
         // goes to that group again - a load under `if` would make hipcc wait for it in front of the MFMAs)
         float bva[U], bvb[U];
         auto load_g = [&](int x, float (&b_)[U]) {
             const int xc = __builtin_amdgcn_readfirstlane(x < W ? x : W - 2 * U);
 #pragma unroll
-            for (int u = 0; u < U; ++u) b_[u] = vad_bload1(rg, gl, grow + (unsigned)((xc + 2 * u) * p.cout) * 4u);
+            for (int u = 0; u < U; ++u) b_[u] = vad_bload_e<T>(rg, gl, grow + (unsigned)((xc + 2 * u) * p.cout) * ES);
         };
         auto mma = [&](int x, const float (&b_)[U]) {
             float av[U];
@@ -773,15 +804,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
 // train_video.py:54-55): per input pixel the 4x3 outputs, their squared error against x, d(pre-activation) and the
 // gradient with respect to the 32 input channels.  dpre is also written as the 32-column GEMM operand of the weight
 // gradient (columns q*3+c, 12..31 zero).
-struct To3P {
-    const float* in; const float* w; const float* bias; const float* x;
-    float* recon; float* din; float* dpre; float* loss_parts;
+struct To3P {         // in / din / dpre: fp32 or bf16 (the kernel's storage type)
+    const void* in; const float* w; const float* bias; const float* x;
+    float* recon; void* din; void* dpre; float* loss_parts;
     int n, h, w_;           // input resolution (output is 2h x 2w)
     float gscale;           // 2 / (n * 3 * 2h * 2w)
     long long total;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void convt_to3_mse_kernel(To3P p) {
+    typedef vad_io4<T> io;
     __shared__ float ws[32 * 12], bs[3], red[4];
     for (int i = threadIdx.x; i < 384; i += 256) ws[i] = p.w[i];     // [ci][c][q]
     if (threadIdx.x < 3) bs[threadIdx.x] = p.bias[threadIdx.x];
@@ -794,7 +827,7 @@ __global__ __launch_bounds__(256) void convt_to3_mse_kernel(To3P p) {
         float r[32];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f32x4 v = *(const f32x4*)&p.in[idx * 32 + 4 * k];
+            const f32x4 v = io::ld((const T*)p.in + idx * 32 + 4 * k);
             r[4 * k] = v[0]; r[4 * k + 1] = v[1]; r[4 * k + 2] = v[2]; r[4 * k + 3] = v[3];
         }
         float dp[12];       // index q*3 + c
@@ -826,7 +859,7 @@ __global__ __launch_bounds__(256) void convt_to3_mse_kernel(To3P p) {
                         for (int c = 0; c < 3; ++c) s = fmaf(dp[q * 3 + c], ws[(4 * k + e) * 12 + c * 4 + q], s);
                     o[e] = s;
                 }
-                *(f32x4*)&p.din[idx * 32 + 4 * k] = o;
+                io::st((T*)p.din + idx * 32 + 4 * k, o);
             }
         }
         if (p.dpre) {
@@ -834,7 +867,7 @@ __global__ __launch_bounds__(256) void convt_to3_mse_kernel(To3P p) {
             for (int k = 0; k < 8; ++k) {
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
                 if (k < 3) o = f32x4{dp[4 * k], dp[4 * k + 1], dp[4 * k + 2], dp[4 * k + 3]};
-                *(f32x4*)&p.dpre[idx * 32 + 4 * k] = o;
+                io::st((T*)p.dpre + idx * 32 + 4 * k, o);
             }
         }
     }
@@ -909,7 +942,7 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* w, int c
     }
 }
 
-__global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int cin, int cout, float* fwd, float* dgrad, int split) {
+__global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int cin, int cout, float* fwd, float* dgrad, int split, int dgrad16) {
     const long long total = (long long)cin * cout * 4;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int q = (int)(idx & 3), co = (int)((idx >> 2) % cout), ci = (int)(idx / (4ll * cout));
@@ -920,15 +953,25 @@ __global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int 
         }
         // data gradient = 1x1 convolution over the space-to-depth gradient (K index q*cout+co, N index ci); that GEMM
         // runs in exact fp32 in either mode
-        if (dgrad) { const int kk = q * cout + co; dgrad[(((size_t)(kk / 8)) * cin + ci) * 8 + (kk & 7)] = v; }
+        // (dgrad16: VAD_PREC_BF16S runs that GEMM on bf16 operands too - the gradient tensors are bf16 in memory)
+        if (dgrad) {
+            const int kk = q * cout + co;
+            if (dgrad16) put_split(dgrad, (size_t)(kk / 16) * cin + ci, kk & 15, v, 2);
+            else dgrad[(((size_t)(kk / 8)) * cin + ci) * 8 + (kk & 7)] = v;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void pack_conv1x1_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad) {
+__global__ __launch_bounds__(256) void pack_conv1x1_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad, int bf16) {
     const long long total = (long long)cout * cin;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int ci = (int)(idx % cin), co = (int)(idx / cin);
         const float v = w[idx];
+        if (bf16) {
+            if (fwd) put_split(fwd, (size_t)(ci / 16) * cout + co, ci & 15, v, 2);
+            if (dgrad) put_split(dgrad, (size_t)(co / 16) * cin + ci, co & 15, v, 2);
+            continue;
+        }
         if (fwd) fwd[(((size_t)(ci / 8)) * cout + co) * 8 + (ci & 7)] = v;          // K = ci, N = co
         if (dgrad) dgrad[(((size_t)(co / 8)) * cin + ci) * 8 + (co & 7)] = v;       // K = co, N = ci
     }
@@ -1034,7 +1077,7 @@ extern "C" int vad_bn_stats(const float* y, long long npix, int c, float eps, fl
     const long long chunk = stats_chunk(npix);
     const int nb = (int)((npix + chunk - 1) / chunk);
     // pivot = the first pixel's channel vector (y[0..c)): a sample of each channel
-    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, npix, c, chunk, y, ws);
+    hipLaunchKernelGGL(chan_sums_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, npix, c, chunk, y, ws);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
                        (double)npix, 0, eps, momentum, stats, running_mean, running_var, (float*)nullptr, (float*)nullptr, y);
@@ -1055,10 +1098,16 @@ int vad_bn_stats_from_partials(const float* partials, int nblocks, long long npi
 }
 
 extern "C" int vad_chan_sum(const float* g, long long npix, int c, float* out, float* ws, void* stream) {
+    return vad_chan_sum_t(g, 0, npix, c, out, ws, stream);
+}
+
+// io16 != 0 (here and in the *_t forms below): the activation / gradient tensors are bf16 in memory (VAD_PREC_BF16S)
+int vad_chan_sum_t(const void* g, int io16, long long npix, int c, float* out, float* ws, void* stream) {
     VAD_REQUIRE(g && out && ws && npix > 0 && chan_ok(c), "chan_sum: bad arguments (c=%d)", c);
     const long long chunk = stats_chunk(npix);
     const int nb = (int)((npix + chunk - 1) / chunk);
-    hipLaunchKernelGGL(chan_sums_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, npix, c, chunk, (const float*)nullptr, ws);
+    if (io16) hipLaunchKernelGGL(chan_sums_kernel<vad_bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const vad_bf16*)g, npix, c, chunk, (const float*)nullptr, ws);
+    else hipLaunchKernelGGL(chan_sums_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)g, npix, c, chunk, (const float*)nullptr, ws);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nb, c,
                        (double)npix, 2, 0.f, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, out, (const float*)nullptr);
@@ -1069,14 +1118,21 @@ extern "C" int vad_chan_sum(const float* g, long long npix, int c, float* out, f
 extern "C" int vad_bn_act_pool_fwd(const float* y, const float* stats, const float* gamma, const float* beta, float* out,
                                    long long out_fs, int out_ps, int remap_t, int remap_b, int n, int h, int w, int c,
                                    int act, int pool, void* stream) {
+    return vad_bn_act_pool_fwd_t(y, 0, stats, gamma, beta, out, out_fs, out_ps, remap_t, remap_b, n, h, w, c, act, pool, stream);
+}
+
+int vad_bn_act_pool_fwd_t(const void* y, int io16, const float* stats, const float* gamma, const float* beta, void* out,
+                          long long out_fs, int out_ps, int remap_t, int remap_b, int n, int h, int w, int c,
+                          int act, int pool, void* stream) {
     VAD_REQUIRE(y && stats && gamma && beta && out && n > 0 && h > 0 && w > 0 && chan_ok(c), "bn_act_pool_fwd: bad arguments");
     VAD_REQUIRE(act >= 0 && act <= 2 && (!pool || (h % 2 == 0 && w % 2 == 0)), "bn_act_pool_fwd: bad act/pool");
     VAD_REQUIRE(remap_t == 0 || (remap_b > 0 && n == remap_t * remap_b), "bn_act_pool_fwd: n must equal T*B with a frame remap");
     const int oh = pool ? h / 2 : h, ow = pool ? w / 2 : w;
     BnFwdP p{y, stats, gamma, beta, out, out_fs ? out_fs : (long long)oh * ow * (out_ps ? out_ps : c), out_ps ? out_ps : c,
              remap_t, remap_b, n, h, w, c, act, pool, (long long)n * oh * ow * (c / 4)};
-    VAD_REQUIRE(p.out_ps % 4 == 0 && p.out_fs % 4 == 0, "bn_act_pool_fwd: strides must be multiples of 4 floats");
-    hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    VAD_REQUIRE(p.out_ps % 4 == 0 && p.out_fs % 4 == 0, "bn_act_pool_fwd: strides must be multiples of 4 elements");
+    if (io16) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<vad_bf16>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<float>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -1093,6 +1149,14 @@ extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const flo
                                    long long dout_fs, int dout_ps, int remap_t, int remap_b, float* dy, int s2d,
                                    float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
                                    int pool, void* stream) {
+    return vad_bn_act_pool_bwd_t(y, 0, stats, gamma, beta, dout, dout_fs, dout_ps, remap_t, remap_b, dy, s2d, dgamma, dbeta, ksums, ws,
+                                 n, h, w, c, act, pool, stream);
+}
+
+int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const float* gamma, const float* beta, const void* dout,
+                          long long dout_fs, int dout_ps, int remap_t, int remap_b, void* dy, int s2d,
+                          float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
+                          int pool, void* stream) {
     VAD_REQUIRE(y && stats && gamma && beta && dout && dy && dgamma && dbeta && ksums && ws, "bn_act_pool_bwd: null pointer");
     VAD_REQUIRE(n > 0 && h > 0 && w > 0 && chan_ok(c) && act >= 0 && act <= 2, "bn_act_pool_bwd: bad arguments");
     VAD_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "bn_act_pool_bwd: pooling needs even H, W");
@@ -1118,23 +1182,31 @@ extern "C" int vad_bn_act_pool_bwd(const float* y, const float* stats, const flo
     VAD_REQUIRE(p.dout_ps % 4 == 0 && p.dout_fs % 4 == 0, "bn_act_pool_bwd: strides must be multiples of 4 floats");
     const int nb = (int)((p.opix + p.chunk - 1) / p.chunk);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(nb), dim3(256), 0, s, p);
+    if (io16) hipLaunchKernelGGL(bn_bwd_sums_kernel<vad_bf16>, dim3(nb), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(nb), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, s, (const float*)ws, nb, c,
                        (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     p.dec = nullptr;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(p.opix * (c / 4))), dim3(256), 0, s, p);
+    if (io16) hipLaunchKernelGGL(bn_bwd_apply_kernel<vad_bf16>, dim3(grid_for(p.opix * (c / 4))), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(p.opix * (c / 4))), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
 
 extern "C" int vad_lstm_gates_fwd(float* z, const float* c_prev, float* c_out, float* h1, long long h1_fs, int h1_ps,
                                   float* h2, long long h2_fs, int h2_ps, int nb, int hw, int hid, void* stream) {
+    return vad_lstm_gates_fwd_t(z, 0, c_prev, c_out, h1, h1_fs, h1_ps, h2, h2_fs, h2_ps, nb, hw, hid, stream);
+}
+
+int vad_lstm_gates_fwd_t(void* z, int io16, const float* c_prev, float* c_out, void* h1, long long h1_fs, int h1_ps,
+                         void* h2, long long h2_fs, int h2_ps, int nb, int hw, int hid, void* stream) {
     VAD_REQUIRE(z && c_out && nb > 0 && hw > 0 && hid > 0 && hid % 4 == 0, "lstm_gates_fwd: bad arguments");
     LstmFwdP p{z, c_prev, c_out, h1, h1_fs ? h1_fs : (long long)hw * (h1_ps ? h1_ps : hid), h1_ps ? h1_ps : hid,
                h2, h2_fs ? h2_fs : (long long)hw * (h2_ps ? h2_ps : hid), h2_ps ? h2_ps : hid, hw, hid, (long long)nb * hw * (hid / 4)};
-    hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    if (io16) hipLaunchKernelGGL(lstm_gates_fwd_kernel<vad_bf16>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(lstm_gates_fwd_kernel<float>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -1142,11 +1214,18 @@ extern "C" int vad_lstm_gates_fwd(float* z, const float* c_prev, float* c_out, f
 extern "C" int vad_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, const float* dh1, long long dh1_fs,
                                   int dh1_ps, const float* dh2, long long dh2_fs, int dh2_ps, const float* dc_next, float* dz,
                                   float* dc_prev, int nb, int hw, int hid, void* stream) {
+    return vad_lstm_gates_bwd_t(gates, 0, c_prev, c, dh1, dh1_fs, dh1_ps, dh2, dh2_fs, dh2_ps, dc_next, dz, dc_prev, nb, hw, hid, stream);
+}
+
+int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const float* c, const void* dh1, long long dh1_fs,
+                         int dh1_ps, const void* dh2, long long dh2_fs, int dh2_ps, const float* dc_next, void* dz,
+                         float* dc_prev, int nb, int hw, int hid, void* stream) {
     VAD_REQUIRE(gates && c && dz && dc_prev && nb > 0 && hw > 0 && hid > 0 && hid % 4 == 0, "lstm_gates_bwd: bad arguments");
     LstmBwdP p{gates, c_prev, c, dh1, dh1_fs ? dh1_fs : (long long)hw * (dh1_ps ? dh1_ps : hid), dh1_ps ? dh1_ps : hid,
                dh2, dh2_fs ? dh2_fs : (long long)hw * (dh2_ps ? dh2_ps : hid), dh2_ps ? dh2_ps : hid, dc_next, dz, dc_prev,
                hw, hid, (long long)nb * hw * (hid / 4)};
-    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    if (io16) hipLaunchKernelGGL(lstm_gates_bwd_kernel<vad_bf16>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(lstm_gates_bwd_kernel<float>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -1172,7 +1251,7 @@ extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int 
 extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
                               int taps, int layout, int precision, void* stream) {
     VAD_REQUIRE(a && g && dw && ws && n > 0 && h > 0 && w > 0, "conv_wgrad: bad arguments");
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "conv_wgrad: precision=%d must be 0 (fp32), 1 (split: weight gradients stay fp32) or 2 (bf16)", precision);
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "conv_wgrad: precision=%d must be 0 (fp32), 1 (split: weight gradients stay fp32), 2 (bf16 operands) or 3 (a and g are bf16 tensors)", precision);
     VAD_REQUIRE(cin % 32 == 0 && ncols % 32 == 0 && cin > 0 && ncols > 0, "conv_wgrad: cin=%d ncols=%d must be multiples of 32", cin, ncols);
     VAD_REQUIRE((taps == 9 && layout == 0) || (taps == 1 && (layout == 1 || layout == 3 || layout == 4)), "conv_wgrad: taps/layout mismatch");
     VAD_REQUIRE(layout != 1 || ncols % 128 == 0, "conv_wgrad: convT gradient needs ncols = 4*cout");
@@ -1191,10 +1270,14 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     p.nitems = (unsigned)items;
     const dim3 grid((unsigned)((items + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
-    if (precision == VAD_PREC_BF16) {
-        if (taps == 9) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<9, 1>), grid, dim3(256), 0, s, p);
-        else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 4>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1>), grid, dim3(256), 0, s, p);
+    if (precision == VAD_PREC_BF16S) {
+        if (taps == 9) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<9, 1, 1>), grid, dim3(256), 0, s, p);
+        else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 4, 1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1, 1>), grid, dim3(256), 0, s, p);
+    } else if (precision == VAD_PREC_BF16) {
+        if (taps == 9) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<9, 1, 0>), grid, dim3(256), 0, s, p);
+        else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 4, 0>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1, 0>), grid, dim3(256), 0, s, p);
     } else if (taps == 9) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), grid, dim3(256), 0, s, p);
     else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
@@ -1212,6 +1295,10 @@ extern "C" size_t vad_conv_c3_wgrad_ws_floats(int n, int h, int cout) {
 
 extern "C" int vad_conv_c3_wgrad(const float* x_nchw, const float* g, float* dw, float* ws, int n, int h, int w, int cout,
                                  void* stream) {
+    return vad_conv_c3_wgrad_t(x_nchw, g, 0, dw, ws, n, h, w, cout, stream);
+}
+
+int vad_conv_c3_wgrad_t(const float* x_nchw, const void* g, int io16, float* dw, float* ws, int n, int h, int w, int cout, void* stream) {
     VAD_REQUIRE(x_nchw && g && dw && ws && n > 0 && h > 0 && w > 0 && cout > 0 && cout % 32 == 0, "conv_c3_wgrad: bad arguments");
     VAD_REQUIRE((long long)h * w * cout * 4 < (1ll << 31), "conv_c3_wgrad: frame too large for 32-bit offsets");
     WgradC3P p{};
@@ -1224,10 +1311,14 @@ extern "C" int vad_conv_c3_wgrad(const float* x_nchw, const float* g, float* dw,
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)4 * 9 * (w + 8) * sizeof(float);
     if (w % 8 == 0 && w <= 1024 && lds <= 64 * 1024) {
-        if (w <= 256) hipLaunchKernelGGL(conv_c3_wgrad_lds_kernel<1>, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, s, p);
-        else hipLaunchKernelGGL(conv_c3_wgrad_lds_kernel<4>, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, s, p);
+        const dim3 g4((unsigned)((items + 3) / 4));
+        if (w <= 256) { if (io16) hipLaunchKernelGGL((conv_c3_wgrad_lds_kernel<1, vad_bf16>), g4, dim3(256), lds, s, p);
+                        else hipLaunchKernelGGL((conv_c3_wgrad_lds_kernel<1, float>), g4, dim3(256), lds, s, p); }
+        else { if (io16) hipLaunchKernelGGL((conv_c3_wgrad_lds_kernel<4, vad_bf16>), g4, dim3(256), lds, s, p);
+               else hipLaunchKernelGGL((conv_c3_wgrad_lds_kernel<4, float>), g4, dim3(256), lds, s, p); }
     } else {
-        hipLaunchKernelGGL(conv_c3_wgrad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
+        if (io16) hipLaunchKernelGGL(conv_c3_wgrad_kernel<vad_bf16>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_c3_wgrad_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
     }
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((32ll * cout + 63) / 64)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
@@ -1245,6 +1336,11 @@ extern "C" size_t vad_convt_to3_mse_ws_floats(int n, int h, int w) {
 extern "C" int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
                                  float* din, float* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w,
                                  void* stream) {
+    return vad_convt_to3_mse_t(in_nhwc, 0, w_iohw, bias3, x_nchw, recon, din, dpre32, loss, dbias3, ws, n, h, w, stream);
+}
+
+int vad_convt_to3_mse_t(const void* in_nhwc, int io16, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
+                        void* din, void* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w, void* stream) {
     VAD_REQUIRE(in_nhwc && w_iohw && bias3 && x_nchw && loss && ws && n > 0 && h > 0 && w > 0, "convt_to3_mse: bad arguments");
     VAD_REQUIRE(!dbias3 || dpre32, "convt_to3_mse: the bias gradient needs the dpre buffer");
     const long long total = (long long)n * h * w;
@@ -1253,14 +1349,16 @@ extern "C" int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, cons
     const double count = (double)n * 3.0 * (2.0 * h) * (2.0 * w);
     To3P p{in_nhwc, w_iohw, bias3, x_nchw, recon, din, dpre32, ws, n, h, w, (float)(2.0 / count), total};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(convt_to3_mse_kernel, dim3((unsigned)nb), dim3(256), 0, s, p);
+    if (io16) hipLaunchKernelGGL(convt_to3_mse_kernel<vad_bf16>, dim3((unsigned)nb), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(convt_to3_mse_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, p);
     VAD_LAUNCH_CHECK();
     float* colsum = ws + nb;
     if (dbias3) {
         const long long chunk = stats_chunk(total);
         const int cb = (int)((total + chunk - 1) / chunk);
         float* cws = ws + nb + 64;
-        hipLaunchKernelGGL(chan_sums_kernel, dim3(cb), dim3(256), 0, s, (const float*)dpre32, total, 32, chunk, (const float*)nullptr, cws);
+        if (io16) hipLaunchKernelGGL(chan_sums_kernel<vad_bf16>, dim3(cb), dim3(256), 0, s, (const vad_bf16*)dpre32, total, 32, chunk, (const float*)nullptr, cws);
+        else hipLaunchKernelGGL(chan_sums_kernel<float>, dim3(cb), dim3(256), 0, s, (const float*)dpre32, total, 32, chunk, (const float*)nullptr, cws);
         VAD_LAUNCH_CHECK();
         hipLaunchKernelGGL(chan_finalize_kernel, dim3(32), dim3(256), 0, s, (const float*)cws, cb, 32, (double)total, 2, 0.f, 0.f,
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, colsum, (const float*)nullptr);
@@ -1284,8 +1382,8 @@ extern "C" int vad_adam_step(float* p, const float* g, float* m, float* v, long 
 
 extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv3x3: bad arguments");
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "train_pack_conv3x3: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
-    const int split = precision;                      // the packed layout follows the arithmetic mode, like the host packers (2 = bf16 in the hi slots)
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "train_pack_conv3x3: precision=%d must be 0 (fp32), 1 (split fp16), 2 or 3 (bf16)", precision);
+    const int split = precision == VAD_PREC_BF16S ? 2 : precision;   // the packed layout follows the arithmetic mode, like the host packers (2 = bf16 in the hi slots)
     VAD_REQUIRE(!split || (cin % 16 == 0 && (!dgrad || cout % 16 == 0)), "train_pack_conv3x3: split precision needs channel counts in multiples of 16");
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(9ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad, split);
     VAD_LAUNCH_CHECK();
@@ -1294,17 +1392,25 @@ extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, fl
 
 extern "C" int vad_train_pack_convt2x2(const float* w_iohw, int cin, int cout, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_iohw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || (4 * cout) % 8 == 0), "train_pack_convt2x2: bad arguments");
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "train_pack_convt2x2: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
-    const int split = precision;
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "train_pack_convt2x2: precision=%d must be 0 (fp32), 1 (split fp16), 2 or 3 (bf16)", precision);
+    const int split = precision == VAD_PREC_BF16S ? 2 : precision;
     VAD_REQUIRE(!split || cin % 16 == 0, "train_pack_convt2x2: split precision needs cin in multiples of 16");
-    hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad, split);
+    hipLaunchKernelGGL(pack_convt2x2_kernel, dim3(grid_for(4ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_iohw, cin, cout, fwd, dgrad, split,
+                       precision == VAD_PREC_BF16S ? 1 : 0);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
 
 extern "C" int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream) {
+    return vad_train_pack_conv1x1_p(w_oihw, cout, cin, fwd, dgrad, VAD_PREC_FP32, stream);
+}
+
+// precision VAD_PREC_BF16S: bf16 operand forms ([K/16][N][half][8 x bf16 | unused]) for vad_conv1x1_p; anything else: fp32
+int vad_train_pack_conv1x1_p(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv1x1: bad arguments");
-    hipLaunchKernelGGL(pack_conv1x1_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad);
+    const int bf16 = precision == VAD_PREC_BF16S;
+    VAD_REQUIRE(!bf16 || (cin % 16 == 0 && cout % 16 == 0), "train_pack_conv1x1: bf16 operands need channel counts in multiples of 16");
+    hipLaunchKernelGGL(pack_conv1x1_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad, bf16);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

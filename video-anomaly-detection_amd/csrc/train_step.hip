@@ -225,10 +225,13 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
                                      const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
                                      int precision, float* loss, float* recon, void* stream) {
     VAD_REQUIRE(x && params && grads && workspace && loss, "vid_train_fwd_bwd: null pointer");
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "vid_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "vid_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16), 2 (bf16 operands) or 3 (bf16 tensors)", precision);
     // Arithmetic mode (argument `precision`): 0 = exact fp32 everywhere (the parity path); 1 = the 3x3 and transposed
     // convolutions (forward and data gradients) take split-fp16 operands (22-bit products, fp32 accumulate), everything
-    // else - first layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam - stays fp32.
+    // else - first layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam - stays fp32; 2 = bf16 operands
+    // in the same places plus the weight gradients; 3 (VAD_PREC_BF16S) = 2 with every activation / activation-gradient
+    // tensor of the workspace stored as bf16 (the buffers keep their fp32-sized slots and use the first half) and the 1x1
+    // data gradients on bf16 operands too.
     Plan p;
     VAD_REQUIRE(make_plan(p, b, t, h, w, latent, hid, layers),
                 "vid_train_fwd_bwd: unsupported configuration (B=%d T=%d %dx%d latent=%d hid=%d layers=%d): H, W multiples of 16, "
@@ -241,6 +244,11 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     float* G = grads;
     const int N = p.N, B = p.B, T = p.T, H = p.H, W = p.W, L = p.L, Hd = p.Hd, NL = p.NL, hw = p.hw;
     const float eps = 1e-5f, mom = 0.1f;     // nn.BatchNorm2d defaults (models/video_autoencoder.py:193)
+    const int io = precision == VAD_PREC_BF16S;          // activation tensors are bf16
+    const size_t es = io ? 2 : 4;
+    // element `elem` of the activation buffer at workspace offset `off` (floats), in the mode's storage type
+    auto A = [&](size_t off, size_t elem = 0) -> float* { return (float*)((char*)(ws + off) + elem * es); };
+    auto at = [&](const float* base, size_t elem) -> float* { return (float*)((char*)base + elem * es); };
     float* zeros = ws + p.zeros;
     VAD_HIP_TRY(hipMemsetAsync(zeros, 0, 1024 * sizeof(float), s));
 
@@ -252,87 +260,93 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         TRY(vad_train_pack_conv3x3(P + p.l_w[l], 4 * Hd, p.lstm_cin(l) + Hd, ws + p.pk_l[l], ws + p.pk_l_dg[l], precision, s));
     for (int j = 0; j < 3; ++j)
         TRY(vad_train_pack_convt2x2(P + p.d_w[j], p.decC[j], p.decC[j + 1], ws + p.pk_d[j], ws + p.pk_d_dg[j], precision, s));
-    if (p.proj) TRY(vad_train_pack_conv1x1(P + p.pj_w, L, Hd, ws + p.pk_pj, ws + p.pk_pj_dg, s));
+    if (p.proj) TRY(vad_train_pack_conv1x1_p(P + p.pj_w, L, Hd, ws + p.pk_pj, ws + p.pk_pj_dg, precision, s));
 
     // ================================================================================== forward
     // encoder (models/video_autoencoder.py:191-215): conv -> BatchNorm(batch stats) -> LeakyReLU(0.2) -> MaxPool2
     for (int k = 0; k < 4; ++k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
-        float* y = ws + p.y[k];
+        float* y = A(p.y[k]);
         int sblocks = 0;      // > 0: the convolution wrote the BatchNorm partial sums itself (first layer: no second pass over y)
-        if (k == 0) TRY(vad_conv3x3_c3_stats(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s));
-        else TRY(vad_conv3x3_stats(ws + p.a[k - 1], 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, ws + p.chan_ws, &sblocks, s));
+        if (k == 0) TRY(vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, io, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s));
+        else TRY(vad_conv3x3_stats(A(p.a[k - 1]), 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, ws + p.chan_ws, &sblocks, s));
         float* rs = running ? running + p.e_rs[k] : nullptr;
         if (sblocks > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[k], s));
-        else TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
+        else {
+            VAD_REQUIRE(!io, "vid_train_fwd_bwd: bf16 tensors need the convolutions' own BatchNorm partial sums (persistent kernels)");
+            TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
+        }
         if (k < 3)
-            TRY(vad_bn_act_pool_fwd(y, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.a[k], 0, 0, 0, 0, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+            TRY(vad_bn_act_pool_fwd_t(y, io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.a[k]), 0, 0, 0, 0, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         else   // latent features go straight into layer 0's operand buffers: frame b*T+t -> slot t*B+b, x-part
-            TRY(vad_bn_act_pool_fwd(y, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.cat[0], 0, L + Hd, T, B, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+            TRY(vad_bn_act_pool_fwd_t(y, io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.cat[0]), 0, L + Hd, T, B, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
     }
     // ConvLSTM (models/video_autoencoder.py:153-163): layer by layer, step by step; h(-1) = c(-1) = 0
     for (int l = 0; l < NL; ++l) {
         const int cx = p.lstm_cin(l), cin = cx + Hd;
         const size_t slab = (size_t)B * hw * cin;
         // h-part of the t = 0 operand is the zero initial state (the x-part was / will be written by the producer)
-        VAD_HIP_TRY(hipMemset2DAsync(ws + p.cat[l] + cx, (size_t)cin * sizeof(float), 0, (size_t)Hd * sizeof(float), (size_t)B * hw, s));
+        VAD_HIP_TRY(hipMemset2DAsync(A(p.cat[l], cx), (size_t)cin * es, 0, (size_t)Hd * es, (size_t)B * hw, s));
         for (int tt = 0; tt < T; ++tt) {
-            float* zt = ws + p.z[l] + (size_t)tt * B * hw * 4 * Hd;
+            float* zt = A(p.z[l], (size_t)tt * B * hw * 4 * Hd);
             float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
-            TRY(vad_conv3x3(ws + p.cat[l] + tt * slab, 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, precision, s));
-            float* h1 = tt + 1 < T ? ws + p.cat[l] + (tt + 1) * slab + cx : nullptr;
+            TRY(vad_conv3x3(A(p.cat[l], tt * slab), 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, precision, s));
+            float* h1 = tt + 1 < T ? A(p.cat[l], (tt + 1) * slab + cx) : nullptr;
             float* h2; long long h2_fs; int h2_ps;
-            if (l + 1 < NL) { h2 = ws + p.cat[l + 1] + (size_t)tt * B * hw * 2 * Hd; h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
-            else { h2 = ws + p.hseq + (size_t)tt * hw * Hd; h2_ps = Hd; h2_fs = (long long)T * hw * Hd; }
-            TRY(vad_lstm_gates_fwd(zt, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, h1, (long long)hw * cin, cin, h2, h2_fs, h2_ps, B, hw, Hd, s));
+            if (l + 1 < NL) { h2 = A(p.cat[l + 1], (size_t)tt * B * hw * 2 * Hd); h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
+            else { h2 = A(p.hseq, (size_t)tt * hw * Hd); h2_ps = Hd; h2_fs = (long long)T * hw * Hd; }
+            TRY(vad_lstm_gates_fwd_t(zt, io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, h1, (long long)hw * cin, cin, h2, h2_fs, h2_ps, B, hw, Hd, s));
         }
     }
     // proj (models/video_autoencoder.py:311-312, 346-349): Conv2d k1 hidden -> latent when the two differ, else Identity
-    const float* dec_in = ws + p.hseq;
+    const float* dec_in = A(p.hseq);
     if (p.proj) {
-        TRY(vad_conv1x1(ws + p.hseq, ws + p.pk_pj, P + p.pj_b, ws + p.pseq, (long long)N * hw, Hd, L, s));
-        dec_in = ws + p.pseq;
+        TRY(vad_conv1x1_p(A(p.hseq), ws + p.pk_pj, P + p.pj_b, A(p.pseq), (long long)N * hw, Hd, L, precision, s));
+        dec_in = A(p.pseq);
     }
     // decoder (models/video_autoencoder.py:242-256): convT -> BatchNorm -> ReLU, three times
     for (int j = 0; j < 3; ++j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
-        const float* in = j == 0 ? dec_in : ws + p.r[j - 1];
-        float* u = ws + p.u[j];
+        const float* in = j == 0 ? dec_in : A(p.r[j - 1]);
+        float* u = A(p.u[j]);
         int srows = 0;        // > 0: the transposed convolution wrote the BatchNorm partial sums itself
         TRY(vad_convt2x2_stats(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, precision, ws + p.chan_ws, &srows, s));
         float* rs = running ? running + p.d_rs[j] : nullptr;
         if (srows > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, srows, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, P + p.d_b[j], s));
-        else TRY(vad_bn_stats(u, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
-        TRY(vad_bn_act_pool_fwd(u, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], ws + p.r[j], 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
+        else {
+            VAD_REQUIRE(!io, "vid_train_fwd_bwd: bf16 tensors need the transposed convolutions' own BatchNorm partial sums");
+            TRY(vad_bn_stats(u, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
+        }
+        TRY(vad_bn_act_pool_fwd_t(u, io, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], A(p.r[j]), 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
     }
     // last layer + loss, forward and backward (models/video_autoencoder.py:259-260, train_video.py:55)
-    float *g0 = ws + p.g[0], *g2 = ws + p.g[2];
-    TRY(vad_convt_to3_mse(ws + p.r[2], P + p.t_w, P + p.t_b, x, recon, g0, ws + p.dpre, loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, s));
+    float *g0 = A(p.g[0]), *g2 = A(p.g[2]);
+    TRY(vad_convt_to3_mse_t(A(p.r[2]), io, P + p.t_w, P + p.t_b, x, recon, g0, A(p.dpre), loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, s));
 
     if (g_vad_train_stop == 20) return VAD_OK;      // debug: g0 = gradient of the last decoder activation, dpre intact
 
     // ================================================================================== backward
-    TRY(vad_conv_wgrad(ws + p.r[2], ws + p.dpre, G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, precision, s));
+    TRY(vad_conv_wgrad(A(p.r[2]), A(p.dpre), G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, precision, s));
     for (int j = 2; j >= 0; --j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
-        const float* in = j == 0 ? dec_in : ws + p.r[j - 1];
+        const float* in = j == 0 ? dec_in : A(p.r[j - 1]);
         // g0 = d r_j (dense, 2hj x 2wj) -> g2 = d u_j in the space-to-depth view [N][hj][wj][4*co]
-        TRY(vad_bn_act_pool_bwd(ws + p.u[j], ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.d_g[j], G + p.d_be[j],
-                                ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
+        TRY(vad_bn_act_pool_bwd_t(A(p.u[j]), io, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.d_g[j], G + p.d_be[j],
+                                  ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
         TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, precision, s));
         // bias of a conv that feeds a batch-statistics BatchNorm: sum(dy) = gamma*invstd*(sum(dz) - M*k1 - k2*sum(xhat)) = 0
         // exactly (the batch mean removes any constant).  Autograd returns ~1e-9 rounding noise there, which Adam turns
         // into a +-lr random walk; an exact zero costs no pass over the tensor and leaves the bias where it is.
         VAD_HIP_TRY(hipMemsetAsync(G + p.d_b[j], 0, (size_t)co * sizeof(float), s));
-        TRY(vad_conv1x1(g2, ws + p.pk_d_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, s));     // g0 = d (input of convT j)
+        TRY(vad_conv1x1_p(g2, ws + p.pk_d_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, precision, s));     // g0 = d (input of convT j)
         if (g_vad_train_stop == j) return VAD_OK;
     }
     // g0 = gradient of the decoder input [b*T+t][hw][L]; through proj when present
     const float* dhseq = g0;
     if (p.proj) {
-        TRY(vad_conv_wgrad(ws + p.hseq, g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, precision, s));
-        TRY(vad_chan_sum(g0, (long long)N * hw, L, G + p.pj_b, ws + p.chan_ws, s));
-        TRY(vad_conv1x1(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, s));
+        TRY(vad_conv_wgrad(A(p.hseq), g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, precision, s));
+        TRY(vad_chan_sum_t(g0, io, (long long)N * hw, L, G + p.pj_b, ws + p.chan_ws, s));
+        TRY(vad_conv1x1_p(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, precision, s));
         dhseq = g2;
     }
     // dhseq = d hseq [b*T+t][hw][Hd].  BPTT, top layer first.
@@ -342,34 +356,34 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         float* dc = ws + p.dc;
         for (int tt = T - 1; tt >= 0; --tt) {
             const float* dh1; long long dh1_fs; int dh1_ps;
-            if (l == NL - 1) { dh1 = dhseq + (size_t)tt * hw * Hd; dh1_ps = Hd; dh1_fs = (long long)T * hw * Hd; }
-            else { dh1 = ws + p.dcat[l + 1] + (size_t)tt * B * hw * 2 * Hd; dh1_ps = 2 * Hd; dh1_fs = (long long)hw * dh1_ps; }
-            const float* dh2 = tt + 1 < T ? ws + p.dcat[l] + (tt + 1) * slab + cx : nullptr;
-            float* dzt = ws + p.dzl[l] + (size_t)tt * B * hw * 4 * Hd;
+            if (l == NL - 1) { dh1 = at(dhseq, (size_t)tt * hw * Hd); dh1_ps = Hd; dh1_fs = (long long)T * hw * Hd; }
+            else { dh1 = A(p.dcat[l + 1], (size_t)tt * B * hw * 2 * Hd); dh1_ps = 2 * Hd; dh1_fs = (long long)hw * dh1_ps; }
+            const float* dh2 = tt + 1 < T ? A(p.dcat[l], (tt + 1) * slab + cx) : nullptr;
+            float* dzt = A(p.dzl[l], (size_t)tt * B * hw * 4 * Hd);
             const float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
-            TRY(vad_lstm_gates_bwd(ws + p.z[l] + (size_t)tt * B * hw * 4 * Hd, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
-                                   dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s));
-            TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, ws + p.dcat[l] + tt * slab, 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, precision, s));
+            TRY(vad_lstm_gates_bwd_t(A(p.z[l], (size_t)tt * B * hw * 4 * Hd), io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
+                                     dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s));
+            TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, A(p.dcat[l], tt * slab), 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, precision, s));
         }
         // weight / bias gradients of the cell's convolution over all steps at once (frames = T*B)
-        TRY(vad_conv_wgrad(ws + p.cat[l], ws + p.dzl[l], G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s));
-        TRY(vad_chan_sum(ws + p.dzl[l], (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s));
+        TRY(vad_conv_wgrad(A(p.cat[l]), A(p.dzl[l]), G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s));
+        TRY(vad_chan_sum_t(A(p.dzl[l]), io, (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s));
         if (g_vad_train_stop == 10 + l) return VAD_OK;
     }
     // encoder, last stage first; the x-part of layer 0's operand gradient is d(latent features)
     for (int k = 3; k >= 0; --k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         if (k == 3)
-            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], ws + p.dcat[0], 0, L + Hd, T, B, g2, 0,
-                                    G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+            TRY(vad_bn_act_pool_bwd_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.dcat[0]), 0, L + Hd, T, B, g2, 0,
+                                      G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         else
-            TRY(vad_bn_act_pool_bwd(ws + p.y[k], ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, g2, 0,
-                                    G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+            TRY(vad_bn_act_pool_bwd_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, g2, 0,
+                                      G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         VAD_HIP_TRY(hipMemsetAsync(G + p.e_b[k], 0, (size_t)co * sizeof(float), s));      // structurally zero, see the decoder loop
         if (k == 0) {
-            TRY(vad_conv_c3_wgrad(x, g2, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
+            TRY(vad_conv_c3_wgrad_t(x, g2, io, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
         } else {
-            TRY(vad_conv_wgrad(ws + p.a[k - 1], g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s));
+            TRY(vad_conv_wgrad(A(p.a[k - 1]), g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s));
             TRY(vad_conv3x3(g2, 0, ws + p.pk_e_dg[k], zeros, g0, 0, N, hk, wk, co, ci, VAD_ACT_NONE, 0, precision, s));
         }
     }

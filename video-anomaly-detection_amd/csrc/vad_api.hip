@@ -209,13 +209,14 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
             { VadProfScope ps(9 + 2 * blk, s);
               TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, precision, s)); }
         }
-        // dec4.0 + dec4.3 + score.  Exact fp32: ONE kernel, the 8.4 MB per frame map between the two layers never exists in
-        // memory (dec4_fused.hip).  Split precision (and the A/B switch): two launches, convT 32->32 then the VALU tail; those
+        // dec4.0 + dec4.3 + score: ONE kernel, the 8.4 MB per frame map between the two layers never exists in memory
+        // (dec4_fused.hip), in BOTH arithmetic modes: these layers are HBM-bound, so the split mode keeps them exact fp32
+        // (dec4.0 is packed as fp32 in every blob).  A/B switch: two launches, convT 32->32 then the VALU tail; those
         // can run in sub-groups (vad_debug_set_tail_group) so that the map stays in the 256 MiB Infinity Cache - measured
         // on MI355X this does NOT pay (15.2 k frames/s whole group vs 14.9 k at 16 frames), so the default is the whole group.
         const size_t in_f = (size_t)hh * ww * 32;
         int nparts = nparts_tail;
-        if (precision == VAD_PREC_FP32 && g_vad_dec4_fused.load(std::memory_order_relaxed)) {
+        if (g_vad_dec4_fused.load(std::memory_order_relaxed)) {
             nparts = vad_dec4_score_partials(h, w);
             VadProfScope ps(18, s);
             TRY(vad_dec4_score_fmt(B, W_(14), B_(14), W_(15) + 8 * 108, B_(15), xin, x_format, parts,
@@ -227,7 +228,7 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
         for (int f1 = 0; f1 < n; f1 += sub) {
             const int m = (n - f1 < sub) ? (n - f1) : sub;
             { VadProfScope ps(14, s);
-              TRY(vad_convt2x2(B + (size_t)f1 * in_f, 0, W_(14), B_(14), A, 0, m, hh, ww, 32, 32, VAD_ACT_RELU, precision, s)); }
+              TRY(vad_convt2x2(B + (size_t)f1 * in_f, 0, W_(14), B_(14), A, 0, m, hh, ww, 32, 32, VAD_ACT_RELU, VAD_PREC_FP32, s)); }
             { VadProfScope ps(15, s);
               const size_t fo = (size_t)(f0 + f1);
               TRY(vad_conv3x3_to3_score_fmt(A, W_(15), B_(15), xin + (size_t)f1 * 3 * h * w * xelem, x_format, parts + (size_t)f1 * nparts,

@@ -89,7 +89,45 @@ __device__ __forceinline__ float vad_bload1(__amdgpu_buffer_rsrc_t r, unsigned v
 __device__ __forceinline__ void vad_bstore1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ void vad_bstore_h(unsigned short v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b16((short)v, r, (int)voff, (int)soff, 0);
+}
 constexpr unsigned VAD_OOB = 0x80000000u;   // byte offset no frame reaches (host checks frames < 2^31 bytes)
+
+// ---- bf16 storage (training mode VAD_PREC_BF16S: activations and activation gradients live in HBM as bf16, every
+// arithmetic step is fp32).  Storage type = the 16-bit pattern; conversion to bf16 rounds to nearest even.
+typedef unsigned short vad_bf16;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vad_bf16_f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ unsigned short vad_f_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned vad_pack_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, bf16x2_{(__bf16)lo, (__bf16)hi});
+}
+// four consecutive elements <-> f32x4 (fp32: one 16-byte access; bf16: one 8-byte access)
+template <typename T> struct vad_io4;
+template <> struct vad_io4<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void st(float* p, f32x4 v) { *(f32x4*)p = v; }
+    static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct vad_io4<vad_bf16> {
+    static __device__ __forceinline__ f32x4 ld(const vad_bf16* p) {
+        const u32x2 r = *(const u32x2*)p;
+        return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ void st(vad_bf16* p, f32x4 v) { *(u32x2*)p = u32x2{vad_pack_bf16(v[0], v[1]), vad_pack_bf16(v[2], v[3])}; }
+    static __device__ __forceinline__ float ld1(const vad_bf16* p) { return vad_bf16_f(*p); }
+    static __device__ __forceinline__ float round(float v) { return vad_bf16_f(vad_f_bf16(v)); }
+};
+
+// one element through a buffer descriptor, offsets in BYTES (fp32: dword load; bf16: 16-bit load, widened)
+template <typename T> __device__ __forceinline__ float vad_bload_e(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ float vad_bload_e<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return vad_bload1(r, voff, soff); }
+template <> __device__ __forceinline__ float vad_bload_e<vad_bf16>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return vad_bf16_f((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0));
+}
 
 // Input formats of the ORIGINAL frames handed to the model-level entry points.
 //   VAD_X_F32_NCHW : float32 [N,3,H,W], already normalised to [-1,1] (what the reference's datasets produce)
@@ -118,6 +156,9 @@ int vad_bn_stats_from_partials(const float* partials, int nblocks, long long npi
 int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const float* b0, const float* w1, const float* b1,
                              float* out, int n, int h, int wd, int precision, void* stream);
 int vad_nhwc_to_nchw_ld(const float* in, int in_c, float* out, int n, int h, int w, int c, void* stream);   // first c of in_c channels
+// first layer with a bf16 output tensor (out16 != 0; VAD_PREC_BF16S); the other bf16-tensor forms are declared in vad_hip.h
+int vad_conv3x3_c3_stats_t(const void* x, int fmt, const float* w, const float* bias, void* out, int out16, int n, int h, int wd, int cout,
+                           int act, int pool, float* stats, int* stats_blocks, void* stream);
 // vad_score_finalize + the device-side blob check: when hdr != NULL and hdr[1] != want_tag every score becomes NaN
 int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, float* frame_scores,
                               float* seq_scores, int t, const unsigned* hdr, unsigned want_tag, void* stream);

@@ -20,8 +20,10 @@ SOURCES = ["conv_mfma.hip", "dec4_fused.hip", "tail.hip", "ssim.hip", "train_ops
 
 VAD_OK = 0
 ABI_VERSION = 2
-PREC_FP32, PREC_SPLIT, PREC_BF16 = 0, 1, 2
-PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16}     # bf16: training entry points only
+PREC_FP32, PREC_SPLIT, PREC_BF16, PREC_BF16S = 0, 1, 2, 3
+# bf16 modes: training entry points only.  "bf16_operands" = bf16 MFMA operands converted from fp32 tensors; "bf16_tensors" =
+# the activation / gradient tensors themselves are bf16 in HBM (VAD_PREC_BF16S, video training step only)
+PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16, "bf16_operands": PREC_BF16, "bf16_tensors": PREC_BF16S}
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 X_F32_NCHW, X_U8_NHWC = 0, 1
 PROF_SLOTS = 32
@@ -118,6 +120,17 @@ SIGNATURES = {
     "vad_conv_c3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_convt_to3_mse_ws_floats": (_sz, [_i, _i, _i]),
     "vad_convt_to3_mse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vad_chan_sum_t": (_i, [_vp, _i, _ll, _i, _vp, _vp, _vp]),
+    "vad_bn_act_pool_fwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_bn_act_pool_bwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp,
+                                   _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_lstm_gates_fwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _vp]),
+    "vad_lstm_gates_bwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vad_conv_c3_wgrad_t": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_convt_to3_mse_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vad_train_pack_conv1x1_p": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
+    "vad_conv1x1_p": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "vad_conv3x3_c3_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "vad_train_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
     "vad_train_pack_convt2x2": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),

@@ -210,13 +210,16 @@ class VideoTrainer(_FlatTrainer):
     def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
                  eps: float = 1e-8, process_group=None, precision: str = "fp32"):
         self._check_model(model, VideoAutoencoder, "VideoTrainer")
-        if precision not in ("fp32", "split", "bf16"):
-            raise hip.VadError(f"precision must be 'fp32', 'split' or 'bf16', got {precision!r}")
+        if precision not in ("fp32", "split", "bf16", "bf16_operands", "bf16_tensors"):
+            raise hip.VadError(f"precision must be 'fp32', 'split', 'bf16' (= 'bf16_tensors') or 'bf16_operands', got {precision!r}")
         #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
         #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32.
-        #: "bf16" (BASELINE.json configs[4]): the same convolutions on bf16 operands (8-bit significands, fp32 accumulate),
-        #: fp32 master weights / BatchNorm / loss / weight gradients / Adam; gated by loss-curve agreement, not parity
-        self.precision = precision
+        #: "bf16" (BASELINE.json configs[4]) = "bf16_tensors": every activation and activation-gradient tensor between the
+        #: kernels is bf16 in HBM and every convolution / weight-gradient GEMM behind the first layer runs on bf16 MFMA
+        #: operands with fp32 accumulation; arithmetic inside the kernels, BatchNorm statistics, cell states, master weights,
+        #: parameter gradients, loss and Adam stay fp32.  "bf16_operands" (round 2's form, kept for A/B): fp32 tensors in
+        #: HBM, converted to bf16 while they are staged.  Both are gated by loss-curve agreement, not parity
+        self.precision = "bf16_tensors" if precision == "bf16" else precision
         l = hip.lib()
         self.cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
         super().__init__(model, l.vad_vid_train_nparams(*self.cfg), l.vad_vid_train_nstats(*self.cfg), lr, weight_decay, betas, eps,
