@@ -373,11 +373,51 @@ def layers_and_roofline(hip, lib, kind, hw, per_gpu, steps, t, stride, default_s
     return layers, roofline
 
 
+# Algorithmic work of the kernel groups of one training step (vad_prof_slot_name(2, .)), per 256x256 frame of a T = 10 clip of
+# the default VideoAutoencoder (SURVEY.md Appendix B layer table; every layer's forward FLOPs recur once in its data gradient
+# and once in its weight gradient).  GFLOP per frame for the MFMA groups; MB per frame of fp32 tensors for the HBM-bound
+# passes (bf16 tensors: half): BatchNorm forward reads the conv outputs (15.2 encoder + 3.7 decoder) and writes the activated
+# (pooled) maps (7.5); backward pass A reads conv outputs + upstream gradients, pass B the same plus the write of dy.
+TRAIN_GROUP_GFLOP = {"first layer fwd": 0.11325, "conv3x3 fwd": 1.50995, "ConvLSTM conv fwd": 1.20796, "convT / proj fwd": 0.16777,
+                     "conv3x3 dgrad": 1.50995, "ConvLSTM conv dgrad": 1.20796, "convT / proj dgrad (1x1)": 0.16777,
+                     "weight gradients": 1.50995 + 1.20796 + 0.16777 + 0.01258, "first layer wgrad": 0.11325}
+TRAIN_GROUP_MB_FP32 = {"BatchNorm fwd": 18.9 + 7.5, "BatchNorm bwd": (18.9 + 7.5) + (18.9 + 7.5 + 18.9)}
+TRAIN_PEAK_TFLOPS = {"fp32": 157.3, "split": 2500.0 / 3, "bf16": 2500.0}
+
+
+def training_groups(vad, frames, hw, precision):
+    """Per-group hipEvent times of the step(s) recorded since the last vad_prof_reset -> {group: ms per step, achieved rate}."""
+    import ctypes as C
+    hip, lib = vad.hip, vad.hip.lib()
+    ms = (C.c_float * hip.PROF_SLOTS)()
+    cnt = (C.c_int * hip.PROF_SLOTS)()
+    hip.check(lib.vad_prof_read(ms, cnt), "vad_prof_read")
+    scale = (hw / 256.0) ** 2
+    groups = {}
+    for i in range(hip.PROF_SLOTS):
+        if not cnt[i]:
+            continue
+        name = lib.vad_prof_slot_name(2, i).decode()
+        g = {"ms": round(ms[i], 4), "launches": cnt[i]}
+        if name in TRAIN_GROUP_GFLOP and ms[i] > 0:
+            g["tflops"] = round(TRAIN_GROUP_GFLOP[name] * scale * frames / ms[i], 2)        # GFLOP / ms = TFLOP/s
+        if name in TRAIN_GROUP_MB_FP32 and ms[i] > 0:
+            mb = TRAIN_GROUP_MB_FP32[name] * scale * (0.5 if precision == "bf16" else 1.0)
+            g["algorithmic_GB"] = round(mb * frames / 1e3, 3)
+            g["TBps"] = round(mb * frames / ms[i] / 1e3, 3)                                   # MB / ms = GB/s
+        groups[name] = g
+    return groups
+
+
 def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
     """frames/s through VideoTrainer.step (forward in train mode + MSE + backward + Adam as HIP kernels) on synthetic clips,
-    default VideoAutoencoder(latent 128, hidden 128, 2 layers); FLOPs counted as 3 x the forward's."""
+    default VideoAutoencoder(latent 128, hidden 128, 2 layers); FLOPs counted as 3 x the forward's.
+    Each precision also gets a `roofline` object: the MFMA groups of the step (convolutions forward + data gradients, weight
+    gradients) against the mode's dense matrix peak and the BatchNorm passes against HBM, from per-group hipEvents of ONE extra
+    step (the events are recorded by the library around every launch group; the timed steps run without them)."""
     import numpy as np
     import torch
+    lib = vad.hip.lib()
     m = vad.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, 5).items()}, strict=True)
@@ -398,6 +438,27 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
         dt = (time.perf_counter() - t0) / steps
         res = {"value": round(clips * t / dt, 1), "ms_per_step": round(dt * 1e3, 3), "loss_first_last": [first, float(loss)],
                "algorithmic_tflops": round(3 * 3011510272.0 * (hw / 256.0) ** 2 * clips * t / dt / 1e12, 2)}
+        # one more step with the per-group events on
+        vad.hip.check(lib.vad_prof_reset(), "vad_prof_reset")
+        vad.hip.check(lib.vad_prof_enable(1), "vad_prof_enable")
+        tr.forward_backward(x)
+        torch.cuda.synchronize(dev)
+        groups = training_groups(vad, clips * t, hw, precision)
+        vad.hip.check(lib.vad_prof_enable(0), "vad_prof_enable")
+        vad.hip.check(lib.vad_prof_reset(), "vad_prof_reset")
+        mf = [g for n, g in groups.items() if n in TRAIN_GROUP_GFLOP and n not in ("first layer fwd", "first layer wgrad")]
+        mf_ms = sum(g["ms"] for g in mf)
+        mf_tf = sum(g["tflops"] * g["ms"] for g in mf) / mf_ms if mf_ms > 0 else 0.0
+        bn = [g for n, g in groups.items() if n in TRAIN_GROUP_MB_FP32]
+        bn_ms = sum(g["ms"] for g in bn)
+        peak = TRAIN_PEAK_TFLOPS[precision]
+        res["roofline"] = {"bound": "mfma", "kernel": "3x3 / transposed / 1x1 convolutions (forward + data gradients) and weight-gradient GEMMs behind the first layer",
+                           "achieved": round(mf_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(mf_tf / peak, 4),
+                           "ms": round(mf_ms, 3), "traffic": None,
+                           "batchnorm_passes": {"bound": "hbm", "ms": round(bn_ms, 3), "share_of_step": round(bn_ms / (dt * 1e3), 3),
+                                                "achieved": round(sum(g["algorithmic_GB"] for g in bn) / bn_ms, 3) if bn_ms > 0 else None,
+                                                "peak": 8.0, "unit": "TB/s"},
+                           "groups": groups}
         if precision == "fp32":
             out.update(res)
             out["workspace_GiB"] = round(tr._ws.numel() / 2**30, 2)
@@ -405,8 +466,9 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
             out["split_precision"] = dict(res, arithmetic="3x3 / transposed convolutions (forward + data gradients) on split-fp16 operands, "
                                                           "everything else fp32")
         else:
-            out["bf16_precision"] = dict(res, arithmetic="BASELINE configs[4] dtype: 3x3 / transposed convolutions (forward + data gradients) on bf16 "
-                                                         "operands with fp32 accumulation; master weights, BatchNorm, loss, weight gradients, Adam fp32")
+            out["bf16_precision"] = dict(res, arithmetic="BASELINE configs[4] dtype: activation and activation-gradient tensors bf16 in HBM, every convolution / "
+                                                         "weight-gradient GEMM behind the first layer on bf16 MFMA operands with fp32 accumulation; arithmetic inside "
+                                                         "the kernels, BatchNorm statistics, cell states, master weights, parameter gradients, loss, Adam fp32")
         m.load_state_dict(state)
         del tr
     del m, x

@@ -444,7 +444,7 @@ int vad_graph_destroy(void* exec);
 int vad_prof_enable(int on);
 int vad_prof_reset(void);
 int vad_prof_read(float* ms /*[VAD_PROF_SLOTS]*/, int* launches /*[VAD_PROF_SLOTS]*/);
-const char* vad_prof_slot_name(int model /*0 img, 1 vid*/, int slot);
+const char* vad_prof_slot_name(int model /*0 img, 1 vid, 2 video training step (kernel groups)*/, int slot);
 
 #ifdef __cplusplus
 }

@@ -147,12 +147,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
     typedef vad_io4<T> io;
     const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
-        const int c4 = (int)(idx % cg);
-        long long pix = idx / cg;
-        const int x = (int)(pix % ow); pix /= ow;
-        const int y = (int)(pix % oh);
-        const int n = (int)(pix / oh);
+    // (32-bit index arithmetic, host-checked: three 64-bit divisions per item cost more than the item's memory traffic once
+    // the tensors are bf16)
+    const unsigned total = (unsigned)p.total, ucg = (unsigned)cg, uow = (unsigned)ow, uoh = (unsigned)oh;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned pix = idx / ucg, t_ = pix / uow, un = t_ / uoh;
+        const int c4 = (int)(idx - pix * ucg);
+        const int x = (int)(pix - t_ * uow);
+        const int y = (int)(t_ - un * uoh);
+        const int n = (int)un;
         const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
         const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
         const T* src = (const T*)p.y + (size_t)n * p.h * p.w * p.c + 4 * c4;
@@ -223,13 +226,15 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
     if (row < rows) {
         const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
         const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
-        for (long long q = p0 + row; q < p1; q += rows) {
-            const int x = (int)(q % ow), y = (int)((q / ow) % oh), n = (int)(q / ((long long)ow * oh));
-            const f32x4 g = io::ld(&pdout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4]);
+        auto fetch = [&](long long q, f32x4& g, f32x4 (&yv)[4]) {
+            const unsigned uq = (unsigned)q, t_ = uq / (unsigned)ow, un = t_ / (unsigned)oh;       // (opix < 2^31: host-checked)
+            const int x = (int)(uq - t_ * (unsigned)ow), y = (int)(t_ - un * (unsigned)oh), n = (int)un;
+            g = io::ld(&pdout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4]);
             const size_t o0 = (size_t)n * p.h * p.w * p.c + 4 * c4 + (p.pool ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
-            f32x4 yv[4];
             yv[0] = io::ld(&py[o0]);
             if (p.pool) { yv[1] = io::ld(&py[o0 + p.c]); yv[2] = io::ld(&py[o0 + (size_t)p.w * p.c]); yv[3] = io::ld(&py[o0 + (size_t)p.w * p.c + p.c]); }
+        };
+        auto add = [&](long long q, const f32x4& g, const f32x4 (&yv)[4]) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
@@ -238,6 +243,13 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
                 s0[e] += r.gz;
                 s1[e] += r.gz * r.xh;
             }
+        };
+        // (two pixels per trip with all ten loads first measured SLOWER - 1.61 -> 2.0 ms per bf16 training step: the second
+        // register set costs occupancy, and the pass is bound by its ~230 VALU instructions per pixel quad as much as by memory)
+        for (long long q = p0 + row; q < p1; q += rows) {
+            f32x4 ga, ya[4];
+            fetch(q, ga, ya);
+            add(q, ga, ya);
         }
     }
     block_chan_reduce(s0, s1, p.c, p.ws + (size_t)blockIdx.x * 2 * p.c);
@@ -252,11 +264,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
     const T* pdout = (const T*)p.dout;
     T* pdy = (T*)p.dy;
     const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w, nwin = p.pool ? 4 : 1;
-    const long long total = p.opix * cg;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int c4 = (int)(idx % cg);
-        const long long q = idx / cg;
-        const int x = (int)(q % ow), y = (int)((q / ow) % oh), n = (int)(q / ((long long)ow * oh));
+    const unsigned total = (unsigned)(p.opix * cg), ucg = (unsigned)cg;               // (< 2^31: host-checked)
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned q = idx / ucg, t_ = q / (unsigned)ow, un = t_ / (unsigned)oh;
+        const int c4 = (int)(idx - q * ucg);
+        const int x = (int)(q - t_ * (unsigned)ow), y = (int)(t_ - un * (unsigned)oh), n = (int)un;
         const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
         const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
         const f32x4 k1 = *(const f32x4*)&p.k[4 * c4], k2 = *(const f32x4*)&p.k[p.c + 4 * c4];
@@ -379,6 +391,10 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(LstmBwdP p) {
 // One wave owns a 32 (ci) x 32*NT (col) tile of every tap and a slice of the image rows (split-K); each
 // v_mfma_f32_32x32x2_f32 consumes two horizontally adjacent pixels: lane (li, lh) feeds A[pixel lh][ci li] and
 // G[pixel lh][col li], both 128-byte coalesced rows of the NHWC tensors.  Partials go to ws[split][tap][ci][col].
+// WGRAD_XCD: consecutive items share operands - the (ci tile, column group) pairs of ONE slice of image rows read the same rows
+// of `a` and `g`, each tile pair re-reading them (a 32 x 32 tile per wave: ~144 FLOP per byte requested) - so consecutive
+// LOGICAL blocks are placed on the same XCD (vad_xcd_remap): the re-reads then hit that XCD's L2 instead of going to the
+// Infinity Cache / HBM once per XCD.
 struct WgradP {       // a / g: fp32, or bf16 for the IO16 form of the bf16 kernel
     const void* a; const void* g; float* ws;
     int n, h, w, cin, ncols;
@@ -389,7 +405,7 @@ struct WgradP {       // a / g: fp32, or bf16 for the IO16 form of the bf16 kern
 template <int TAPS, int NT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    unsigned item = __builtin_amdgcn_readfirstlane(vad_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));   // see WGRAD_XCD
     if (item >= p.nitems) return;
     const int ct = item % p.ci_tiles; item /= p.ci_tiles;
     const int cgp = item % p.col_groups;
@@ -506,6 +522,13 @@ __device__ __forceinline__ wg_bf16x8 wg_frag(unsigned a, unsigned b, unsigned c,
 
 // IO16: both operands are ALREADY bf16 in memory (VAD_PREC_BF16S): the same access pattern with 16-bit loads (half the bytes
 // through L1) and a pair of values is packed with one v_perm / v_lshl_or instead of a conversion.
+// What bounds it (round 3, measured on the five 3x3 layers of the bf16 training step, all at ~450 TFLOP/s = 0.18 of the bf16
+// peak whatever their shape): the NUMBER of load instructions - 38 per 9 MFMAs, each a 64-lane 2- or 4-byte gather through
+// the texture addresser.  Not their bytes (bf16 tensors: the same time as fp32 tensors), not the VALU work around them (lane
+// offsets as loop invariants with the pixel group in the scalar offset cut it from ~150 to ~50 instructions per group: no
+// change), not latency (the two-deep pipeline below: -8 %), not L2 misses (XCD-aware item order: no change).  The next
+// step is a workgroup-shared LDS tile written transposed ([channel][pixel]) from 16-byte loads, so that a fragment is one
+// ds_read_b128: not built.
 template <int TAPS, int NT, int IO16>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
     constexpr unsigned ES = IO16 ? 2u : 4u;
@@ -518,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
         else return wg_pk(__uint_as_float(a), __uint_as_float(b));
     };
     const int lane = threadIdx.x & 63, li = lane & 31, kb = lane >> 5;
-    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    unsigned item = __builtin_amdgcn_readfirstlane(vad_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));   // see WGRAD_XCD
     if (item >= p.nitems) return;
     const int ct = item % p.ci_tiles; item /= p.ci_tiles;
     const int cgp = item % p.col_groups;
@@ -537,24 +560,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
     const unsigned pix_a = (unsigned)p.cin * ES, pix_g = (unsigned)p.ncols * ES;
     const unsigned lane_a = (unsigned)(ct * 32 + li) * ES, lane_g = (unsigned)(cgp * NT * 32 + li) * ES;
     const __amdgpu_buffer_rsrc_t rzero = vad_rsrc(p.a, 0);
-    for (int row = r0; row < r1; ++row) {
-        const int n_ = row / H, ly = row - n_ * H;
-        const char* fa = (const char*)p.a + (size_t)n_ * H * W * p.cin * ES;
-        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const char*)p.g + (size_t)n_ * H * W * p.ncols * ES, g_bytes);
-        const unsigned gbase = (unsigned)(ly * W) * pix_g;
-        __amdgpu_buffer_rsrc_t rrow[NR];
-        unsigned rbase[NR];
+    // Software pipeline over (row, 16-pixel group): the 38 loads of the NEXT group are in flight while the current group is
+    // packed and multiplied (two register sets).  Without it every group paid a full memory round trip in front of its 9
+    // MFMAs - with two waves per SIMD the matrix pipe was ~13 % busy whatever the operand width (fp32 or bf16 tensors: 2.19 /
+    // 2.18 ms per training step).  The load stage keeps its own position (lrow, lx) and row descriptors; groups past the end
+    // of the slice load through out-of-range offsets (zeros) and the surplus MFMAs add nothing.
+    const int groups_per_row = (W + 15) / 16;
+    int lrow = r0, lx = 0;
+    __amdgpu_buffer_rsrc_t rrow[NR], rg = rzero;
+    unsigned rbase[NR], gbase = 0;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int yy = ly + (NR == 3 ? i - 1 : 0);
-            const bool rok = yy >= 0 && yy < H;
-            rrow[i] = rok ? vad_rsrc(fa, a_bytes) : rzero;       // rows above / below the image: zero-sized descriptor -> zeros
-            rbase[i] = rok ? (unsigned)(yy * W) * pix_a : 0u;
+    for (int i = 0; i < NR; ++i) { rrow[i] = rzero; rbase[i] = 0; }
+    auto LOAD = [&](unsigned (&gv)[NT][8], unsigned (&av)[NR][NE]) {
+        // (no load below sits under a condition that involves a uniform value: hipcc turns those into branches around the
+        // loads and joins the paths with vmcnt(0) - past the end of the slice the DESCRIPTORS become zero-sized instead)
+        if (lx == 0 && lrow >= r1) {
+            rg = rzero;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) rrow[i] = rzero;
+        } else if (lx == 0) {
+            const int n_ = lrow / H, ly = lrow - n_ * H;
+            const char* fa = (const char*)p.a + (size_t)n_ * H * W * p.cin * ES;
+            rg = vad_rsrc((const char*)p.g + (size_t)n_ * H * W * p.ncols * ES, g_bytes);
+            gbase = (unsigned)(ly * W) * pix_g;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int yy = ly + (NR == 3 ? i - 1 : 0);
+                const bool rok = yy >= 0 && yy < H;
+                rrow[i] = rok ? vad_rsrc(fa, a_bytes) : rzero;       // rows above / below the image: zero-sized descriptor -> zeros
+                rbase[i] = rok ? (unsigned)(yy * W) * pix_a : 0u;
+            }
         }
-        for (int lx = 0; lx < W; lx += 16) {
+        {
             const int px0 = lx + 8 * kb;
-            // every load of the step first (38 in flight), then the conversions and the MFMAs
-            unsigned gv[NT][8], av[NR][NE];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int x = px0 + e;
@@ -569,34 +607,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
                     const int x = px0 + e - HALO;
                     av[i][e] = LD(rrow[i], (unsigned)x < (unsigned)W ? lane_a + (unsigned)x * pix_a : VAD_OOB, rbase[i]);
                 }
-            wg_bf16x8 gb[NT];
+        }
+        lx += 16;
+        if (lx >= W) { lx = 0; ++lrow; }
+    };
+    auto COMPUTE = [&](const unsigned (&gv)[NT][8], const unsigned (&av)[NR][NE]) {
+        wg_bf16x8 gb[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                gb[nt] = wg_frag(PK(gv[nt][0], gv[nt][1]), PK(gv[nt][2], gv[nt][3]), PK(gv[nt][4], gv[nt][5]), PK(gv[nt][6], gv[nt][7]));
+        for (int nt = 0; nt < NT; ++nt)
+            gb[nt] = wg_frag(PK(gv[nt][0], gv[nt][1]), PK(gv[nt][2], gv[nt][3]), PK(gv[nt][4], gv[nt][5]), PK(gv[nt][6], gv[nt][7]));
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                if constexpr (TAPS == 9) {
-                    unsigned pe[5], po[4];
+        for (int i = 0; i < NR; ++i) {
+            if constexpr (TAPS == 9) {
+                unsigned pe[5], po[4];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) pe[k] = PK(av[i][2 * k], av[i][2 * k + 1]);
+                for (int k = 0; k < 5; ++k) pe[k] = PK(av[i][2 * k], av[i][2 * k + 1]);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) po[k] = PK(av[i][2 * k + 1], av[i][2 * k + 2]);
-                    const wg_bf16x8 f0 = wg_frag(pe[0], pe[1], pe[2], pe[3]);      // dx = 0: pixels x-1 .. x+6
-                    const wg_bf16x8 f1 = wg_frag(po[0], po[1], po[2], po[3]);      // dx = 1: pixels x   .. x+7
-                    const wg_bf16x8 f2 = wg_frag(pe[1], pe[2], pe[3], pe[4]);      // dx = 2: pixels x+1 .. x+8
+                for (int k = 0; k < 4; ++k) po[k] = PK(av[i][2 * k + 1], av[i][2 * k + 2]);
+                const wg_bf16x8 f0 = wg_frag(pe[0], pe[1], pe[2], pe[3]);      // dx = 0: pixels x-1 .. x+6
+                const wg_bf16x8 f1 = wg_frag(po[0], po[1], po[2], po[3]);      // dx = 1: pixels x   .. x+7
+                const wg_bf16x8 f2 = wg_frag(pe[1], pe[2], pe[3], pe[4]);      // dx = 2: pixels x+1 .. x+8
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[i * 3 + 0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, gb[nt], acc[i * 3 + 0][nt], 0, 0, 0);
-                        acc[i * 3 + 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, gb[nt], acc[i * 3 + 1][nt], 0, 0, 0);
-                        acc[i * 3 + 2][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, gb[nt], acc[i * 3 + 2][nt], 0, 0, 0);
-                    }
-                } else {
-                    const wg_bf16x8 f = wg_frag(PK(av[0][0], av[0][1]), PK(av[0][2], av[0][3]), PK(av[0][4], av[0][5]), PK(av[0][6], av[0][7]));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, gb[nt], acc[0][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[i * 3 + 0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, gb[nt], acc[i * 3 + 0][nt], 0, 0, 0);
+                    acc[i * 3 + 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, gb[nt], acc[i * 3 + 1][nt], 0, 0, 0);
+                    acc[i * 3 + 2][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, gb[nt], acc[i * 3 + 2][nt], 0, 0, 0);
                 }
+            } else {
+                const wg_bf16x8 f = wg_frag(PK(av[0][0], av[0][1]), PK(av[0][2], av[0][3]), PK(av[0][4], av[0][5]), PK(av[0][6], av[0][7]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, gb[nt], acc[0][nt], 0, 0, 0);
             }
         }
+    };
+    const int ngroups = (r1 - r0) * groups_per_row;
+    {
+    unsigned gv0[NT][8], av0[NR][NE], gv1[NT][8], av1[NR][NE];
+    LOAD(gv0, av0);
+    for (int it = 0; it < ngroups; it += 2) {
+        LOAD(gv1, av1);
+        __builtin_amdgcn_sched_barrier(0);
+        COMPUTE(gv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD(gv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        COMPUTE(gv1, av1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -620,7 +677,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_c3_wgrad_kernel(WgradC3P p) {
     constexpr unsigned ES = sizeof(T);
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    unsigned item = __builtin_amdgcn_readfirstlane(vad_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));   // see WGRAD_XCD
     if (item >= p.nitems) return;
     const int ctiles = p.cout / 32;
     const int cgp = item % ctiles;
@@ -676,7 +733,7 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_lds_kernel(WgradC3P p) {
     constexpr unsigned ES = sizeof(T);
     extern __shared__ __attribute__((aligned(16))) float dyn_xs[];
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
-    unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    unsigned item = __builtin_amdgcn_readfirstlane(vad_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);   // see WGRAD_XCD
     if (item >= p.nitems) return;
     const int ctiles = p.cout / 32;
     const int cgp = item % ctiles;
@@ -1131,6 +1188,7 @@ int vad_bn_act_pool_fwd_t(const void* y, int io16, const float* stats, const flo
     BnFwdP p{y, stats, gamma, beta, out, out_fs ? out_fs : (long long)oh * ow * (out_ps ? out_ps : c), out_ps ? out_ps : c,
              remap_t, remap_b, n, h, w, c, act, pool, (long long)n * oh * ow * (c / 4)};
     VAD_REQUIRE(p.out_ps % 4 == 0 && p.out_fs % 4 == 0, "bn_act_pool_fwd: strides must be multiples of 4 elements");
+    VAD_REQUIRE(p.total < (1ll << 31), "bn_act_pool_fwd: %lld items are too many for the kernel's 32-bit index arithmetic", p.total);
     if (io16) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<vad_bf16>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<float>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
@@ -1171,6 +1229,7 @@ int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const flo
     p.t = remap_t; p.b = remap_b; p.ws = ws; p.k = ksums; p.dy = dy; p.s2d = s2d;
     p.n = n; p.h = h; p.w = w; p.c = c; p.act = act; p.pool = pool;
     p.opix = (long long)n * oh * ow;
+    VAD_REQUIRE(p.opix * (c / 4) < (1ll << 31), "bn_act_pool_bwd: %lld items are too many for the kernels' 32-bit index arithmetic", p.opix * (c / 4));
     p.chunk = stats_chunk(p.opix);
     p.dec = nullptr;
     if (g_dec_buf) {
@@ -1270,17 +1329,15 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     p.nitems = (unsigned)items;
     const dim3 grid((unsigned)((items + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
+#define WG16(T_, N_, IO_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<T_, N_, IO_>), grid, dim3(256), 0, s, p);
     if (precision == VAD_PREC_BF16S) {
-        if (taps == 9) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<9, 1, 1>), grid, dim3(256), 0, s, p);
-        else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 4, 1>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1, 1>), grid, dim3(256), 0, s, p);
+        if (taps == 9) { WG16(9, 1, 1) } else if (nt == 4) { WG16(1, 4, 1) } else { WG16(1, 1, 1) }
     } else if (precision == VAD_PREC_BF16) {
-        if (taps == 9) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<9, 1, 0>), grid, dim3(256), 0, s, p);
-        else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 4, 0>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1, 0>), grid, dim3(256), 0, s, p);
+        if (taps == 9) { WG16(9, 1, 0) } else if (nt == 4) { WG16(1, 4, 0) } else { WG16(1, 1, 0) }
     } else if (taps == 9) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), grid, dim3(256), 0, s, p);
     else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
+#undef WG16
     VAD_LAUNCH_CHECK();
     const long long total = (long long)taps * cin * ncols;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);

@@ -175,6 +175,11 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
 static int g_vad_train_stop = -1;
 extern "C" int vad_debug_set_train_stop(int stage) { g_vad_train_stop = stage; return VAD_OK; }
 
+// per-group timing (vad_prof_*, model 2 of vad_prof_slot_name): every launch of the step belongs to one of these groups
+enum { TS_C3_FWD = 0, TS_CONV_FWD, TS_BN_FWD, TS_LSTM_CONV_FWD, TS_LSTM_GATES_FWD, TS_CONVT_FWD, TS_LOSS, TS_WGRAD, TS_BN_BWD,
+       TS_CONVT_DGRAD, TS_LSTM_GATES_BWD, TS_LSTM_CONV_DGRAD, TS_CONV_DGRAD, TS_C3_WGRAD, TS_PACK, TS_STATS_MISC };
+#define PS(slot) VadProfScope ps_(slot, s)
+
 #define TRY(expr)                    \
     do {                             \
         const int rc_ = (expr);      \
@@ -253,6 +258,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     VAD_HIP_TRY(hipMemsetAsync(zeros, 0, 1024 * sizeof(float), s));
 
     // ---- operand packing of the current parameters
+    { PS(TS_PACK);
     TRY(vad_train_pack_conv3x3_c3(P + p.e_w[0], 32, ws + p.pk_e[0], s));
     for (int k = 1; k < 4; ++k)
         TRY(vad_train_pack_conv3x3(P + p.e_w[k], p.encC[k + 1], p.encC[k], ws + p.pk_e[k], ws + p.pk_e_dg[k], precision, s));
@@ -261,6 +267,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     for (int j = 0; j < 3; ++j)
         TRY(vad_train_pack_convt2x2(P + p.d_w[j], p.decC[j], p.decC[j + 1], ws + p.pk_d[j], ws + p.pk_d_dg[j], precision, s));
     if (p.proj) TRY(vad_train_pack_conv1x1_p(P + p.pj_w, L, Hd, ws + p.pk_pj, ws + p.pk_pj_dg, precision, s));
+    }
 
     // ================================================================================== forward
     // encoder (models/video_autoencoder.py:191-215): conv -> BatchNorm(batch stats) -> LeakyReLU(0.2) -> MaxPool2
@@ -268,14 +275,15 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         float* y = A(p.y[k]);
         int sblocks = 0;      // > 0: the convolution wrote the BatchNorm partial sums itself (first layer: no second pass over y)
-        if (k == 0) TRY(vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, io, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s));
-        else TRY(vad_conv3x3_stats(A(p.a[k - 1]), 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, ws + p.chan_ws, &sblocks, s));
+        if (k == 0) { PS(TS_C3_FWD); TRY(vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, io, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s)); }
+        else { PS(TS_CONV_FWD); TRY(vad_conv3x3_stats(A(p.a[k - 1]), 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, ws + p.chan_ws, &sblocks, s)); }
         float* rs = running ? running + p.e_rs[k] : nullptr;
-        if (sblocks > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[k], s));
+        if (sblocks > 0) { PS(TS_STATS_MISC); TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[k], s)); }
         else {
             VAD_REQUIRE(!io, "vid_train_fwd_bwd: bf16 tensors need the convolutions' own BatchNorm partial sums (persistent kernels)");
             TRY(vad_bn_stats(y, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
         }
+        PS(TS_BN_FWD);
         if (k < 3)
             TRY(vad_bn_act_pool_fwd_t(y, io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.a[k]), 0, 0, 0, 0, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         else   // latent features go straight into layer 0's operand buffers: frame b*T+t -> slot t*B+b, x-part
@@ -290,17 +298,19 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         for (int tt = 0; tt < T; ++tt) {
             float* zt = A(p.z[l], (size_t)tt * B * hw * 4 * Hd);
             float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
-            TRY(vad_conv3x3(A(p.cat[l], tt * slab), 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, precision, s));
+            { PS(TS_LSTM_CONV_FWD); TRY(vad_conv3x3(A(p.cat[l], tt * slab), 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, precision, s)); }
             float* h1 = tt + 1 < T ? A(p.cat[l], (tt + 1) * slab + cx) : nullptr;
             float* h2; long long h2_fs; int h2_ps;
             if (l + 1 < NL) { h2 = A(p.cat[l + 1], (size_t)tt * B * hw * 2 * Hd); h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
             else { h2 = A(p.hseq, (size_t)tt * hw * Hd); h2_ps = Hd; h2_fs = (long long)T * hw * Hd; }
+            PS(TS_LSTM_GATES_FWD);
             TRY(vad_lstm_gates_fwd_t(zt, io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, h1, (long long)hw * cin, cin, h2, h2_fs, h2_ps, B, hw, Hd, s));
         }
     }
     // proj (models/video_autoencoder.py:311-312, 346-349): Conv2d k1 hidden -> latent when the two differ, else Identity
     const float* dec_in = A(p.hseq);
     if (p.proj) {
+        PS(TS_CONVT_FWD);
         TRY(vad_conv1x1_p(A(p.hseq), ws + p.pk_pj, P + p.pj_b, A(p.pseq), (long long)N * hw, Hd, L, precision, s));
         dec_in = A(p.pseq);
     }
@@ -310,43 +320,46 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         const float* in = j == 0 ? dec_in : A(p.r[j - 1]);
         float* u = A(p.u[j]);
         int srows = 0;        // > 0: the transposed convolution wrote the BatchNorm partial sums itself
-        TRY(vad_convt2x2_stats(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, precision, ws + p.chan_ws, &srows, s));
+        { PS(TS_CONVT_FWD); TRY(vad_convt2x2_stats(in, 0, ws + p.pk_d[j], P + p.d_b[j], u, 0, N, hj, wj, ci, co, VAD_ACT_NONE, precision, ws + p.chan_ws, &srows, s)); }
         float* rs = running ? running + p.d_rs[j] : nullptr;
-        if (srows > 0) TRY(vad_bn_stats_from_partials(ws + p.chan_ws, srows, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, P + p.d_b[j], s));
+        if (srows > 0) { PS(TS_STATS_MISC); TRY(vad_bn_stats_from_partials(ws + p.chan_ws, srows, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, P + p.d_b[j], s)); }
         else {
             VAD_REQUIRE(!io, "vid_train_fwd_bwd: bf16 tensors need the transposed convolutions' own BatchNorm partial sums");
             TRY(vad_bn_stats(u, (long long)N * 4 * hj * wj, co, eps, mom, ws + p.st_d[j], rs, rs ? rs + co : nullptr, ws + p.chan_ws, s));
         }
+        PS(TS_BN_FWD);
         TRY(vad_bn_act_pool_fwd_t(u, io, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], A(p.r[j]), 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
     }
     // last layer + loss, forward and backward (models/video_autoencoder.py:259-260, train_video.py:55)
     float *g0 = A(p.g[0]), *g2 = A(p.g[2]);
-    TRY(vad_convt_to3_mse_t(A(p.r[2]), io, P + p.t_w, P + p.t_b, x, recon, g0, A(p.dpre), loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, s));
+    { PS(TS_LOSS);
+    TRY(vad_convt_to3_mse_t(A(p.r[2]), io, P + p.t_w, P + p.t_b, x, recon, g0, A(p.dpre), loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, s)); }
 
     if (g_vad_train_stop == 20) return VAD_OK;      // debug: g0 = gradient of the last decoder activation, dpre intact
 
     // ================================================================================== backward
-    TRY(vad_conv_wgrad(A(p.r[2]), A(p.dpre), G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, precision, s));
+    { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.r[2]), A(p.dpre), G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, precision, s)); }
     for (int j = 2; j >= 0; --j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
         const float* in = j == 0 ? dec_in : A(p.r[j - 1]);
         // g0 = d r_j (dense, 2hj x 2wj) -> g2 = d u_j in the space-to-depth view [N][hj][wj][4*co]
+        { PS(TS_BN_BWD);
         TRY(vad_bn_act_pool_bwd_t(A(p.u[j]), io, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.d_g[j], G + p.d_be[j],
-                                  ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
-        TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, precision, s));
+                                  ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s)); }
+        { PS(TS_WGRAD); TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, precision, s)); }
         // bias of a conv that feeds a batch-statistics BatchNorm: sum(dy) = gamma*invstd*(sum(dz) - M*k1 - k2*sum(xhat)) = 0
         // exactly (the batch mean removes any constant).  Autograd returns ~1e-9 rounding noise there, which Adam turns
         // into a +-lr random walk; an exact zero costs no pass over the tensor and leaves the bias where it is.
         VAD_HIP_TRY(hipMemsetAsync(G + p.d_b[j], 0, (size_t)co * sizeof(float), s));
-        TRY(vad_conv1x1_p(g2, ws + p.pk_d_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, precision, s));     // g0 = d (input of convT j)
+        { PS(TS_CONVT_DGRAD); TRY(vad_conv1x1_p(g2, ws + p.pk_d_dg[j], zeros, g0, (long long)N * hj * wj, 4 * co, ci, precision, s)); }     // g0 = d (input of convT j)
         if (g_vad_train_stop == j) return VAD_OK;
     }
     // g0 = gradient of the decoder input [b*T+t][hw][L]; through proj when present
     const float* dhseq = g0;
     if (p.proj) {
-        TRY(vad_conv_wgrad(A(p.hseq), g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, precision, s));
-        TRY(vad_chan_sum_t(g0, io, (long long)N * hw, L, G + p.pj_b, ws + p.chan_ws, s));
-        TRY(vad_conv1x1_p(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, precision, s));
+        { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.hseq), g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, precision, s)); }
+        { PS(TS_STATS_MISC); TRY(vad_chan_sum_t(g0, io, (long long)N * hw, L, G + p.pj_b, ws + p.chan_ws, s)); }
+        { PS(TS_CONVT_DGRAD); TRY(vad_conv1x1_p(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, precision, s)); }
         dhseq = g2;
     }
     // dhseq = d hseq [b*T+t][hw][Hd].  BPTT, top layer first.
@@ -361,29 +374,35 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
             const float* dh2 = tt + 1 < T ? A(p.dcat[l], (tt + 1) * slab + cx) : nullptr;
             float* dzt = A(p.dzl[l], (size_t)tt * B * hw * 4 * Hd);
             const float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
+            { PS(TS_LSTM_GATES_BWD);
             TRY(vad_lstm_gates_bwd_t(A(p.z[l], (size_t)tt * B * hw * 4 * Hd), io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
-                                     dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s));
+                                     dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s)); }
+            PS(TS_LSTM_CONV_DGRAD);
             TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, A(p.dcat[l], tt * slab), 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, precision, s));
         }
         // weight / bias gradients of the cell's convolution over all steps at once (frames = T*B)
-        TRY(vad_conv_wgrad(A(p.cat[l]), A(p.dzl[l]), G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s));
-        TRY(vad_chan_sum_t(A(p.dzl[l]), io, (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s));
+        { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.cat[l]), A(p.dzl[l]), G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s)); }
+        { PS(TS_STATS_MISC); TRY(vad_chan_sum_t(A(p.dzl[l]), io, (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s)); }
         if (g_vad_train_stop == 10 + l) return VAD_OK;
     }
     // encoder, last stage first; the x-part of layer 0's operand gradient is d(latent features)
     for (int k = 3; k >= 0; --k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
+        { PS(TS_BN_BWD);
         if (k == 3)
             TRY(vad_bn_act_pool_bwd_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.dcat[0]), 0, L + Hd, T, B, g2, 0,
                                       G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         else
             TRY(vad_bn_act_pool_bwd_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, g2, 0,
                                       G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
+        }
         VAD_HIP_TRY(hipMemsetAsync(G + p.e_b[k], 0, (size_t)co * sizeof(float), s));      // structurally zero, see the decoder loop
         if (k == 0) {
+            PS(TS_C3_WGRAD);
             TRY(vad_conv_c3_wgrad_t(x, g2, io, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
         } else {
-            TRY(vad_conv_wgrad(A(p.a[k - 1]), g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s));
+            { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.a[k - 1]), g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s)); }
+            PS(TS_CONV_DGRAD);
             TRY(vad_conv3x3(g2, 0, ws + p.pk_e_dg[k], zeros, g0, 0, N, hk, wk, co, ci, VAD_ACT_NONE, 0, precision, s));
         }
     }

@@ -74,7 +74,11 @@ static const char* kImgSlots[] = {"enc1.0", "enc1.0+enc1.3+pool", "enc2.0", "enc
                                   "dec3.3", "dec4.0", "dec4.3+score", "finalize", "latent_nchw", "dec4.0+dec4.3+score"};
 static const char* kVidSlots[] = {"enc.0+pool", "enc.4+pool", "enc.8+pool", "enc.12+pool", "convlstm", "proj",
                                   "dec.0", "dec.3", "dec.6", "dec.9+score", "finalize"};
+static const char* kTrainSlots[] = {"first layer fwd", "conv3x3 fwd", "BatchNorm fwd", "ConvLSTM conv fwd", "ConvLSTM gates fwd", "convT / proj fwd",
+                                    "last layer + loss", "weight gradients", "BatchNorm bwd", "convT / proj dgrad (1x1)", "ConvLSTM gates bwd",
+                                    "ConvLSTM conv dgrad", "conv3x3 dgrad", "first layer wgrad", "operand packing", "statistics finalize + bias sums"};
 extern "C" const char* vad_prof_slot_name(int model, int slot) {
+    if (model == 2 && slot >= 0 && slot < (int)(sizeof kTrainSlots / sizeof *kTrainSlots)) return kTrainSlots[slot];
     if (model == 0 && slot >= 0 && slot < (int)(sizeof kImgSlots / sizeof *kImgSlots)) return kImgSlots[slot];
     if (model == 1 && slot >= 0 && slot < (int)(sizeof kVidSlots / sizeof *kVidSlots)) return kVidSlots[slot];
     return "";
