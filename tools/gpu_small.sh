@@ -1,20 +1,21 @@
 #!/bin/bash
+# the reference's own call sizes after a change to the small-grid paths: model / layer / fuzz tests, then image batch 1 / 16,
+# video 4 x 16 / 1 x 16 and one dense window (eager, no per-layer events)
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-O=gpurun_out; T=${1:-r02b}
-python -m pytest tests -m gpu -q > $O/${T}_tests.log 2>&1 || { tail -40 $O/${T}_tests.log; exit 1; }
-tail -2 $O/${T}_tests.log
-python bench.py --workload video --batch 4 --clip-len 16 --steps 50 --no-split --no-cpu-baseline > $O/${T}_bench_video_b4t16.json 2> $O/${T}_v4.err || { tail -20 $O/${T}_v4.err; exit 1; }
-python bench.py --workload video --batch 4 --clip-len 16 --steps 50 --no-split --no-cpu-baseline --no-wavefront > $O/${T}_bench_video_b4t16_nowf.json 2> $O/${T}_v4n.err || { tail -20 $O/${T}_v4n.err; exit 1; }
-python bench.py --workload video --batch 4 --clip-len 16 --steps 50 --no-split --no-cpu-baseline --no-layer-events > $O/${T}_bench_video_b4t16_noev.json 2> $O/${T}_v4e.err || { tail -20 $O/${T}_v4e.err; exit 1; }
-python bench.py --workload dense --batch 1 --steps 50 --no-split --no-cpu-baseline --no-layer-events > $O/${T}_bench_dense_b1_noev.json 2> $O/${T}_d1e.err || { tail -20 $O/${T}_d1e.err; exit 1; }
-python bench.py --workload dense --batch 1 --steps 50 --no-split --no-cpu-baseline > $O/${T}_bench_dense_b1.json 2> $O/${T}_d1.err || { tail -20 $O/${T}_d1.err; exit 1; }
-python bench.py --workload video --batch 16 --steps 30 --no-split --no-cpu-baseline > $O/${T}_bench_video_b16.json 2> $O/${T}_v16.err || { tail -20 $O/${T}_v16.err; exit 1; }
-python bench.py --workload video --no-split --no-cpu-baseline > $O/${T}_bench_video.json 2> $O/${T}_v.err || { tail -20 $O/${T}_v.err; exit 1; }
-for f in video_b4t16 video_b4t16_nowf video_b4t16_noev dense_b1 dense_b1_noev video_b16 video; do python - <<PY
+O=gpurun_out; T=${1:-small}
+timeout -k 10 900 python -m pytest tests/test_hip_layers.py tests/test_hip_models.py tests/test_hip_fuzz.py -m gpu -x -q > $O/${T}_tests.log 2>&1 || { tail -40 $O/${T}_tests.log; exit 1; }
+tail -1 $O/${T}_tests.log
+C="--no-split --no-cpu-baseline --no-train --no-layer-events --steps 100 --warmup 10"
+python bench.py --batch 1 $C > $O/${T}_img1.json 2> $O/${T}_1.err || { tail -20 $O/${T}_1.err; exit 1; }
+python bench.py --batch 16 $C > $O/${T}_img16.json 2> $O/${T}_2.err || { tail -20 $O/${T}_2.err; exit 1; }
+python bench.py --workload video --batch 4 --clip-len 16 $C > $O/${T}_vid4.json 2> $O/${T}_3.err || { tail -20 $O/${T}_3.err; exit 1; }
+python bench.py --workload video --batch 1 --clip-len 16 $C > $O/${T}_vid1.json 2> $O/${T}_4.err || { tail -20 $O/${T}_4.err; exit 1; }
+python bench.py --workload dense --batch 1 $C > $O/${T}_dense1.json 2> $O/${T}_5.err || { tail -20 $O/${T}_5.err; exit 1; }
+python bench.py --no-split --no-cpu-baseline --no-train --no-video --stream-frames 0 > $O/${T}_img512.json 2> $O/${T}_6.err || { tail -20 $O/${T}_6.err; exit 1; }
+for f in img1 img16 vid4 vid1 dense1 img512; do python - <<PY
 import json
-d=json.load(open("$O/${T}_bench_$f.json"))
-l=d.get("layers") or {}
-print("$f", d["value"], d["ms_per_step"], "lstm ms/step", round(l["convlstm"]["ms"]/d["steps"],3) if l else None)
+d=json.load(open("$O/${T}_$f.json"))
+print("$f", d["value"], d["ms_per_step"])
 PY
 done

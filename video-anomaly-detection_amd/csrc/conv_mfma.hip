@@ -449,6 +449,16 @@ int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const fl
             return pool ? L3(32, 2, 1, 2, 2, MODE_POOL) : L3(32, 2, 1, 2, 2, MODE_PLAIN);
         return pool ? L3(32, 2, 1, 4, 1, MODE_POOL) : L3(32, 2, 1, 4, 1, MODE_PLAIN);
     }
+    // Latency tiling (round 3; the reference's own call sizes: one image in main.py:274, 16 in evaluate.py:240): a launch takes
+    // as long as ONE wave's serial K loop when its grid does not fill the chip - enc4.3 on one 256x256 frame was 16
+    // work-groups and 123 us.  When the throughput tiling gives fewer work-groups than CUs, a work-group takes 4 rows x 16
+    // columns x 64 channels instead (one 32x32 MFMA tile per wave: a quarter of the serial work, 4x the work-groups; same K
+    // order, bit-identical results).
+    if (cout % 64 == 0) {
+        const long long px = (long long)n * ((wd + 15) / 16);
+        const long long nb_thr = cout % 128 == 0 ? px * ((h + 7) / 8) * (cout / 128) : px * ((h + 15) / 16) * (cout / 64);
+        if (nb_thr < vad_num_cus()) return pool ? L3(32, 1, 1, 2, 2, MODE_POOL) : L3(32, 1, 1, 2, 2, MODE_PLAIN);
+    }
     if (cout % 128 == 0) {
         // Small grids (the per-step ConvLSTM gate convolutions of the training path: 16x16 maps, a few dozen frames): the
         // 8-row tile yields 8 work-groups per 16x16x512 frame, too few to fill 256 CUs twice; a 4-row tile doubles them
@@ -1126,7 +1136,12 @@ int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const f
     q.n = n; q.h = h; q.w_ = wd; q.cin = cin; q.cout = cout;
     const int prec = precision;                      // split-fp16 operands: two accumulator sets, so half the columns per wave (bf16 shares the tiling)
     // wave tile 2 x 4 (exact) measured best of {2x4, 1x4, 2x2, 1x2}: dec4.0 2.18 / 2.47 / 2.28 / 2.78 us per frame
-    const int mt = 2, nt = prec ? 2 : 4;
+    int mt = 2, nt = prec ? 2 : 4;
+    // latency tiling (see vad_conv3x3): fewer wave items than the chip has SIMDs -> one 32-pixel x 32-column tile per item
+    // (dec1.0 on one 256x256 frame: 16 items of 27 us each -> 128 items); exact fp32, activated launches = the scoring path
+    const bool small_ct = prec == VAD_PREC_FP32 && act == VAD_ACT_RELU &&
+                          (long long)n * ((wd + 15) / 16) * ((h + 3) / 4) * (4 * cout / 128) < 4ll * vad_num_cus();
+    if (small_ct) { mt = 1; nt = 1; }
     q.tiles_x = (wd + 15) / 16; q.tiles_y = (h + 2 * mt - 1) / (2 * mt);
     q.ngroups = 4 * cout / (32 * nt);
     if (prec == VAD_PREC_BF16S) {          // bf16 tensors in, bf16 tensors out (un-activated: host-checked above)
@@ -1172,7 +1187,8 @@ int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const f
         else if (prec == VAD_PREC_BF16) CT_LAUNCH_(A, 2, 2, 2)                                               \
         else CT_LAUNCH_(A, 2, 4, 0)                                                                          \
     }
-    if (act == VAD_ACT_RELU) CT_LAUNCH(VAD_ACT_RELU)
+    if (small_ct) CT_LAUNCH_(VAD_ACT_RELU, 1, 1, 0)
+    else if (act == VAD_ACT_RELU) CT_LAUNCH(VAD_ACT_RELU)
     else if (act == VAD_ACT_LEAKY) CT_LAUNCH(VAD_ACT_LEAKY)
     else if (with_stats) {       // the statistics epilogue is its own instantiation (un-activated launches only)
         if (prec == VAD_PREC_SPLIT) CT_LAUNCH_ST(VAD_ACT_NONE, 2, 2, 1, 1)
