@@ -221,6 +221,33 @@ def test_video_scores_do_not_depend_on_the_convlstm_kernel_form(vad, clips):
     assert torch.equal(got["seq"][-1:], alone["seq"]) and torch.equal(got["frame"][-1:], alone["frame"])
 
 
+@pytest.mark.parametrize("latent,hid,layers,hw", [(128, 128, 2, 64), (64, 64, 3, 32), (32, 64, 1, 32), (100, 100, 2, 48)])
+def test_convlstm_x_halves_ahead_of_the_recurrence_change_no_bit(vad, latent, hid, layers, hw):
+    """Small launch groups compute bias + the x half of every ConvLSTM step's gate pre-activations ahead of the recurrence (one
+    batched convolution for layer 0 - per SOURCE frame when windows overlap - and one launch per step on a helper stream for
+    the layers above) and the step kernel resumes the accumulator chain with the h half: the chain is cut at a chunk boundary
+    and stored as fp32, so every output is the same bits as with the split switched off (vad_debug_set_conv_variant bit 5),
+    with the layer wavefront on or off."""
+    l = vad.hip.lib()
+    m, _ = _vid_model(vad, latent, hid, layers, 9)
+    x = torch.from_numpy(vad.synth.clips(55, 0, 3, 5, 3, hw, hw)).cuda()
+    frames = torch.from_numpy(vad.synth.frames(56, 0, 9, 3, hw, hw)).cuda()
+    outs = []
+    try:
+        for bits, wf in ((1, 1), (1 | 32, 1), (1, 0), (1 | 32, 0)):
+            l.vad_debug_set_conv_variant(bits)
+            l.vad_debug_set_lstm_wavefront(wf)
+            with torch.no_grad():
+                outs.append((m.score_all(x), m.score_windows(frames, sequence_length=4, stride=1, recon=True)))
+    finally:
+        l.vad_debug_set_conv_variant(1)
+        l.vad_debug_set_lstm_wavefront(1)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+
+
 def test_video_causal_and_clip_independent(vad):
     """Reference properties (SURVEY.md section 4): perturbing frames >= k leaves frame scores < k bit-identical;
     a clip's scores do not depend on the rest of the batch."""

@@ -30,6 +30,8 @@ struct Conv3P {
     const float* w;   const float* bias;
     float* out;       long long out_fs;
     const float* c_prev; float* c_out;               // MODE_LSTM
+    const float* zx; long long zx_fs;                // small-grid ConvLSTM kernel: bias + the x half of the gate pre-activations
+                                                     // [n][h][w][4*hid], computed ahead for all time steps (NULL: computed here)
     const float* w0; const float* b0;                // FUSE_C3: first-layer (3->32) weights [28][32], bias
     int xu8;                                         // FUSE_C3: `in` is uint8 NHWC [N,H,W,3] (normalised in the kernel)
     int n, h, w_, cin, cout, hid;
@@ -271,8 +273,14 @@ extern "C" int vad_debug_set_stamp_buffer(void* p) { g_vad_dbg = (unsigned long 
 static std::atomic<int> g_vad_conv_bits{1};   // bit 0: 1 = persistent + register prefetch (default), 0 = one tile per work-group;
                                               // bit 1: pricing runs, results invalid (exact: drop epilogue stores; split: no weight reads);
                                               // bit 2: alternative cout-64 tiling;
-                                              // bit 3: never use the small-grid (16x16x4) ConvLSTM kernel; bit 4: always use it
-extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 31; return VAD_OK; }
+                                              // bit 3: never use the small-grid (16x16x4) ConvLSTM kernel; bit 4: always use it;
+                                              // bit 5: never compute the ConvLSTM x halves ahead of the recurrence
+extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 63; return VAD_OK; }
+// may the model-level launch sequence split the ConvLSTM steps of small launch groups into x halves (ahead) + h halves?
+bool vad_convlstm_hoist_ok(void) {
+    const int b = g_vad_conv_bits.load(std::memory_order_relaxed);
+    return (b & 1) && !(b & 8) && !(b & 32);
+}
 struct ConvKnobs {
     int variant, stagger, conv64, no_small, all_small;
     ConvKnobs() {
@@ -413,6 +421,14 @@ extern "C" int vad_conv3x3(const float* in, long long in_fs, const float* w, con
 int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const float* bias,
                       float* out, long long out_fs, int n, int h, int wd, int cin, int cout,
                       int act, int pool, int precision, float* stats, int* stats_rows, void* stream) {
+    return vad_conv3x3_kpart(in, in_fs, w, bias, out, out_fs, n, h, wd, cin, cin, cout, act, pool, precision, stats, stats_rows, stream);
+}
+
+// cin_w >= cin: the packed weights have cin_w input channels and the convolution uses their first `cin` (the x half of a
+// ConvLSTM cell's weight (4*hid, x + hid, 3, 3): exact fp32, persistent kernels only)
+int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const float* bias,
+                      float* out, long long out_fs, int n, int h, int wd, int cin, int cin_w, int cout,
+                      int act, int pool, int precision, float* stats, int* stats_rows, void* stream) {
     if (stats_rows) *stats_rows = 0;
     VAD_REQUIRE((stats == nullptr) == (stats_rows == nullptr), "conv3x3: stats and stats_rows come together");
     VAD_REQUIRE(in && w && bias && out, "conv3x3: null pointer");
@@ -430,7 +446,9 @@ int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const fl
     p.w = w; p.bias = bias; p.out = out;
     const int ho = pool ? h / 2 : h, wo = pool ? wd / 2 : wd;
     p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
-    p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout; p.hid = 0;
+    p.h = h; p.w_ = wd; p.cin = cin_w; p.cout = cout; p.hid = 0;
+    VAD_REQUIRE(cin_w == cin || (cin_w > cin && cin_w % 32 == 0 && precision == VAD_PREC_FP32 && kn.variant != 0),
+                "conv3x3: a channel sub-range of the weights (cin %d of %d) is offered by the exact-fp32 persistent kernels only", cin, cin_w);
     hipStream_t s = (hipStream_t)stream;
     const bool with_stats = stats && !pool && act == VAD_ACT_NONE && kn.variant != 0;
     p.stats = with_stats ? stats : nullptr;
@@ -523,10 +541,30 @@ int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const floa
     return VAD_OK;
 }
 
+// the cost model of vad_convlstm_step: does the small-grid (16x16x4) form serve n frames of h x w best?
+bool vad_convlstm_small_wins(int n, int h, int wd, int hid) {
+    const long long nb_big = (long long)n * ((wd + 15) / 16) * ((h + 3) / 4) * (hid / 64);
+    const int ncu = vad_num_cus();
+    const long long m_big = (nb_big + ncu - 1) / ncu;
+    const double cost_big = 2.0 * (double)(m_big / 2) + 1.107 * (double)(m_big % 2);     // in units of half a pair's time
+    const double cost_small = 1.178 * (double)nb_big / (double)ncu;
+    return nb_big < ncu || cost_small < cost_big;
+}
+
 extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_prev, long long h_prev_fs, const float* c_prev,
                                  const float* w, const float* bias, float* h_out, long long h_out_fs,
                                  float* c_out, int n, int h, int wd, int cin_x, int hid, int precision, void* stream) {
-    VAD_REQUIRE(x && w && bias && h_out && c_out, "convlstm_step: null pointer");
+    return vad_convlstm_step_zx(x, x_fs, nullptr, 0, h_prev, h_prev_fs, c_prev, w, bias, h_out, h_out_fs, c_out, n, h, wd, cin_x, hid, precision, stream);
+}
+
+// zx != NULL (exact fp32, small-grid kernel): bias + x half of the gate pre-activations [n][h][w][4*hid] (frame stride zx_fs,
+// 0 = dense) computed ahead by vad_conv3x3_kpart on the cell's weight; the step then multiplies the h half only (nothing at
+// all when h_prev == NULL).  Bit-identical to the un-split step: the accumulator chain is cut at a chunk boundary, stored as
+// fp32 and resumed.  x is unused then.
+int vad_convlstm_step_zx(const float* x, long long x_fs, const float* zx, long long zx_fs, const float* h_prev, long long h_prev_fs,
+                         const float* c_prev, const float* w, const float* bias, float* h_out, long long h_out_fs,
+                         float* c_out, int n, int h, int wd, int cin_x, int hid, int precision, void* stream) {
+    VAD_REQUIRE((x || zx) && w && bias && h_out && c_out, "convlstm_step: null pointer");
     VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "convlstm_step: precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision);
     VAD_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), "convlstm_step: h_prev and c_prev must both be given or both NULL");
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "convlstm_step: bad shape");
@@ -538,6 +576,7 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
     p.w = w; p.bias = bias; p.out = h_out;
     p.out_fs = h_out_fs ? h_out_fs : (long long)h * wd * hid;
     p.c_prev = c_prev; p.c_out = c_out;
+    p.zx = zx; p.zx_fs = zx_fs ? zx_fs : (long long)h * wd * 4 * hid;
     p.h = h; p.w_ = wd; p.cin = cin_x + hid; p.cout = 4 * hid; p.hid = hid;
     // the persistent kernel shares one set of staging offsets between x and h: needs cin_x == hid
     VAD_REQUIRE(!(precision == VAD_PREC_SPLIT && cin_x != hid), "convlstm_step: split precision needs cin_x == hid (got %d, %d)", cin_x, hid);
@@ -549,13 +588,9 @@ extern "C" int vad_convlstm_step(const float* x, long long x_fs, const float* h_
     // runs m = ceil(groups / CUs) of the large work-groups two at a time (measured per step, 16x16 map, hid 128: 0.166 ms alone,
     // 0.30 ms for a pair), while the small form's time is proportional to the work (0.354 ms at 64 clips).  40 clips: 0.281 ms
     // large (64 CUs hold a pair, 192 one group and wait) vs 0.228 ms small; 64 clips: 0.320 vs 0.354.
-    const long long nb_big = (long long)n * ((wd + 15) / 16) * ((h + 3) / 4) * (hid / 64);
-    const int ncu = vad_num_cus();
-    const long long m_big = (nb_big + ncu - 1) / ncu;
-    const double cost_big = 2.0 * (double)(m_big / 2) + 1.107 * (double)(m_big % 2);     // in units of half a pair's time
-    const double cost_small = 1.178 * (double)nb_big / (double)ncu;
-    const bool small_wins = nb_big < ncu || cost_small < cost_big;
-    if (precision == VAD_PREC_FP32 && kn.variant != 0 && !kn.no_small && (small_wins || kn.all_small)) {
+    const bool small_wins = vad_convlstm_small_wins(n, h, wd, hid);
+    VAD_REQUIRE(!zx || (precision == VAD_PREC_FP32 && kn.variant != 0), "convlstm_step: precomputed x halves go with the exact-fp32 small-grid kernel");
+    if (precision == VAD_PREC_FP32 && kn.variant != 0 && ((!kn.no_small && (small_wins || kn.all_small)) || zx)) {
         p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 1) / 2; p.cblocks = hid / 32;
         const long long nb = (long long)n * p.tiles_x * p.tiles_y * p.cblocks;
         p.nblocks = (unsigned)nb; p.n = n;

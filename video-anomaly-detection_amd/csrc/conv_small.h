@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
 
     const int nch_a = p.cin_a / CK;
     const int nch = (p.in2 ? p.cin : p.cin_a) / CK;
+    // x half computed ahead (p.zx: bias + the chunks [0, nch_a) of every accumulator chain, stored as fp32): start behind them
+    const int ch0 = p.zx ? nch_a : 0;
 
     // staging: slot i of this thread = float4 number tid + 256 i of the halo tile (pixel-major, 8 quads per pixel)
     f32x4 pf[NPF];
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
             pf[i] = vad_bload4(r, ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, pstride) + coff + c4 * 4) * 4u : VAD_OOB, 0);
         }
     };
-    issue(0);
+    if (ch0 < nch) issue(ch0);
 
     // B fragments run PB steps ahead in a ring of NB register sets: a step is only 8 MFMAs x 32 cycles, and a weight line that
     // misses L2 comes back from the Infinity Cache in ~550 cycles (one step ahead left ~300 cycles exposed per step: 73 us
@@ -91,8 +93,10 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
         const unsigned woff_ = (unsigned)((step) >> 2) * wtap + (unsigned)((chunk) * 4 + ((step) & 3)) * wstep;       \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) b[buf][g] = vad_bload2(rw, wl[g], woff_);                       \
     }
+    if (ch0 < nch) {
 #pragma unroll
-    for (int s0 = 0; s0 < PB; ++s0) SLOAD_B(s0, 0, s0);
+        for (int s0 = 0; s0 < PB; ++s0) SLOAD_B(s0, ch0, s0);
+    }
 
     // Every other load of the prologue goes out behind the first tile and the first weights, and nothing waits before all
     // of them are requested: ONE round trip in front of the first MFMA (bias -> accumulators -> tile was three in a row, ~3 us
@@ -108,13 +112,24 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
         }
     }
     f32x4 acc[4];
+    if (p.zx) {
+        const __amdgpu_buffer_rsrc_t rz = vad_rsrc(p.zx + (size_t)n * p.zx_fs, (unsigned)(H * W) * (unsigned)(4 * hid) * 4u);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float bv = p.bias[g * hid + hc];
-        acc[g] = f32x4{bv, bv, bv, bv};
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+                acc[g][r] = vad_bload1(rz, (y < H && x < W) ? (unsigned)(__mul24(__mul24(y, W) + x, 4 * hid) + g * hid + hc) * 4u : VAD_OOB, 0);
+            }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float bv = p.bias[g * hid + hc];
+            acc[g] = f32x4{bv, bv, bv, bv};
+        }
     }
 
-    for (int ch = 0; ch < nch; ++ch) {
+    for (int ch = ch0; ch < nch; ++ch) {
         __syncthreads();                               // every wave is done reading the previous chunk
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {

@@ -260,8 +260,11 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
 // models/video_autoencoder.py:144-145).
 namespace {
 struct VidWs {
-    size_t act, enc, hseq, cst, proj, parts, total;
+    size_t act, enc, hseq, cst, proj, parts, zx0, zxl, total;
 };
+// work-groups of one ConvLSTM step in the large (32x32x2) tiling: below one per CU the layers run as a wavefront on helper
+// streams and the steps' x halves are computed ahead of the recurrence
+long long vid_lstm_groups(int nc, int h16, int w16, int hid) { return (long long)nc * ((w16 + 15) / 16) * ((h16 + 3) / 4) * (hid / 64); }
 VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_real, int layers) {
     VidWs z{};
     const int latent = vad_vid_latent_p(latent_real, hid_real), hid = vad_vid_hid_p(latent_real, hid_real);
@@ -273,7 +276,12 @@ VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_re
     z.cst = up256(sizeof(float) * (size_t)chunk * p16 * hid);
     z.proj = (hid_real != latent_real) ? up256(sizeof(float) * n * p16 * latent) : 0;
     z.parts = up256(sizeof(float) * n * (size_t)vad_score_partials(1, h, w));
-    z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst) + z.proj + z.parts;   // h sequence + cell state per layer
+    // small launch groups: bias + x half of every step's gate pre-activations, [frames][h/16][w/16][4*hid] - layer 0 per SOURCE
+    // frame (overlapping windows share them), the layers above per (clip, t)
+    const bool small = vid_lstm_groups(chunk, h / 16, w / 16, hid) < 256;
+    z.zx0 = small ? up256(sizeof(float) * nf * p16 * 4 * hid) : 0;
+    z.zxl = small ? up256(sizeof(float) * n * p16 * 4 * hid) : 0;
+    z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst) + z.proj + z.parts + z.zx0 + (size_t)(layers - 1) * z.zxl;   // h sequence + cell state per layer
     return z;
 }
 
@@ -284,8 +292,10 @@ VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_re
 // asynchronous and capturable into a hipGraph (after one eager call has created the streams).
 struct VadSideStreams {
     int dev = -1, n = 0;
-    hipStream_t st[7] = {};
+    hipStream_t st[7] = {};       // st[l-1]: the steps of layer l
+    hipStream_t xs[7] = {};       // xs[l-1]: the x halves of layer l's steps (one launch per step, as soon as layer l-1 has produced its input)
     hipEvent_t done[8] = {};      // done[l]: layer l finished its latest step
+    hipEvent_t xdone[8] = {};     // xdone[l]: the x half of layer l's next step is ready
     hipEvent_t fork = nullptr;
 };
 static thread_local VadSideStreams t_side;
@@ -299,9 +309,11 @@ static int side_streams(int layers, VadSideStreams** out) {
         S.dev = dev;
         VAD_HIP_TRY(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
         for (int l = 0; l < 8; ++l) VAD_HIP_TRY(hipEventCreateWithFlags(&S.done[l], hipEventDisableTiming));
+        for (int l = 0; l < 8; ++l) VAD_HIP_TRY(hipEventCreateWithFlags(&S.xdone[l], hipEventDisableTiming));
     }
     while (S.n < layers - 1) {
         VAD_HIP_TRY(hipStreamCreateWithFlags(&S.st[S.n], hipStreamNonBlocking));
+        VAD_HIP_TRY(hipStreamCreateWithFlags(&S.xs[S.n], hipStreamNonBlocking));
         ++S.n;
     }
     *out = &S;
@@ -334,7 +346,12 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
     for (int l = 0; l < layers; ++l) { CS[l] = (float*)base; base += Z.cst; }
     float* P = nullptr;
     if (L.has_proj) { P = (float*)base; base += Z.proj; }
-    float* parts = (float*)base;
+    float* parts = (float*)base; base += Z.parts;
+    float* ZX[8] = {};
+    if (Z.zx0) {
+        ZX[0] = (float*)base; base += Z.zx0;
+        for (int l = 1; l < layers; ++l) { ZX[l] = (float*)base; base += Z.zxl; }
+    }
     const int nparts = vad_score_partials(1, h, w);
     const int h16 = h / 16, w16 = w / 16;
     const long long fs_lat = (long long)h16 * w16 * latent, fs_hid = (long long)h16 * w16 * hid;
@@ -353,38 +370,73 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, precision, s)); }
         { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, precision, s)); }
         // ConvLSTM, zero initial state (models/video_autoencoder.py:144-166).  Step (l, t) needs (l, t-1) and (l-1, t) only.
+        const long long fs_zx = (long long)h16 * w16 * 4 * hid;
+        // x halves ahead of the recurrence (small launch groups, exact fp32): a step's accumulator chain runs over the x chunks
+        // first and the h chunks second, so bias + x half can be computed for ALL steps of layer 0 in one batched convolution
+        // (per source frame: overlapping windows share it) and per step for the layers above, stored as fp32 and resumed by
+        // the step kernel - bit-identical, and the serial K loop of a step halves (models/video_autoencoder.py:67-70 multiplies
+        // cat([x, h]) inside the recurrence).
+        const bool hoist = precision == VAD_PREC_FP32 && ZX[0] && vad_convlstm_hoist_ok();
         auto lstm_step = [&](int l, int ti, hipStream_t st) -> int {
             const float* xin_l = (l == 0) ? E : HS[l - 1];
             const long long fs_in = (l == 0) ? fs_lat : fs_hid;
             const long long clip_in = (l == 0) ? (long long)cs * fs_lat : (long long)t * fs_hid;   // layer 0 reads the shared features
+            const long long clip_zx = (l == 0) ? (long long)cs * fs_zx : (long long)t * fs_zx;
             VadProfScope ps(4, st);
-            return vad_convlstm_step(xin_l + (size_t)ti * fs_in, clip_in,
-                                     ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
-                                     ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l),
-                                     HS[l] + (size_t)ti * fs_hid, (long long)t * fs_hid, CS[l],
-                                     nc, h16, w16, (l == 0) ? latent : hid, hid, precision, st);
+            return vad_convlstm_step_zx(xin_l + (size_t)ti * fs_in, clip_in, hoist ? ZX[l] + (size_t)ti * fs_zx : nullptr, clip_zx,
+                                        ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
+                                        ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l),
+                                        HS[l] + (size_t)ti * fs_hid, (long long)t * fs_hid, CS[l],
+                                        nc, h16, w16, (l == 0) ? latent : hid, hid, precision, st);
+        };
+        // bias + x half of layer l's step ti for the nc clips (l >= 1), or of every source frame (l == 0, ti < 0)
+        auto lstm_xhalf = [&](int l, int ti, hipStream_t st) -> int {
+            VadProfScope ps(4, st);
+            if (l == 0)
+                return vad_conv3x3_kpart(E, 0, W_(4), B_(4), ZX[0], 0, nf, h16, w16, latent, latent + hid, 4 * hid, VAD_ACT_NONE, 0,
+                                         VAD_PREC_FP32, nullptr, nullptr, st);
+            return vad_conv3x3_kpart(HS[l - 1] + (size_t)ti * fs_hid, (long long)t * fs_hid, W_(4 + l), B_(4 + l), ZX[l] + (size_t)ti * fs_zx,
+                                     (long long)t * fs_zx, nc, h16, w16, hid, 2 * hid, 4 * hid, VAD_ACT_NONE, 0, VAD_PREC_FP32, nullptr, nullptr, st);
         };
         // Large launch groups fill the chip with one step: layers outer, time inner on the caller's stream (the reference's
         // order).  Small ones (the reference's batch sizes; a step is then one wave's serial K loop on a fraction of the
         // CUs) run the layers as a wavefront on helper streams.
-        const long long lstm_groups = (long long)nc * ((w16 + 15) / 16) * ((h16 + 3) / 4) * (hid / 64);
+        const long long lstm_groups = vid_lstm_groups(nc, h16, w16, hid);
         const int wf = g_vad_lstm_wavefront.load(std::memory_order_relaxed);
+        if (hoist) TRY(lstm_xhalf(0, -1, s));
         if (layers > 1 && ((lstm_groups < 256 && wf) || wf == 2)) {
             VadSideStreams* S = nullptr;
             TRY(side_streams(layers, &S));
-            VAD_HIP_TRY(hipEventRecord(S->fork, s));                          // the encoder's output is ready
-            for (int l = 1; l < layers; ++l) VAD_HIP_TRY(hipStreamWaitEvent(S->st[l - 1], S->fork, 0));
+            VAD_HIP_TRY(hipEventRecord(S->fork, s));                          // the encoder's output (and layer 0's x halves) are ready
+            for (int l = 1; l < layers; ++l) {
+                VAD_HIP_TRY(hipStreamWaitEvent(S->st[l - 1], S->fork, 0));
+                if (hoist) VAD_HIP_TRY(hipStreamWaitEvent(S->xs[l - 1], S->fork, 0));
+            }
             for (int ti = 0; ti < t; ++ti)
                 for (int l = 0; l < layers; ++l) {
                     hipStream_t st = l ? S->st[l - 1] : s;
-                    if (l) VAD_HIP_TRY(hipStreamWaitEvent(st, S->done[l - 1], 0));     // (l-1, ti) finished
+                    if (l && hoist) {                                                  // (l-1, ti) finished -> x half of (l, ti) -> step (l, ti)
+                        hipStream_t xs = S->xs[l - 1];
+                        VAD_HIP_TRY(hipStreamWaitEvent(xs, S->done[l - 1], 0));
+                        TRY(lstm_xhalf(l, ti, xs));
+                        VAD_HIP_TRY(hipEventRecord(S->xdone[l], xs));
+                        VAD_HIP_TRY(hipStreamWaitEvent(st, S->xdone[l], 0));
+                    } else if (l) {
+                        VAD_HIP_TRY(hipStreamWaitEvent(st, S->done[l - 1], 0));     // (l-1, ti) finished
+                    }
                     TRY(lstm_step(l, ti, st));
                     if (l + 1 < layers || ti + 1 == t) VAD_HIP_TRY(hipEventRecord(S->done[l], st));
                 }
-            for (int l = 1; l < layers; ++l) VAD_HIP_TRY(hipStreamWaitEvent(s, S->done[l], 0));   // join
+            for (int l = 1; l < layers; ++l) VAD_HIP_TRY(hipStreamWaitEvent(s, S->done[l], 0));   // join (the x streams end before their steps)
         } else {
-            for (int l = 0; l < layers; ++l)
+            for (int l = 0; l < layers; ++l) {
+                if (l && hoist) {                        // one batched launch per layer: its whole input sequence exists
+                    VadProfScope ps(4, s);
+                    TRY(vad_conv3x3_kpart(HS[l - 1], 0, W_(4 + l), B_(4 + l), ZX[l], 0, nc * t, h16, w16, hid, 2 * hid, 4 * hid, VAD_ACT_NONE, 0,
+                                          VAD_PREC_FP32, nullptr, nullptr, s));
+                }
                 for (int ti = 0; ti < t; ++ti) TRY(lstm_step(l, ti, s));
+            }
         }
         const float* dec_in = HS[layers - 1];
         int li = 4 + layers;

@@ -147,6 +147,13 @@ int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bi
                          int act, int pool, float* stats, int* stats_blocks, void* stream);   // + BatchNorm partial sums (training forward)
 int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs, int n, int h,
                       int wd, int cin, int cout, int act, int pool, int precision, float* stats, int* stats_rows, void* stream);
+int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs, int n, int h,
+                      int wd, int cin, int cin_w, int cout, int act, int pool, int precision, float* stats, int* stats_rows, void* stream);
+bool vad_convlstm_small_wins(int n, int h, int wd, int hid);
+bool vad_convlstm_hoist_ok(void);
+int vad_convlstm_step_zx(const float* x, long long x_fs, const float* zx, long long zx_fs, const float* h_prev, long long h_prev_fs,
+                         const float* c_prev, const float* w, const float* bias, float* h_out, long long h_out_fs,
+                         float* c_out, int n, int h, int wd, int cin_x, int hid, int precision, void* stream);
 size_t vad_conv3x3_stats_floats(int cout);
 int vad_convt2x2_stats(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs, int n, int h,
                        int wd, int cin, int cout, int act, int precision, float* stats, int* stats_rows, void* stream);
