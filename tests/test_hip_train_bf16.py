@@ -98,8 +98,17 @@ def test_conv3x3_on_bf16_tensors_equals_the_bf16_operand_kernels(vad, n, h, w, c
     ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, 9, cin, cout))
     w32, w16 = _nan32(cout, cin, 3, 3), _nan32(cout, cin, 3, 3)
     vad.hip.check(l.vad_conv_wgrad(a32.data_ptr(), g32.data_ptr(), w32.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16, H.stream()))
-    vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16S, H.stream()))
+    l.vad_debug_set_wgrad_pairs(0)
+    try:
+        vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16S, H.stream()))
+    finally:
+        l.vad_debug_set_wgrad_pairs(1)
     assert torch.equal(w16, w32)                                             # parameter gradients stay fp32
+    # default: the paired-channel kernel where cin and cout are multiples of 64 (dword loads, 64 x 64 tiles, one item per kernel
+    # row): the same bf16 products, fp32 sums split differently over the image rows
+    w16p = _nan32(cout, cin, 3, 3)
+    vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16p.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16S, H.stream()))
+    assert float((w16p - w32).abs().max()) < 2e-5 * float(w32.abs().max())
     # and the bf16-operand kernel itself is held to float64 on these inputs (products exact, fp32 sums)
     ref = torch.nn.functional.conv2d(a32.double().permute(0, 3, 1, 2).cpu(), wt.to(torch.bfloat16).double().cpu(), bias.double().cpu(), padding=1)
     assert float((o32.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
@@ -123,8 +132,15 @@ def test_convt2x2_on_bf16_tensors(vad, n, h, w, cin, cout):
     ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, 1, cin, 4 * cout))
     w32, w16 = _nan32(cin, cout, 2, 2), _nan32(cin, cout, 2, 2)
     vad.hip.check(l.vad_conv_wgrad(a32.data_ptr(), g32.data_ptr(), w32.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16, H.stream()))
-    vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16S, H.stream()))
+    l.vad_debug_set_wgrad_pairs(0)
+    try:
+        vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16S, H.stream()))
+    finally:
+        l.vad_debug_set_wgrad_pairs(1)
     assert torch.equal(w16, w32)
+    w16p = _nan32(cin, cout, 2, 2)
+    vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16p.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16S, H.stream()))
+    assert float((w16p - w32).abs().max()) < 2e-5 * float(w32.abs().max())
     # 1x1 data gradient (K = 4*cout) on bf16 operands: against float64 on the same bf16 values; products are exact, the sum
     # is fp32, the result is rounded to bf16 (2^-9 relative)
     # (pixel counts that are not a multiple of 16 run as one ragged frame: (2, 5, 3) -> 30 pixels)

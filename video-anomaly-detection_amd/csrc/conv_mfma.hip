@@ -475,7 +475,10 @@ int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const fl
     if (cout % 64 == 0) {
         const long long px = (long long)n * ((wd + 15) / 16);
         const long long nb_thr = cout % 128 == 0 ? px * ((h + 7) / 8) * (cout / 128) : px * ((h + 15) / 16) * (cout / 64);
-        if (nb_thr < vad_num_cus()) return pool ? L3(32, 1, 1, 2, 2, MODE_POOL) : L3(32, 1, 1, 2, 2, MODE_PLAIN);
+        // (not for the training forward's statistics launches: the convolution's values do not depend on the tiling, but its
+        // BatchNorm partial sums are grouped by work-group, and the multi-step loss-curve gate of tests/test_hip_train_step.py was
+        // calibrated - 1.1e-4 against a 5e-4 bound, chaotic in the last digits of the statistics - on the throughput tilings)
+        if (nb_thr < vad_num_cus() && !with_stats) return pool ? L3(32, 1, 1, 2, 2, MODE_POOL) : L3(32, 1, 1, 2, 2, MODE_PLAIN);
     }
     if (cout % 128 == 0) {
         // Small grids (the per-step ConvLSTM gate convolutions of the training path: 16x16 maps, a few dozen frames): the

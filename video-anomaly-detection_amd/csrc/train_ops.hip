@@ -15,6 +15,8 @@
 //   * Adam with L2 weight decay folded into the gradient (torch.optim.Adam semantics) over ONE flat parameter buffer.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "vad_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -666,6 +668,86 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
             }
 }
 
+// bf16 TENSORS, cin and ncols multiples of 64: the same GEMM with DWORD loads.  A dword holds the channel pair (2l, 2l+1) of
+// one pixel, so the 10 (3x3: 8 pixels + halo) dwords a lane loads for a row feed TWO M-tiles - the tile's even channels from
+// the low halves, its odd channels from the high halves (one v_perm per packed pair) - and the 8 dwords of the gradient feed
+// two N-tiles: a wave owns a 64 x 64 tile of ONE kernel row (three taps) and issues 18 loads per 12 MFMAs where the kernel
+// above issues 38 per 9.  That ratio is what bounds these kernels (see above): every load instruction is a 64-lane gather
+// through the texture addresser whatever its width.  The three kernel rows of a tile are three work items (each re-reads the
+// gradient row).  Row m of an M-tile is channel 64 ct + 2 m + parity, column j of an N-tile is column 64 cg + 2 j + parity.
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x2_kernel(WgradP p) {
+    constexpr int ND = TAPS == 9 ? 3 : 1, HALO = TAPS == 9 ? 1 : 0, NE = 8 + 2 * HALO, NPASS = TAPS == 9 ? 3 : 1;
+    const int lane = threadIdx.x & 63, li = lane & 31, kb = lane >> 5;
+    unsigned item = __builtin_amdgcn_readfirstlane(vad_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));   // see WGRAD_XCD
+    if (item >= p.nitems) return;
+    const int ct = item % p.ci_tiles; item /= p.ci_tiles;
+    const int cgp = item % p.col_groups; item /= p.col_groups;
+    const int pass = item % NPASS;
+    const int split = item / NPASS;
+    const int H = p.h, W = p.w, total_rows = p.n * H;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * 2u, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * 2u;
+    const unsigned pix_a = (unsigned)p.cin * 2u, pix_g = (unsigned)p.ncols * 2u;
+    const unsigned lane_a = (unsigned)(ct * 64 + 2 * li) * 2u, lane_g = (unsigned)(cgp * 64 + 2 * li) * 2u;
+    f32x16 acc[ND][2][2];          // [dx][channel parity][column parity]
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][q >> 1][q & 1][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rzero = vad_rsrc(p.a, 0);
+    const int dy = TAPS == 9 ? pass - 1 : 0;
+    for (int row = r0; row < r1; ++row) {
+        const int n_ = row / H, ly = row - n_ * H, yy = ly + dy;
+        if (yy < 0 || yy >= H) continue;                          // (uniform) this kernel row falls outside the image: zero padding
+        const __amdgpu_buffer_rsrc_t ra = vad_rsrc((const char*)p.a + (size_t)n_ * H * W * p.cin * 2u, a_bytes);
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const char*)p.g + (size_t)n_ * H * W * p.ncols * 2u, g_bytes);
+        const unsigned abase = (unsigned)(yy * W) * pix_a, gbase = (unsigned)(ly * W) * pix_g;
+        for (int lx = 0; lx < W; lx += 16) {
+            const int px0 = lx + 8 * kb;
+            unsigned gd[8], ad[NE];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int x = px0 + e;
+                gd[e] = __builtin_bit_cast(unsigned, vad_bload1(rg, x < W ? lane_g + (unsigned)x * pix_g : VAD_OOB, gbase));
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int x = px0 + e - HALO;
+                ad[e] = __builtin_bit_cast(unsigned, vad_bload1(ra, (unsigned)x < (unsigned)W ? lane_a + (unsigned)x * pix_a : VAD_OOB, abase));
+            }
+            // low / high halves of two dwords -> one packed pair (pixels k, k+1 of one channel)
+            auto lo2 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); };
+            auto hi2 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); };
+            wg_bf16x8 gb[2];
+            gb[0] = wg_frag(lo2(gd[0], gd[1]), lo2(gd[2], gd[3]), lo2(gd[4], gd[5]), lo2(gd[6], gd[7]));
+            gb[1] = wg_frag(hi2(gd[0], gd[1]), hi2(gd[2], gd[3]), hi2(gd[4], gd[5]), hi2(gd[6], gd[7]));
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {                        // window of 8 pixels starting at element d
+                const wg_bf16x8 fe = wg_frag(lo2(ad[d], ad[d + 1]), lo2(ad[d + 2], ad[d + 3]), lo2(ad[d + 4], ad[d + 5]), lo2(ad[d + 6], ad[d + 7]));
+                const wg_bf16x8 fo = wg_frag(hi2(ad[d], ad[d + 1]), hi2(ad[d + 2], ad[d + 3]), hi2(ad[d + 4], ad[d + 5]), hi2(ad[d + 6], ad[d + 7]));
+                acc[d][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fe, gb[0], acc[d][0][0], 0, 0, 0);
+                acc[d][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fe, gb[1], acc[d][0][1], 0, 0, 0);
+                acc[d][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo, gb[0], acc[d][1][0], 0, 0, 0);
+                acc[d][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo, gb[1], acc[d][1][1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int tap = (TAPS == 9 ? 3 * pass : 0) + d;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ct * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kb) + pa;
+                *(f32x2*)&p.ws[(((size_t)split * TAPS + tap) * p.cin + ci) * p.ncols + cgp * 64 + 2 * li] = f32x2{acc[d][pa][0][r], acc[d][pa][1][r]};
+            }
+    }
+}
+
 // First layer (input NCHW, 3 channels): M index k = c*9 + tap (27, padded to 32), A gathered from the input planes.
 struct WgradC3P {     // g: fp32 or bf16 (the kernels' storage type)
     const float* x; const void* g; float* ws;
@@ -1289,6 +1371,11 @@ int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const
     return VAD_OK;
 }
 
+// debug / A-B: 0 = the bf16-tensor mode uses the one-channel-per-lane kernel everywhere (default 1: paired-channel kernel where
+// cin and ncols are multiples of 64)
+static std::atomic<int> g_wgrad_x2{1};
+extern "C" int vad_debug_set_wgrad_pairs(int on) { g_wgrad_x2 = on; return VAD_OK; }
+
 // split-K factor: enough waves to fill the chip (~4096), never more splits than image rows.  Measured on both training
 // steps (32 clips / 128 images): a 2048-wave target is within noise of 4096 (35.8 vs 35.6-36.0 ms, 38.5 vs 39.0 ms), 1024
 // is 13 % slower; the partial buffers are small either way.
@@ -1304,7 +1391,12 @@ extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int 
     if (n <= 0 || h <= 0 || cin <= 0 || ncols <= 0 || cin % 32 || ncols % 32 || (taps != 9 && taps != 1)) return 0;
     const int nt = (taps == 1 && ncols % 128 == 0) ? 4 : 1;
     const long long tiles = (long long)(cin / 32) * (ncols / (32 * nt));
-    return (size_t)wgrad_splits(tiles, n * h) * taps * cin * ncols;
+    int splits = wgrad_splits(tiles, n * h);
+    if (cin % 64 == 0 && ncols % 64 == 0) {      // the paired-channel kernel of the bf16-tensor mode: 64 x 64 tiles, one item per kernel row
+        const int s2 = wgrad_splits((long long)(cin / 64) * (ncols / 64) * (taps == 9 ? 3 : 1), n * h);
+        if (s2 > splits) splits = s2;
+    }
+    return (size_t)splits * taps * cin * ncols;
 }
 
 extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
@@ -1318,6 +1410,25 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     VAD_REQUIRE((long long)h * w * cin * 4 < (1ll << 31) && (long long)h * w * ncols * 4 < (1ll << 31), "conv_wgrad: frame too large for 32-bit offsets");
     WgradP p{};
     p.a = a; p.g = g; p.ws = ws; p.n = n; p.h = h; p.w = w; p.cin = cin; p.ncols = ncols;
+    if (precision == VAD_PREC_BF16S && cin % 64 == 0 && ncols % 64 == 0 && g_wgrad_x2.load(std::memory_order_relaxed)) {
+        const int npass = taps == 9 ? 3 : 1;
+        p.ci_tiles = cin / 64; p.col_groups = ncols / 64;
+        const long long tiles2 = (long long)p.ci_tiles * p.col_groups * npass;
+        p.splits = wgrad_splits(tiles2, n * h);
+        p.rows_per_split = (n * h + p.splits - 1) / p.splits;
+        p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;
+        const long long items2 = tiles2 * p.splits;
+        VAD_REQUIRE(items2 < (1ll << 31), "conv_wgrad: too many work items");
+        p.nitems = (unsigned)items2;
+        hipStream_t s2 = (hipStream_t)stream;
+        if (taps == 9) hipLaunchKernelGGL(conv_wgrad_bf16x2_kernel<9>, dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, s2, p);
+        else hipLaunchKernelGGL(conv_wgrad_bf16x2_kernel<1>, dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, s2, p);
+        VAD_LAUNCH_CHECK();
+        const long long total2 = (long long)taps * cin * ncols;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total2 + 63) / 64)), dim3(256), 0, s2, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
     const int nt = (taps == 1 && ncols % 128 == 0) ? 4 : 1;
     p.ci_tiles = cin / 32; p.col_groups = ncols / (32 * nt);
     const long long tiles = (long long)p.ci_tiles * p.col_groups;
