@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 T=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 for wl in image video; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_trace_$wl -- python3 $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-train > $R/gpurun_out/${T}_trace_$wl.json 2> $R/gpurun_out/${T}_trace_$wl.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_trace_$wl -- python3 $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-train --no-video --stream-frames 0 > $R/gpurun_out/${T}_trace_$wl.json 2> $R/gpurun_out/${T}_trace_$wl.err
   echo "trace $wl done"
 done
 cd $R

@@ -457,11 +457,9 @@ int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const fl
 #define L3(CK, MT, NT, WM, WN, MODE) conv3_stats_rows(launch_conv3<CK, MT, NT, WM, WN, MODE>(p, n, act, s, precision, kn.variant, kn), p, with_stats, stats_rows)
     if (precision != VAD_PREC_FP32) {
         // split-fp16 operands double the accumulators (main + cross terms): keep one N-tile per wave (bf16 shares the tilings)
-        // (small grids - the per-step ConvLSTM data gradients of the training path: 32 frames of 16x16 with cout 256 are 128
-        // work-groups of the 128-column tiling on 256 CUs - take the 64-column tiling and twice the work-groups)
-        const long long nb128 = (long long)n * ((wd + 15) / 16) * ((h + 7) / 8) * (cout / 128);
-        const bool fills = nb128 >= vad_num_cus() || cout % 64 != 0;
-        if (cout % 128 == 0 && !kn.conv64 && fills)   // one B fragment per 4 M-tiles: halves the weight traffic through L1
+        // (a 64-column tiling for grids of the 128-column one that leave CUs idle - the per-step ConvLSTM data gradients of the
+        // bf16 training step: 128 work-groups - measured no gain: 56 vs 53 us per launch; not kept)
+        if (cout % 128 == 0 && !kn.conv64)   // one B fragment per 4 M-tiles: halves the weight traffic through L1
             return pool ? L3(32, 4, 1, 1, 4, MODE_POOL) : L3(32, 4, 1, 1, 4, MODE_PLAIN);
         if (cout % 64 == 0)
             return pool ? L3(32, 2, 1, 2, 2, MODE_POOL) : L3(32, 2, 1, 2, 2, MODE_PLAIN);
