@@ -22,7 +22,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         k = row["Kernel_Name"]
         if not any(s in k for s in ("conv", "score", "wgrad")):
             continue
-        k = k.split("(")[0].replace("void ", "")
+        k = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         dur[k][row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3   # us
 out = {}

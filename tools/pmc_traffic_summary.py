@@ -12,14 +12,14 @@ def load(d):
     acc = defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+            acc[row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(row["Counter_Value"]))
     return acc
 
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    if not any(s in k for s in ("conv", "score", "convt")):
+    if not any(s in k for s in ("conv", "score", "convt", "dec4")):
         continue
     f, w = fetch.get(k, []), write.get(k, [])
     out[k] = {"launches": len(f), "fetch_bytes_per_launch_corrected": 2 * 1024 * sum(f) / max(len(f), 1),

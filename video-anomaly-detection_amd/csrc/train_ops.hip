@@ -145,10 +145,12 @@ __device__ __forceinline__ f32x4 bn_apply(f32x4 y, f32x4 mean, f32x4 invstd, f32
     return v;
 }
 
-template <typename T>
+// POOL / ACT are compile-time (host dispatch): with run-time flags every element paid the selects of both activations and the
+// window loop's guards - VALU work these passes can no longer hide once the tensors are bf16.
+template <typename T, int POOL, int ACT>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
     typedef vad_io4<T> io;
-    const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w;
+    const int cg = p.c >> 2, oh = POOL ? p.h / 2 : p.h, ow = POOL ? p.w / 2 : p.w;
     // (32-bit index arithmetic, host-checked: three 64-bit divisions per item cost more than the item's memory traffic once
     // the tensors are bf16)
     const unsigned total = (unsigned)p.total, ucg = (unsigned)cg, uow = (unsigned)ow, uoh = (unsigned)oh;
@@ -162,16 +164,16 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
         const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
         const T* src = (const T*)p.y + (size_t)n * p.h * p.w * p.c + 4 * c4;
         f32x4 v;
-        if (p.pool) {
+        if constexpr (POOL) {
             const size_t o = ((size_t)(2 * y) * p.w + 2 * x) * p.c;
-            v = bn_apply(io::ld(&src[o]), mean, invstd, gamma, beta, p.act);
-            const f32x4 v1 = bn_apply(io::ld(&src[o + p.c]), mean, invstd, gamma, beta, p.act);
-            const f32x4 v2 = bn_apply(io::ld(&src[o + (size_t)p.w * p.c]), mean, invstd, gamma, beta, p.act);
-            const f32x4 v3 = bn_apply(io::ld(&src[o + (size_t)p.w * p.c + p.c]), mean, invstd, gamma, beta, p.act);
+            v = bn_apply(io::ld(&src[o]), mean, invstd, gamma, beta, ACT);
+            const f32x4 v1 = bn_apply(io::ld(&src[o + p.c]), mean, invstd, gamma, beta, ACT);
+            const f32x4 v2 = bn_apply(io::ld(&src[o + (size_t)p.w * p.c]), mean, invstd, gamma, beta, ACT);
+            const f32x4 v3 = bn_apply(io::ld(&src[o + (size_t)p.w * p.c + p.c]), mean, invstd, gamma, beta, ACT);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(v[e], v1[e]), fmaxf(v2[e], v3[e]));
         } else {
-            v = bn_apply(io::ld(&src[((size_t)y * p.w + x) * p.c]), mean, invstd, gamma, beta, p.act);
+            v = bn_apply(io::ld(&src[((size_t)y * p.w + x) * p.c]), mean, invstd, gamma, beta, ACT);
         }
         io::st((T*)p.out + view_frame(n, p.t, p.b) * p.out_fs + ((size_t)y * ow + x) * p.out_ps + 4 * c4, v);
     }
@@ -216,13 +218,13 @@ __device__ __forceinline__ Routed bn_route(const float y4[4], int nwin, float me
 }
 
 // pass A: per-channel partial sums of dz and dz*xhat (dz itself is never stored; pass B re-derives it)
-template <typename T>
+template <typename T, int POOL, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
     typedef vad_io4<T> io;
     const T* py = (const T*)p.y;
     const T* pdout = (const T*)p.dout;
     const int tid = threadIdx.x, cg = p.c >> 2, rows = 256 / cg, row = tid / cg, c4 = tid - row * cg;
-    const int oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w, nwin = p.pool ? 4 : 1;
+    const int oh = POOL ? p.h / 2 : p.h, ow = POOL ? p.w / 2 : p.w; constexpr int nwin = POOL ? 4 : 1;
     const long long p0 = (long long)blockIdx.x * p.chunk, p1 = (p0 + p.chunk < p.opix) ? p0 + p.chunk : p.opix;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (row < rows) {
@@ -232,15 +234,15 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
             const unsigned uq = (unsigned)q, t_ = uq / (unsigned)ow, un = t_ / (unsigned)oh;       // (opix < 2^31: host-checked)
             const int x = (int)(uq - t_ * (unsigned)ow), y = (int)(t_ - un * (unsigned)oh), n = (int)un;
             g = io::ld(&pdout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4]);
-            const size_t o0 = (size_t)n * p.h * p.w * p.c + 4 * c4 + (p.pool ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
+            const size_t o0 = (size_t)n * p.h * p.w * p.c + 4 * c4 + (POOL ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
             yv[0] = io::ld(&py[o0]);
-            if (p.pool) { yv[1] = io::ld(&py[o0 + p.c]); yv[2] = io::ld(&py[o0 + (size_t)p.w * p.c]); yv[3] = io::ld(&py[o0 + (size_t)p.w * p.c + p.c]); }
+            if constexpr (POOL) { yv[1] = io::ld(&py[o0 + p.c]); yv[2] = io::ld(&py[o0 + (size_t)p.w * p.c]); yv[3] = io::ld(&py[o0 + (size_t)p.w * p.c + p.c]); }
         };
         auto add = [&](long long q, const f32x4& g, const f32x4 (&yv)[4]) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
-                const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[e], p.act);
+                const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[e], ACT);
                 if (p.dec) p.dec[q * p.c + 4 * c4 + e] = (unsigned char)(r.am | (r.v > 0.f ? 4 : 0));
                 s0[e] += r.gz;
                 s1[e] += r.gz * r.xh;
@@ -259,13 +261,13 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
 
 // pass B: dy = gamma * invstd * (dz - k1 - xhat * k2) for every element of the window (dz = 0 off the routed element);
 // s2d writes the space-to-depth view [n][h/2][w/2][4][c] (the operand layout of the transposed convolution's gradients)
-template <typename T>
+template <typename T, int POOL, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
     typedef vad_io4<T> io;
     const T* py = (const T*)p.y;
     const T* pdout = (const T*)p.dout;
     T* pdy = (T*)p.dy;
-    const int cg = p.c >> 2, oh = p.pool ? p.h / 2 : p.h, ow = p.pool ? p.w / 2 : p.w, nwin = p.pool ? 4 : 1;
+    const int cg = p.c >> 2, oh = POOL ? p.h / 2 : p.h, ow = POOL ? p.w / 2 : p.w; constexpr int nwin = POOL ? 4 : 1;
     const unsigned total = (unsigned)(p.opix * cg), ucg = (unsigned)cg;               // (< 2^31: host-checked)
     for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const unsigned q = idx / ucg, t_ = q / (unsigned)ow, un = t_ / (unsigned)oh;
@@ -276,15 +278,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
         const f32x4 k1 = *(const f32x4*)&p.k[4 * c4], k2 = *(const f32x4*)&p.k[p.c + 4 * c4];
         const f32x4 g = io::ld(&pdout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 4 * c4]);
         const size_t fb = (size_t)n * p.h * p.w * p.c + 4 * c4;
-        const size_t o0 = fb + (p.pool ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
+        const size_t o0 = fb + (POOL ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
         const size_t off[4] = {o0, o0 + p.c, o0 + (size_t)p.w * p.c, o0 + (size_t)p.w * p.c + p.c};
         f32x4 yv[4], out[4];
         yv[0] = io::ld(&py[off[0]]);
-        if (p.pool) { yv[1] = io::ld(&py[off[1]]); yv[2] = io::ld(&py[off[2]]); yv[3] = io::ld(&py[off[3]]); }
+        if constexpr (POOL) { yv[1] = io::ld(&py[off[1]]); yv[2] = io::ld(&py[off[2]]); yv[3] = io::ld(&py[off[3]]); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
-            const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[e], p.act);
+            const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[e], ACT);
             const float sc = gamma[e] * invstd[e];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -1271,8 +1273,26 @@ int vad_bn_act_pool_fwd_t(const void* y, int io16, const float* stats, const flo
              remap_t, remap_b, n, h, w, c, act, pool, (long long)n * oh * ow * (c / 4)};
     VAD_REQUIRE(p.out_ps % 4 == 0 && p.out_fs % 4 == 0, "bn_act_pool_fwd: strides must be multiples of 4 elements");
     VAD_REQUIRE(p.total < (1ll << 31), "bn_act_pool_fwd: %lld items are too many for the kernel's 32-bit index arithmetic", p.total);
-    if (io16) hipLaunchKernelGGL(bn_act_pool_fwd_kernel<vad_bf16>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(bn_act_pool_fwd_kernel<float>, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+#define BN_DISPATCH(KERNEL, GRID, STREAM)                                                                                   \
+    {                                                                                                                      \
+        const int v_ = (pool ? 3 : 0) + act;                                                                               \
+        if (io16) switch (v_) {                                                                                            \
+            case 0: hipLaunchKernelGGL((KERNEL<vad_bf16, 0, 0>), GRID, dim3(256), 0, STREAM, p); break;                    \
+            case 1: hipLaunchKernelGGL((KERNEL<vad_bf16, 0, 1>), GRID, dim3(256), 0, STREAM, p); break;                    \
+            case 2: hipLaunchKernelGGL((KERNEL<vad_bf16, 0, 2>), GRID, dim3(256), 0, STREAM, p); break;                    \
+            case 3: hipLaunchKernelGGL((KERNEL<vad_bf16, 1, 0>), GRID, dim3(256), 0, STREAM, p); break;                    \
+            case 4: hipLaunchKernelGGL((KERNEL<vad_bf16, 1, 1>), GRID, dim3(256), 0, STREAM, p); break;                    \
+            default: hipLaunchKernelGGL((KERNEL<vad_bf16, 1, 2>), GRID, dim3(256), 0, STREAM, p); break;                   \
+        } else switch (v_) {                                                                                               \
+            case 0: hipLaunchKernelGGL((KERNEL<float, 0, 0>), GRID, dim3(256), 0, STREAM, p); break;                       \
+            case 1: hipLaunchKernelGGL((KERNEL<float, 0, 1>), GRID, dim3(256), 0, STREAM, p); break;                       \
+            case 2: hipLaunchKernelGGL((KERNEL<float, 0, 2>), GRID, dim3(256), 0, STREAM, p); break;                       \
+            case 3: hipLaunchKernelGGL((KERNEL<float, 1, 0>), GRID, dim3(256), 0, STREAM, p); break;                       \
+            case 4: hipLaunchKernelGGL((KERNEL<float, 1, 1>), GRID, dim3(256), 0, STREAM, p); break;                       \
+            default: hipLaunchKernelGGL((KERNEL<float, 1, 2>), GRID, dim3(256), 0, STREAM, p); break;                      \
+        }                                                                                                                  \
+    }
+    BN_DISPATCH(bn_act_pool_fwd_kernel, dim3(grid_for(p.total)), (hipStream_t)stream)
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -1323,15 +1343,14 @@ int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const flo
     VAD_REQUIRE(p.dout_ps % 4 == 0 && p.dout_fs % 4 == 0, "bn_act_pool_bwd: strides must be multiples of 4 floats");
     const int nb = (int)((p.opix + p.chunk - 1) / p.chunk);
     hipStream_t s = (hipStream_t)stream;
-    if (io16) hipLaunchKernelGGL(bn_bwd_sums_kernel<vad_bf16>, dim3(nb), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3(nb), dim3(256), 0, s, p);
+    BN_DISPATCH(bn_bwd_sums_kernel, dim3(nb), s)
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_finalize_kernel, dim3(c), dim3(256), 0, s, (const float*)ws, nb, c,
                        (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     p.dec = nullptr;
-    if (io16) hipLaunchKernelGGL(bn_bwd_apply_kernel<vad_bf16>, dim3(grid_for(p.opix * (c / 4))), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(p.opix * (c / 4))), dim3(256), 0, s, p);
+    BN_DISPATCH(bn_bwd_apply_kernel, dim3(grid_for(p.opix * (c / 4))), s)
+#undef BN_DISPATCH
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
