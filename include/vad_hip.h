@@ -311,8 +311,9 @@ size_t vad_vid_train_workspace_bytes(int b, int t, int h, int w, int latent, int
  * per output pixel and channel, consecutively into buf; (NULL, 0) stops.  See csrc/train_ops.hip. */
 int vad_debug_set_train_decisions(void* buf, size_t bytes);
 size_t vad_debug_train_decisions_used(void);
-/* A/B: 0 = the weight gradients of the bf16-tensor mode use the one-channel-per-lane kernel everywhere; 1 (default) = the
- * paired-channel kernel (dword loads, 64 x 64 tiles) where cin and ncols are multiples of 64. */
+/* A/B: 0 = the weight gradients of the bf16-tensor mode use the one-channel-per-lane kernel everywhere; 1 = the paired-channel
+ * kernel (dword loads, 64 x 64 wave tiles) where cin and ncols are multiples of 64; 2 (default) = its LDS-staged work-group
+ * form where ncols is a multiple of 128. */
 int vad_debug_set_wgrad_pairs(int on);
 int vad_debug_set_train_stop(int stage);   /* debug: stop vad_vid_train_fwd_bwd after a backward stage (see csrc/train_step.hip) */
 int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent, int hid, int layers, long long* out, int cap);

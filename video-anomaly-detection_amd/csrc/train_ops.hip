@@ -750,6 +750,147 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x2_kernel(WgradP p) {
     }
 }
 
+// The same paired-channel arithmetic with the operands staged ONCE per work-group through LDS (round 3).  A wave of the kernel
+// above re-reads its 64 + 64 channels of every pixel from L2: 4 KB per 12 MFMAs, ~96 B/clk per CU at the matrix pipe's rate -
+// more than L2 delivers, so it sits at ~0.2 of the bf16 peak waiting (SQ_WAIT_ANY 40 %).  Here WM x WN waves share a
+// (64 WM) x (64 WN) tile: per group of 32 pixels the work-group fetches its A rows (34 pixels with the 3x3 halo) and G rows
+// with 16-byte loads (2-5 per thread instead of 36 dword gathers per lane), writes them to LDS in NHWC order (pixel pitch
+// padded by 16 bytes) and every wave reads its dword pairs from there; the next group's loads are in flight during the
+// MFMAs, one barrier per group (two LDS buffers).  Same products, same per-wave accumulation order over (row, group) as the
+// kernel above.
+// GP = pixels per group: 32, or 16 for maps 16 pixels wide (the ConvLSTM layers: half of a 32-pixel group would be padding).
+// PS = 2 (GP 32): two waves share every 64 x 64 tile and take one 16-pixel half of each group each - a second split-K factor
+// inside the work-group (partial slot 2 split + half), so that a 64-channel tile still has four waves per staged group.
+template <int TAPS, int WM, int WN, int GP, int PS = 1>
+__global__ __launch_bounds__(64 * WM * WN * PS, 2) void conv_wgrad_bf16_lds_kernel(WgradP p) {
+    static_assert(PS == 1 || GP == 32, "pixel halves need two 16-pixel sub-groups");
+    constexpr int ND = TAPS == 9 ? 3 : 1, HALO = TAPS == 9 ? 1 : 0, NE = 8 + 2 * HALO, NPASS = TAPS == 9 ? 3 : 1;
+    constexpr int NTH = 64 * WM * WN * PS;                           // threads
+    constexpr int CA = 64 * WM, CG = 64 * WN;                        // channels / columns of the work-group tile
+    constexpr int PA = CA * 2 + 16, PG = CG * 2 + 16;                // LDS pixel pitch in bytes
+    constexpr int NPA = GP + 2 * HALO;                               // A pixels per group
+    constexpr int QA = NPA * (CA / 8), QG = GP * (CG / 8);           // 16-byte chunks per group
+    constexpr int JA = (QA + NTH - 1) / NTH, JG = (QG + NTH - 1) / NTH;
+    constexpr int BUF = NPA * PA + GP * PG;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kb = lane >> 5;
+    const int ph = wave / (WM * WN), wt = wave % (WM * WN), wm = wt / WN, wn = wt % WN;
+    unsigned item = vad_xcd_remap(blockIdx.x, gridDim.x);             // see WGRAD_XCD
+    const int ct = item % p.ci_tiles; item /= p.ci_tiles;
+    const int cgp = item % p.col_groups; item /= p.col_groups;
+    const int pass = item % NPASS;
+    const int split = item / NPASS;
+    const int H = p.h, W = p.w, total_rows = p.n * H;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const int dy = TAPS == 9 ? pass - 1 : 0;
+    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * 2u, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * 2u;
+    const unsigned pix_a = (unsigned)p.cin * 2u, pix_g = (unsigned)p.ncols * 2u;
+    f32x16 acc[ND][2][2];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][q >> 1][q & 1][r] = 0.f;
+
+    // (row, group) positions of this slice whose kernel row lies inside the image, in order
+    auto row_ok = [&](int row) { const int ly = row % H + dy; return ly >= 0 && ly < H; };
+    int row = r0, lx = 0;
+    while (row < r1 && !row_ok(row)) ++row;
+    // staging registers of the group being fetched
+    u32x4 sa[JA], sg[JG];
+    auto fetch = [&](int frow, int flx) {
+        const int n_ = frow / H, ly = frow - n_ * H;
+        const __amdgpu_buffer_rsrc_t ra = vad_rsrc((const char*)p.a + (size_t)n_ * H * W * p.cin * 2u, a_bytes);
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const char*)p.g + (size_t)n_ * H * W * p.ncols * 2u, g_bytes);
+        const unsigned abase = (unsigned)((ly + dy) * W) * pix_a + (unsigned)(ct * CA) * 2u;
+        const unsigned gbase = (unsigned)(ly * W) * pix_g + (unsigned)(cgp * CG) * 2u;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int q = tid + NTH * j, px = q / (CA / 8), c16 = q % (CA / 8), x = flx + px - HALO;
+            const bool ok = q < QA && (unsigned)x < (unsigned)W;
+            sa[j] = __builtin_bit_cast(u32x4, vad_bload4(ra, ok ? (unsigned)x * pix_a + (unsigned)c16 * 16u : VAD_OOB, abase));
+        }
+#pragma unroll
+        for (int j = 0; j < JG; ++j) {
+            const int q = tid + NTH * j, px = q / (CG / 8), c16 = q % (CG / 8), x = flx + px;
+            const bool ok = q < QG && x < W;
+            sg[j] = __builtin_bit_cast(u32x4, vad_bload4(rg, ok ? (unsigned)x * pix_g + (unsigned)c16 * 16u : VAD_OOB, gbase));
+        }
+    };
+    auto stash = [&](int b) {
+        unsigned char* A = lds + b * BUF;
+        unsigned char* G = A + NPA * PA;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int q = tid + NTH * j, px = q / (CA / 8), c16 = q % (CA / 8);
+            if (q < QA) *(u32x4*)(A + px * PA + c16 * 16) = sa[j];
+        }
+#pragma unroll
+        for (int j = 0; j < JG; ++j) {
+            const int q = tid + NTH * j, px = q / (CG / 8), c16 = q % (CG / 8);
+            if (q < QG) *(u32x4*)(G + px * PG + c16 * 16) = sg[j];
+        }
+    };
+    auto lo2 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); };
+    auto hi2 = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); };
+    auto compute = [&](int b) {
+        const unsigned char* A = lds + b * BUF + (wm * 64 + 2 * li) * 2;
+        const unsigned char* G = lds + b * BUF + NPA * PA + (wn * 64 + 2 * li) * 2;
+#pragma unroll
+        for (int sub0 = 0; sub0 < GP / 16 / PS; ++sub0) {
+            const int sub = PS == 2 ? ph : sub0;
+            const int px0 = 16 * sub + 8 * kb;
+            unsigned gd[8], ad[NE];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gd[e] = *(const unsigned*)(G + (px0 + e) * PG);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) ad[e] = *(const unsigned*)(A + (px0 + e) * PA);
+            wg_bf16x8 gb[2];
+            gb[0] = wg_frag(lo2(gd[0], gd[1]), lo2(gd[2], gd[3]), lo2(gd[4], gd[5]), lo2(gd[6], gd[7]));
+            gb[1] = wg_frag(hi2(gd[0], gd[1]), hi2(gd[2], gd[3]), hi2(gd[4], gd[5]), hi2(gd[6], gd[7]));
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const wg_bf16x8 fe = wg_frag(lo2(ad[d], ad[d + 1]), lo2(ad[d + 2], ad[d + 3]), lo2(ad[d + 4], ad[d + 5]), lo2(ad[d + 6], ad[d + 7]));
+                const wg_bf16x8 fo = wg_frag(hi2(ad[d], ad[d + 1]), hi2(ad[d + 2], ad[d + 3]), hi2(ad[d + 4], ad[d + 5]), hi2(ad[d + 6], ad[d + 7]));
+                acc[d][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fe, gb[0], acc[d][0][0], 0, 0, 0);
+                acc[d][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fe, gb[1], acc[d][0][1], 0, 0, 0);
+                acc[d][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo, gb[0], acc[d][1][0], 0, 0, 0);
+                acc[d][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo, gb[1], acc[d][1][1], 0, 0, 0);
+            }
+        }
+    };
+    if (row < r1) {                                   // (uniform over the work-group: every barrier below is reached by all waves)
+        fetch(row, lx);
+        stash(0);
+        __syncthreads();
+        int b = 0;
+        while (true) {
+            int nrow = row, nlx = lx + GP;
+            if (nlx >= W) { nlx = 0; ++nrow; while (nrow < r1 && !row_ok(nrow)) ++nrow; }
+            const bool more = nrow < r1;
+            if (more) fetch(nrow, nlx);               // in flight during this group's MFMAs
+            compute(b);
+            if (!more) break;
+            stash(b ^ 1);                             // the other buffer: nobody reads it (its readers passed the last barrier)
+            __syncthreads();
+            b ^= 1; row = nrow; lx = nlx;
+        }
+    }
+    const int ct64 = ct * WM + wm, cg64 = cgp * WN + wn;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int tap = (TAPS == 9 ? 3 * pass : 0) + d;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ct64 * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kb) + pa;
+                *(f32x2*)&p.ws[(((size_t)(split * PS + ph) * TAPS + tap) * p.cin + ci) * p.ncols + cg64 * 64 + 2 * li] = f32x2{acc[d][pa][0][r], acc[d][pa][1][r]};
+            }
+    }
+}
+
 // First layer (input NCHW, 3 channels): M index k = c*9 + tap (27, padded to 32), A gathered from the input planes.
 struct WgradC3P {     // g: fp32 or bf16 (the kernels' storage type)
     const float* x; const void* g; float* ws;
@@ -1390,9 +1531,9 @@ int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const
     return VAD_OK;
 }
 
-// debug / A-B: 0 = the bf16-tensor mode uses the one-channel-per-lane kernel everywhere (default 1: paired-channel kernel where
-// cin and ncols are multiples of 64)
-static std::atomic<int> g_wgrad_x2{1};
+// debug / A-B: 0 = the bf16-tensor mode uses the one-channel-per-lane kernel everywhere, 1 = paired-channel kernel (dword loads
+// per wave) where cin and ncols are multiples of 64, 2 (default) = its LDS-staged work-group form where ncols is a multiple of 128
+static std::atomic<int> g_wgrad_x2{2};
 extern "C" int vad_debug_set_wgrad_pairs(int on) { g_wgrad_x2 = on; return VAD_OK; }
 
 // split-K factor: enough waves to fill the chip (~4096), never more splits than image rows.  Measured on both training
@@ -1414,6 +1555,14 @@ extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int 
     if (cin % 64 == 0 && ncols % 64 == 0) {      // the paired-channel kernel of the bf16-tensor mode: 64 x 64 tiles, one item per kernel row
         const int s2 = wgrad_splits((long long)(cin / 64) * (ncols / 64) * (taps == 9 ? 3 : 1), n * h);
         if (s2 > splits) splits = s2;
+        if (ncols % 128 == 0) {                  // its LDS-staged form: work-group tiles, 2 or 4 waves each
+            const int wm = cin % 128 == 0 ? 2 : 1, ps = (taps == 9 && wm == 1) ? 2 : 1;
+            const long long tiles3 = (long long)(cin / (64 * wm)) * (ncols / 128) * (taps == 9 ? 3 : 1);
+            long long s3 = (4096 / (2 * wm * ps) + tiles3 - 1) / tiles3;
+            if (s3 > (long long)n * h) s3 = (long long)n * h;
+            if (s3 > 2048) s3 = 2048;
+            if (s3 * ps > splits) splits = (int)(s3 * ps);
+        }
     }
     return (size_t)splits * taps * cin * ncols;
 }
@@ -1429,6 +1578,41 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     VAD_REQUIRE((long long)h * w * cin * 4 < (1ll << 31) && (long long)h * w * ncols * 4 < (1ll << 31), "conv_wgrad: frame too large for 32-bit offsets");
     WgradP p{};
     p.a = a; p.g = g; p.ws = ws; p.n = n; p.h = h; p.w = w; p.cin = cin; p.ncols = ncols;
+    // LDS-staged work-group tiles: 3x3 layers with 128-channel tiles (the 64-channel form has half the waves per tile and its
+    // 192 accumulators + staging registers spill: 0.85 ms against 0.38 ms of the per-wave kernel on enc.8), 1x1 / transposed
+    // layers with 64- or 128-channel tiles
+    const bool lds_ok = ncols % 128 == 0 && (taps == 9 ? (cin % 128 == 0 || (cin % 64 == 0 && w > 16)) : cin % 64 == 0);
+    if (precision == VAD_PREC_BF16S && lds_ok && g_wgrad_x2.load(std::memory_order_relaxed) >= 2) {
+        const int npass = taps == 9 ? 3 : 1, wm = cin % 128 == 0 ? 2 : 1;
+        const int ps = (taps == 9 && wm == 1) ? 2 : 1;               // 3x3 with 64-channel tiles: pixel halves (see the kernel)
+        p.ci_tiles = cin / (64 * wm); p.col_groups = ncols / 128;
+        const long long tiles3 = (long long)p.ci_tiles * p.col_groups * npass;
+        // (items are work-groups of 2 wm ps waves: aim at the same ~4096 waves)
+        long long sp = (4096 / (2 * wm * ps) + tiles3 - 1) / tiles3;
+        if (sp > n * h) sp = n * h;
+        if (sp > 2048) sp = 2048;
+        if (sp < 1) sp = 1;
+        p.splits = (int)sp;
+        p.rows_per_split = (n * h + p.splits - 1) / p.splits;
+        p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;
+        const long long items3 = tiles3 * p.splits;
+        VAD_REQUIRE(items3 < (1ll << 31), "conv_wgrad: too many work items");
+        p.nitems = (unsigned)items3;
+        hipStream_t s3 = (hipStream_t)stream;
+        const dim3 g3((unsigned)items3);
+        const bool narrow = w <= 16;
+#define WGL(T_, WM_, GP_) hipLaunchKernelGGL((conv_wgrad_bf16_lds_kernel<T_, WM_, 2, GP_>), g3, dim3(128 * WM_), 0, s3, p)
+        if (taps == 9 && wm == 1) hipLaunchKernelGGL((conv_wgrad_bf16_lds_kernel<9, 1, 2, 32, 2>), g3, dim3(256), 0, s3, p);
+        else if (taps == 9) { if (narrow) WGL(9, 2, 16); else WGL(9, 2, 32); }
+        else if (wm == 2) { if (narrow) WGL(1, 2, 16); else WGL(1, 2, 32); }
+        else { if (narrow) WGL(1, 1, 16); else WGL(1, 1, 32); }
+#undef WGL
+        VAD_LAUNCH_CHECK();
+        const long long total3 = (long long)taps * cin * ncols;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total3 + 63) / 64)), dim3(256), 0, s3, (const float*)ws, p.splits * ps, taps, cin, ncols, layout, dw);
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
     if (precision == VAD_PREC_BF16S && cin % 64 == 0 && ncols % 64 == 0 && g_wgrad_x2.load(std::memory_order_relaxed)) {
         const int npass = taps == 9 ? 3 : 1;
         p.ci_tiles = cin / 64; p.col_groups = ncols / 64;
