@@ -216,10 +216,26 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 
     typedef typename std::conditional<FUSE_C3 != 0, float, typename std::conditional<IO16 != 0, u32x2, f32x4>::type>::type pf_t;
     pf_t pf[NPF];    // next stage's input, in flight
+    // bf16 tensors (IO16): a chunk's 18 k-steps are ~1 us of matrix work, less than a trip to HBM - one chunk of prefetch left
+    // ~2 us exposed per chunk (the ConvLSTM data gradient: 16 chunks, 55 us per launch for 15 us of MFMAs).  A second register
+    // set puts the fetch TWO chunks ahead: chunk c+2 is requested when chunk c has been written to LDS.  (Chunk counts are
+    // 1 or even; with one chunk per frame the single-set pipeline below is used.)
+    pf_t pf2[IO16 ? NPF : 1];
     float cpv[MODE == MODE_LSTM ? MT : 1][16];   // ConvLSTM: previous cell state of this lane's outputs, in flight during the last chunk
 
     // both sources of a two-source (ConvLSTM) launch have the same channel count (host-checked), so svo serves both
     const unsigned in_bytes = FUSE_C3 ? (unsigned)(3 * H * W) * (p.xu8 ? 1u : 4u) : (unsigned)(H * W) * (unsigned)p.cin_a * ES;
+#define ISSUE_TO(PF_, n_, ch_)   /* plain NHWC source (not the fused first layer) into the staging set PF_ */      \
+    {                                                                                                    \
+        const char* src_ = ((ch_) < nch_a) ? (const char*)p.in + ((size_t)(n_) * p.in_fs + (ch_) * CK) * ES            \
+                                           : (const char*)p.in2 + ((size_t)(n_) * p.in2_fs + ((ch_) - nch_a) * CK) * ES; \
+        const unsigned skip_ = (unsigned)(((ch_) < nch_a) ? (ch_) : (ch_) - nch_a) * CK * ES;            \
+        const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(src_, in_bytes - skip_);                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) {                                             \
+            if constexpr (IO16) pf_set(PF_[i_], __builtin_bit_cast(u32x2, vad_bload2(r_, svo[i_], 0)));  \
+            else pf_set(PF_[i_], vad_bload4(r_, svo[i_], 0));                                            \
+        }                                                                                                \
+    }
 #define ISSUE(n_, ch_)                                                                                   \
     {                                                                                                    \
         if constexpr (FUSE_C3) {                                                                         \
@@ -265,6 +281,10 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
     int n = fg;
     if (n >= p.n) return;                                          // (grid never exceeds the work; defensive)
     ISSUE(n, 0);
+    const bool deep = IO16 && nch >= 2 && (nch & 1) == 0;          // (uniform) two-deep staging, see pf2
+    if constexpr (IO16) {
+        if (deep) { ISSUE_TO(pf2, n, 1); }
+    }
     if constexpr (FUSE_C3) {
         // first frame's halo (published by the barrier at the top of the frame loop), then the second frame's prefetch: from
         // here on pf always holds the frame AFTER the one being computed
@@ -387,7 +407,49 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
         const int nn = n + fgroups;
         const bool has_next = nn < p.n;
 
-        for (int ch = 0; ch < nch; ++ch) {
+        if constexpr (IO16) {
+            if (deep) {
+                // one chunk: publish the staged set, request the chunk two ahead into the same set, run the 18 k-steps
+                auto run_chunk = [&](int ch, pf_t (&cur)[NPF], bool more, int n2, int ch2) {
+                    __syncthreads();                   // every wave is done reading the previous stage
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i)
+                        if ((tid >> 3) + 32 * i < NPIX)
+                            *(u32x2*)&tile[(tid >> 3) * PS + i * 32 * PS + (c4 >> 1) * 8 + (c4 & 1) * 2] = pf_get_u(cur[i]);
+                    __syncthreads();
+                    if (more) { ISSUE_TO(cur, n2, ch2); }
+                    LOAD_A_HALF(0, 0, MT);
+                    constexpr int MH = (MT + 1) / 2;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const int bcur = s % NB, bnxt = (s + PB) % NB;
+                        if (s + PB < NS) { LOAD_B(bnxt, ch, s + PB); }
+                        else if (ch + 1 < nch) { LOAD_B(bnxt, ch + 1, s + PB - NS); }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                vad_mma16<PREC>(acc[mt][nt], corr[0][0], ah[0][mt], al[0][mt], bh[bcur][nt], bl[bcur][nt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s + 1 < NS) LOAD_A_HALF(s + 1, 0, MH);
+#pragma unroll
+                        for (int mt = MH; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                vad_mma16<PREC>(acc[mt][nt], corr[0][0], ah[0][mt], al[0][mt], bh[bcur][nt], bl[bcur][nt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s + 1 < NS) LOAD_A_HALF(s + 1, MH, MT);
+                    }
+                };
+                for (int ch = 0; ch < nch; ch += 2) {      // the flat (frame, chunk) sequence, two sets alternating
+                    const bool in2 = ch + 2 < nch, in3 = ch + 3 < nch;
+                    run_chunk(ch, pf, in2 || has_next, in2 ? n : nn, in2 ? ch + 2 : 0);
+                    run_chunk(ch + 1, pf2, in3 || has_next, in3 ? n : nn, in3 ? ch + 3 : 1);
+                }
+            }
+        }
+        for (int ch = (IO16 && deep) ? nch : 0; ch < nch; ++ch) {
             STAMP(0);
             __syncthreads();                       // every wave is done reading the previous stage
             STAMP(1);
@@ -712,6 +774,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #undef LOAD_A_HALF
 #undef LOAD_B
 #undef ISSUE
+#undef ISSUE_TO
 #undef XWRITE
     if constexpr (STATS) {
         if (p.stats) {           // (uniform)  partial sums of this work-group: lane halves, then the WM waves of a column block

@@ -1597,6 +1597,8 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
         p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;
         const long long items3 = tiles3 * p.splits;
         VAD_REQUIRE(items3 < (1ll << 31), "conv_wgrad: too many work items");
+        VAD_REQUIRE((size_t)p.splits * ps * taps * cin * ncols <= vad_conv_wgrad_ws_floats(n, h, taps, cin, ncols),
+                    "conv_wgrad: internal error: %d x %d partial slots exceed the size vad_conv_wgrad_ws_floats reports", p.splits, ps);
         p.nitems = (unsigned)items3;
         hipStream_t s3 = (hipStream_t)stream;
         const dim3 g3((unsigned)items3);
@@ -1622,6 +1624,8 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
         p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;
         const long long items2 = tiles2 * p.splits;
         VAD_REQUIRE(items2 < (1ll << 31), "conv_wgrad: too many work items");
+        VAD_REQUIRE((size_t)p.splits * taps * cin * ncols <= vad_conv_wgrad_ws_floats(n, h, taps, cin, ncols),
+                    "conv_wgrad: internal error: %d partial slots exceed the size vad_conv_wgrad_ws_floats reports", p.splits);
         p.nitems = (unsigned)items2;
         hipStream_t s2 = (hipStream_t)stream;
         if (taps == 9) hipLaunchKernelGGL(conv_wgrad_bf16x2_kernel<9>, dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, s2, p);
@@ -1640,6 +1644,8 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;     // no empty splits
     const long long items = tiles * p.splits;
     VAD_REQUIRE(items < (1ll << 31), "conv_wgrad: too many work items");
+    VAD_REQUIRE((size_t)p.splits * taps * cin * ncols <= vad_conv_wgrad_ws_floats(n, h, taps, cin, ncols),
+                "conv_wgrad: internal error: %d partial slots exceed the size vad_conv_wgrad_ws_floats reports", p.splits);
     p.nitems = (unsigned)items;
     const dim3 grid((unsigned)((items + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
