@@ -154,8 +154,8 @@ class VideoAutoencoder(nn.Module):
     def _packed(self, device) -> torch.Tensor:
         l = hip.lib()
         mode = hip.precision_mode(self.precision)
-        if mode == hip.PREC_BF16:
-            raise hip.VadError("precision 'bf16' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32' or 'split'")
+        if mode in (hip.PREC_BF16, hip.PREC_BF16S):
+            raise hip.VadError("precision 'bf16' / 'bf16_operands' / 'bf16_tensors' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32' or 'split'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
