@@ -78,6 +78,13 @@ def run(kind, n, h, w, cin, cout, pool, iters, warm=3, prec=0):
                                               None, None, n, h, w, 32, 0, 0, s)
         flop = 2.0 * n * h * w * 4 * 32 * 3
         byts = 4.0 * (x.numel() + img.numel())
+    elif kind == "dec4":                    # fused dec4.0 + dec4.3 + score; h, w = INPUT map size (random, unpacked weights: timing only)
+        x = rnd(n, h, w, 32); wt = rnd(4096) * 0.05; bt = rnd(32); w2 = rnd(1024) * 0.05; b3 = rnd(4); img = rnd(n, 3, 2 * h, 2 * w)
+        parts = torch.empty(n * l.vad_dec4_score_partials(2 * h, 2 * w), device="cuda")
+        fn = lambda: l.vad_dec4_score(x.data_ptr(), wt.data_ptr(), bt.data_ptr(), w2.data_ptr(), b3.data_ptr(), img.data_ptr(),
+                                      parts.data_ptr(), None, None, n, h, w, s)
+        flop = 2.0 * n * h * w * (4 * 32 * 32 + 4 * 32 * 32)
+        byts = 4.0 * (x.numel() + img.numel())
     else:
         raise SystemExit(f"unknown kind {kind}")
     for _ in range(warm):

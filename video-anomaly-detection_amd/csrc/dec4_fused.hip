@@ -9,15 +9,25 @@
 //     order per output is the one convt2x2_pkernel uses (channel pairs (j, 4+j) of each 8-group, j = 0..3): the activation
 //     is bit-identical to the unfused dec4.0.
 //   GEMM 2 (the 3x3 convolution as a per-pixel product): P[pixel][(tap, co)] = sum_ci act[pixel][ci] W[co][ci][tap],
-//     M = 27 (tap, co) rows padded to 32, K = 32 channels, N = pixels.  In that orientation the B operand of step r is
+//     M = 27 (tap, co) rows in 32 slots, K = 32 channels, N = pixels.  In that orientation the B operand of step r is
 //     lane = pixel, k = (channel c_r, c_r + 4) - exactly register r of GEMM 1's result in its two lane halves: bias and ReLU
 //     are applied in place and the 16 registers are fed straight back into the matrix pipe.  No LDS transpose.
 //   The 3x3 neighbourhood is then 27 additions per output pixel: out[y][x][co] = sum_{dy,dx} P[y+dy-1][x+dx-1][(dy,dx),co].
 //     A work-group owns a band of rows over the whole width (no x halo to recompute; the y halo is one input row per band
-//     end) and walks it one OUTPUT row at a time: the four waves put that row of P (27 x 256 floats) into LDS, and after one
-//     barrier thread x adds its nine row sums s[dy][co] = sum_dx P[(dy,dx,co)][x+dx-1] into three running output rows held
-//     in registers: row y is complete when P rows y-1, y, y+1 have passed.  Tanh, error, optional recon / error-map stores
-//     and the per-row partial sum follow in the same thread.  P rows are double-buffered: one barrier per output row.
+//     end) and walks it one OUTPUT row at a time ("phase"): the four waves put that row of P into LDS, one 36-float record
+//     per column (slot order below: a lane's four accumulator registers are one 16-byte store, a reader's nine values per
+//     neighbour column two 16-byte loads and one 4-byte load), and after one barrier thread x adds its nine row sums
+//     s[dy][co] = sum_dx P[(dy,dx,co)][x+dx-1] into three running output rows held in registers: row y is complete when P
+//     rows y-1, y, y+1 have passed.  Tanh, error, optional recon / error-map stores and the per-row partial sum follow.
+//
+// SOFTWARE PIPELINE.  The combine of phase t-1 (LDS reads, 27 adds, tanh, error, row sum: ~250 VALU / LDS instructions) is
+// issued in the SAME instruction stream as the 64 MFMAs of phase t, one basic block, so that it runs in their shadow.
+// Leaving it to the second work-group of the CU does not work: a wave whose next instruction is an MFMA waiting for the
+// matrix pipe holds the SIMD's VALU issue, and the other wave's plain VALU instructions starve until the MFMA stream ends
+// (tools/ubench/mfma_valu_mix.hip: 12 k fmac next to 4 k back-to-back MFMAs finish 12 k x 5.3 clocks AFTER the MFMAs).
+// Everything in the block is branch-free: invalid rows / columns get a zero bias instead of a skipped GEMM (their P is
+// then exactly 0, the convolution's zero padding), loads use out-of-range offsets or clamped addresses, and only the final
+// stores sit under (uniform) conditions.  The pipeline runs across work items: one fill and one drain per work-group.
 //
 // Per 256x256 frame: 2 x 0.134 GFLOP on the fp32 matrix pipe (GEMM 2 pads 27 -> 32 rows; the unfused tail ran 0.113 GFLOP on
 // the VALU, the same pipe) and 2.1 MB + 0.79 MB read from HBM: bound by the exact-fp32 matrix pipe at ~1.8 us per frame.
@@ -28,15 +38,20 @@
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 namespace {
-constexpr int D4_PITCH = 260;                 // P row in LDS: column jl = 2 + j, j = output column - 2 * xs0 in [-1, 256]
-constexpr int D4_ROWS = 27;                   // (tap, co) rows, m = tap * 3 + co
-constexpr int D4_BUF = D4_ROWS * D4_PITCH;    // floats per P buffer
+// One P record per LDS column jl = 2 + j (j = output column - 2 * xs0 in [-2, 257]): 32 GEMM-2 rows + 4 floats of padding
+// (36-float pitch: 16-byte accesses of 8 consecutive lanes, at a stride of one or two columns, touch 32 distinct banks).
+// Slot of (dy, dx, co), idx = 3 dy + co: dx 0 -> idx, dx 1 -> 12 + idx, dx 2 -> 24 + idx (idx < 8) / slot 9 (idx 8);
+// slots 10, 11, 21..23 carry zero weights.
+constexpr int D4_CPITCH = 36;
+constexpr int D4_COLS = 260;
+constexpr int D4_BUF = D4_COLS * D4_CPITCH;   // floats per P buffer (37,440 B; two buffers: dynamic LDS)
+constexpr int D4_LDS_BYTES = 2 * D4_BUF * 4;
 
 struct Dec4P {
     const float* in;       // [n][H][W][32] NHWC: dec3.3 output
     const float* wt;       // transposed-conv weights, fp32 pack [q][cin/8][cout][8] (BatchNorm folded)
     const float* bt;       // [32] folded bias
-    const float* w2;       // GEMM form of the 3x3 weights: [m 32][lane half 2][r 16]
+    const float* w2;       // GEMM form of the 3x3 weights: [m 32][lane half 2][r 16], m = tap * 3 + co (pack.cpp)
     const float* b3;       // [3]
     const void* x;         // original frames (format per template argument)
     float* partials;       // [n][2H * nstrips * 4]
@@ -45,17 +60,51 @@ struct Dec4P {
     int n, H, W;           // input map size; the output is 2H x 2W
     int R, nbands, nstrips;
     unsigned nitems;       // n * nbands * nstrips
+    unsigned long long* dbg;   // VAD_D4_STAMPS diagnostic build only
 };
 
-__device__ __forceinline__ float d4_wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+struct D4Phase { int valid, n, strip, r0, r1, yp, row_ok; };   // one output row of P (all fields wave-uniform); row_ok: its input row is inside the image
+struct D4Out { float rc[3], e, ws; };           // one thread's results of a combine
+
+// Sum over the 64 lanes, valid in lane 63: six DPP adds on the VALU (a __shfl_xor butterfly is six dependent ds_bpermute,
+// each a full LDS latency).  Fixed order: quads, 8s, rows of 16, rows 0+1 / 2+3, halves.
+__device__ __forceinline__ float d4_wave_sum63(float v) {
+#define D4_DPP(ctrl, rows) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), (ctrl), (rows), 0xF, false))
+    v += D4_DPP(0xB1, 0xF);     // quad_perm [1,0,3,2]
+    v += D4_DPP(0x4E, 0xF);     // quad_perm [2,3,0,1]
+    v += D4_DPP(0x141, 0xF);    // row_half_mirror: the other quad of each 8 (every lane of a quad holds the quad's sum)
+    v += D4_DPP(0x140, 0xF);    // row_mirror: the other 8 of each row
+    v += D4_DPP(0x142, 0xA);    // row_bcast15 into rows 1 and 3
+    v += D4_DPP(0x143, 0xC);    // row_bcast31 into rows 2 and 3
+#undef D4_DPP
     return v;
 }
 
+__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {          // two v_pk_add_f32 (IEEE adds, same results as four v_add_f32)
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+#ifdef VAD_D4_STAMPS
+#define STAMP(k)                                                                                      \
+    {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (st_prev) st_sum[k] += t_ - st_prev;                                                       \
+        st_prev = t_;                                                                                 \
+        if ((k) == 3) ++st_n;                                                                         \
+    }
+#else
+#define STAMP(k)
+#endif
+
 template <bool XU8>
 __global__ __launch_bounds__(256, 2) void dec4_score_kernel(Dec4P p) {
-    __shared__ __attribute__((aligned(16))) float P[2 * D4_BUF];
+    extern __shared__ __attribute__((aligned(16))) float P[];            // 2 * D4_BUF
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int H = p.H, W = p.W, H2 = 2 * H, W2 = 2 * W;
@@ -70,165 +119,290 @@ __global__ __launch_bounds__(256, 2) void dec4_score_kernel(Dec4P p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 wA[a][b][ks] = *(const f32x4*)(p.wt + ((((2 * a + b) * 4 + ks) * 32 + li) * 8 + 4 * lh));
-    float bias1[16], w2f[16];
+    // GEMM 2 A fragments: lane li is P slot li; its (tap, co) row of the packed weights, or a zero row
+    int msrc = 27;
+    {
+        const int dx = li < 10 ? (li == 9 ? 2 : 0) : (li >= 12 && li < 21 ? 1 : (li >= 24 ? 2 : -1));
+        const int idx = li == 9 ? 8 : (li < 9 ? li : (li < 21 ? li - 12 : li - 24));
+        if (dx >= 0) msrc = ((idx / 3) * 3 + dx) * 3 + idx % 3;
+    }
+    f32x16 biasv;
+    float w2f[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        bias1[r] = p.bt[(r & 3) + 8 * (r >> 2) + 4 * lh];
-        w2f[r] = p.w2[(li * 2 + lh) * 16 + r];
+        biasv[r] = p.bt[(r & 3) + 8 * (r >> 2) + 4 * lh];
+        w2f[r] = p.w2[(msrc * 2 + lh) * 16 + r];
     }
     const float c3b0 = p.b3[0], c3b1 = p.b3[1], c3b2 = p.b3[2];
 
-    // zero both P buffers once: columns no lane ever writes (the x halo, columns past the image) are the zero padding
+    // zero both P buffers once: the columns no lane ever writes (jl 0, 1, 258, 259) are zero padding / never-owned halo
     for (int i = tid; i < 2 * D4_BUF / 4; i += 256) ((f32x4*)P)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     const unsigned in_bytes = (unsigned)(H * W) * 32u * 4u;
     const size_t plane = (size_t)H2 * W2;
-    unsigned phase = 0;                                                  // P buffer parity, carried across items
+    const int j = tid;                                                   // this thread's output column within the strip (combine)
+#ifdef VAD_D4_STAMPS
+    unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0, st_n = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    for (unsigned item = blockIdx.x; item < p.nitems; item += gridDim.x) {
+    auto decode = [&](unsigned item, int& n, int& strip, int& r0, int& r1) {
         unsigned t_ = item;
-        const int strip = t_ % p.nstrips; t_ /= p.nstrips;
+        strip = t_ % p.nstrips; t_ /= p.nstrips;
         const int band = t_ % p.nbands;
-        const int n = t_ / p.nbands;
-        const int r0 = band * p.R, r1 = (r0 + p.R < H) ? r0 + p.R : H;
-        const int xs0 = 126 * strip;                                     // first input column of the strip
-        const int jlo = strip ? 2 : 0;
+        n = t_ / p.nbands;
+        r0 = band * p.R;
+        r1 = (r0 + p.R < H) ? r0 + p.R : H;
+    };
+    // Loads are issued unconditionally wherever possible (invalid rows / lanes get the out-of-range offset or a clamped
+    // address): a load under a branch leaves hipcc unable to count what is in flight on the other path, and it then waits
+    // for vmcnt(0).
+    auto load_row = [&](f32x4 (&dst)[4], bool have, int n, int strip, int iy) {
+        const int cx = 126 * strip + 32 * wave + li;                     // this lane's input column (GEMM phases)
+        const bool ok = have && iy >= 0 && iy < H && cx < W;
+        const __amdgpu_buffer_rsrc_t rin = vad_rsrc(p.in + (size_t)(have ? n : 0) * H * W * 32, in_bytes);
+        const unsigned off = ok ? (unsigned)(__mul24(__mul24(iy, W) + cx, 32) + 4 * lh) * 4u : VAD_OOB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dst[ks] = vad_bload4(rin, off, (unsigned)ks * 32u);
+    };
+    // What thread j needs to know about its output column of one strip: computed once per work item (every VALU
+    // instruction in the phase loop costs matrix-pipe time, see the header)
+    struct LaneCols {
+        int own;          // this thread stores / scores column ox
+        int ox;           // output column
+        unsigned xoff;    // byte offset of (own ? ox : 0) within one row of the original frame
+        int c0, c1, c2;   // LDS float offsets of the three neighbour column records (column 0 - all zero - past the right edge)
+    };
+    auto lane_cols = [&](int strip) -> LaneCols {
+        const int xs0 = 126 * strip, jlo = strip ? 2 : 0;
         int jhi = W2 - 2 * xs0;
         const int jcap = (strip == p.nstrips - 1) ? 256 : 254;
         if (jhi > jcap) jhi = jcap;
-        if (p.nstrips > 1) {                                             // the never-written columns differ between strips
-            __syncthreads();
-            for (int i = tid; i < 2 * D4_BUF / 4; i += 256) ((f32x4*)P)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            __syncthreads();
+        LaneCols c;
+        c.own = j >= jlo && j < jhi;
+        c.ox = 2 * xs0 + j;
+        c.xoff = (unsigned)(c.own ? c.ox : 0) * (XU8 ? 3u : 4u);
+        c.c0 = (j + 1) * D4_CPITCH;
+        c.c1 = (j + 2) * D4_CPITCH;
+        c.c2 = c.ox + 1 < W2 ? (j + 3) * D4_CPITCH : 0;
+        return c;
+    };
+    const unsigned x_frame_bytes = (unsigned)plane * (XU8 ? 3u : 12u);
+    auto load_x = [&](unsigned (&dst)[3], const D4Phase& ph, const LaneCols& lc) {   // original-input values of ph's output row, raw
+        int yo = ph.yp - 1;                                              // clamped into the band (rows outside are never used)
+        yo = yo < 2 * ph.r0 ? 2 * ph.r0 : yo;
+        yo = yo < 2 * ph.r1 ? yo : 2 * ph.r1 - 1;
+        const __amdgpu_buffer_rsrc_t rx = vad_rsrc((const char*)p.x + (size_t)ph.n * x_frame_bytes, x_frame_bytes);
+        if (XU8) {
+            const unsigned so = (unsigned)(yo * W2) * 3u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[c] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rx, (int)lc.xoff, (int)(so + c), 0);
+        } else {
+            const unsigned so = (unsigned)(yo * W2) * 4u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[c] = __float_as_uint(vad_bload1(rx, lc.xoff, so + (unsigned)c * (unsigned)plane * 4u));
         }
-        const int cx = xs0 + 32 * wave + li;                             // this lane's input column (GEMM phases)
-        const bool wave_on = xs0 + 32 * wave < W;                        // (wave-uniform)
-        const bool col_ok = cx < W;
-        const __amdgpu_buffer_rsrc_t rin = vad_rsrc(p.in + (size_t)n * H * W * 32, in_bytes);
-        const int jl_w = 2 + 2 * (32 * wave + li);                       // LDS column of this lane's b = 0 output
+    };
+    // tanh as vad_tanh computes it, bit for bit, with the two constant factors of exp(2 v) = exp2(v * 2 log2(e)) folded
+    // (a multiplication by 2 is exact, so (2 v) * c == v * (2 c))
+    auto tanh_ = [](float v) {
+        return __builtin_fmaf(-2.0f, vad_rcp(__builtin_amdgcn_exp2f(v * (2.0f * 1.44269504088896341f)) + 1.0f), 1.0f);
+    };
 
-        // this thread's output column (combine phases)
-        const int j = tid, ox = 2 * xs0 + j;
-        const bool own = j >= jlo && j < jhi;
-        const int oxc = own ? ox : 0;
+    float Oa[3] = {0.f, 0.f, 0.f}, Ob[3] = {0.f, 0.f, 0.f};              // rows yp-1 (two of three terms) and yp (one term)
+    // No reset between work items: an item's first output row 2 r0 starts from `Ob = s[0]` of its first phase, and what the
+    // previous item left in Oa / Ob only reaches rows 2 r0 - 2 and 2 r0 - 1, which are not this item's to store.
 
-        f32x4 fr[4], nf[4];                                              // input fragments of the current / next input row
-        auto load_row = [&](f32x4 (&dst)[4], int iy) {
-            const bool ok = iy >= 0 && iy < H && col_ok;
-            const unsigned off = ok ? (unsigned)(__mul24(__mul24(iy, W) + cx, 32) + 4 * lh) * 4u : VAD_OOB;
+    // ---- combine of phase ph (its P row is in rbuf), values only (the stores follow), cut into stages issued between the
+    // GEMM-1 MFMAs of the next phase with a scheduling fence after each: the LDS reads go out first and their latency, like
+    // every wait in the combine, passes while the matrix pipe works.
+    f32x4 g0a, g0b, g1a, g1b, g2a, g2b;
+    float g0c, g1c, g2c, cs[9], fin[3];
+    D4Out o;
+    auto combine_stage = [&](int k, const D4Phase& ph, const LaneCols& lc, const float* rbuf, const unsigned (&xr)[3]) {
+        if (k == 0) {
+            // outside the image P is zero padding: the whole row (uniform), or the right neighbour of the last column -
+            // read the all-zero column 0 instead (three address selects, not 27 value selects)
+            const float* q0 = rbuf + (ph.row_ok ? lc.c0 : 0);
+            const float* q1 = rbuf + (ph.row_ok ? lc.c1 : 0);
+            const float* q2 = rbuf + (ph.row_ok ? lc.c2 : 0);
+            g0a = *(const f32x4*)(q0); g0b = *(const f32x4*)(q0 + 4); g0c = q0[8];
+            g1a = *(const f32x4*)(q1 + 12); g1b = *(const f32x4*)(q1 + 16); g1c = q1[20];
+            g2a = *(const f32x4*)(q2 + 24); g2b = *(const f32x4*)(q2 + 28); g2c = q2[9];
+        } else if (k == 1) {                                             // cs[3 dy + co] = (dx 0 + dx 1) + dx 2, two sums per
+            const f32x4 sa = pk_add4(pk_add4(g0a, g1a), g2a);            // instruction (hipcc scalarises a plain vector add here)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dst[ks] = vad_bload4(rin, off, (unsigned)ks * 32u);
-        };
-        if (wave_on) load_row(fr, r0 - 1);
-
-        unsigned xraw[3] = {0u, 0u, 0u};
-        auto load_x = [&](int yo) {                                      // original-input values of (yo, ox), raw
-            if (!own) return;
-            if (XU8) {
-                const unsigned char* q = (const unsigned char*)p.x + (((size_t)n * H2 + yo) * W2 + oxc) * 3;
-                xraw[0] = q[0]; xraw[1] = q[1]; xraw[2] = q[2];
-            } else {
-                const float* q = (const float*)p.x + (size_t)n * 3 * plane + (size_t)yo * W2 + oxc;
+            for (int i = 0; i < 4; ++i) cs[i] = sa[i];
+        } else if (k == 2) {
+            const f32x4 sb = pk_add4(pk_add4(g0b, g1b), g2b);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) xraw[c] = __float_as_uint(q[c * plane]);
+            for (int i = 0; i < 4; ++i) cs[4 + i] = sb[i];
+            cs[8] = (g0c + g1c) + g2c;
+        } else if (k == 3) {
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                fin[co] = Oa[co] + cs[6 + co];
+                Oa[co] = Ob[co] + cs[3 + co];
+                Ob[co] = cs[co];
+                asm volatile("" : "+v"(Oa[co]), "+v"(Ob[co]));           // computed HERE (loop-carried: hipcc would sink the adds to the trip's end)
             }
-        };
-        load_x(2 * r0);
+        } else if (k == 4) {
+            o.rc[0] = tanh_(fin[0] + c3b0);
+        } else if (k == 5) {
+            o.rc[1] = tanh_(fin[1] + c3b1);
+        } else if (k == 6) {
+            o.rc[2] = tanh_(fin[2] + c3b2);
+        } else {
+            float d[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = (XU8 ? vad_norm_u8(xr[c]) : __uint_as_float(xr[c])) - o.rc[c];
+            // spelled out: the three copies of this code (a = 0 / a = 1 blocks, drain) must contract identically
+            const float e = __builtin_fmaf(d[2], d[2], __builtin_fmaf(d[1], d[1], d[0] * d[0]));
+            o.e = lc.own ? e : 0.f;
+            o.ws = d4_wave_sum63(o.e);
+        }
+    };
+    // the per-row partial sum: one predicated buffer store (out-of-range offset when there is nothing to store), no branch
+    const unsigned part_frame = (unsigned)H2 * p.nstrips * 4u;           // floats per frame
+    auto store_partial = [&](const D4Phase& ph, float ws) {
+        const int yo = ph.yp - 1;
+        const bool outrow = ph.valid && yo >= 2 * ph.r0 && yo < 2 * ph.r1;   // (uniform) row yo is complete and this band's
+        const __amdgpu_buffer_rsrc_t rp = vad_rsrc(p.partials + (size_t)ph.n * part_frame, part_frame * 4u);
+        const unsigned off = (outrow && lane == 63) ? (unsigned)((yo * p.nstrips + ph.strip) * 4 + wave) * 4u : VAD_OOB;
+        vad_bstore1(ws, rp, off, 0u);
+    };
+    auto store_maps = [&](const D4Phase& ph, const LaneCols& lc, const D4Out& o) {   // optional outputs (not on the scoring path)
+        const int yo = ph.yp - 1;
+        if (!(ph.valid && yo >= 2 * ph.r0 && yo < 2 * ph.r1)) return;
+        if (lc.own) {
+            const size_t o0 = (size_t)ph.n * 3 * plane + (size_t)yo * W2 + lc.ox;
+            if (p.recon) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p.recon[o0 + c * plane] = o.rc[c];
+            }
+            if (p.errmap) p.errmap[(size_t)ph.n * plane + (size_t)yo * W2 + lc.ox] = o.e / 3.0f;
+        }
+    };
+    const bool want_maps = p.recon || p.errmap;
 
-        float Oa[3] = {0.f, 0.f, 0.f}, Ob[3] = {0.f, 0.f, 0.f};          // rows yp-1 (two of three terms) and yp (one term)
+    unsigned item = blockIdx.x;
+    if (item >= p.nitems) return;                                        // (the grid never exceeds the work; whole group)
+    int n, strip, r0, r1;
+    decode(item, n, strip, r0, r1);
+    f32x4 fr[4];                                                         // input fragments of the current input row
+    load_row(fr, true, n, strip, r0 - 1);
+    D4Phase prev = {0, n, strip, r0, r1, 2 * r0, 0};
+    LaneCols lc_prev = lane_cols(strip);
+    unsigned xc[3] = {0u, 0u, 0u}, xn[3];
+    unsigned phase = 0;                                                  // P buffer parity
+    const int jl_w = 2 + 2 * (32 * wave + li);                           // LDS column of this lane's b = 0 output
 
+    for (;;) {
+        const unsigned nitem = item + gridDim.x;
+        const bool have_next = nitem < p.nitems;
+        int nn, nstrip, nr0, nr1;
+        decode(have_next ? nitem : item, nn, nstrip, nr0, nr1);
+        const LaneCols lc = lane_cols(strip);
+        bool first = true;                                               // (of this item: `prev` still belongs to the last one)
         for (int iy = r0 - 1; iy <= r1; ++iy) {
-            const bool row_ok = iy >= 0 && iy < H;                       // (uniform)
-            if (wave_on && iy + 1 <= r1) load_row(nf, iy + 1);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 if (a == 0 ? iy < r0 : iy >= r1) continue;               // band ends: only a = 1 of row r0-1, only a = 0 of row r1
-                const int yp = 2 * iy + a;
-                float* buf = P + (phase & 1u) * D4_BUF;
-                if (row_ok && wave_on) {
-                    f32x16 acc1[2], acc2[2];
+                const D4Phase cur = {1, n, strip, r0, r1, 2 * iy + a, iy >= 0 && iy < H};
+                float* wbuf = P + (phase & 1u) * D4_BUF;
+                const float* rbuf = P + ((phase & 1u) ^ 1u) * D4_BUF;
+                STAMP(0);
+                // ---- the 64 MFMAs of `cur` with the combine of `prev` between them
+                // The bias is the C operand of each chain's first MFMA (no accumulator initialisation to issue); P rows / columns
+                // outside the image are computed like any other and never read (combine stage 0).
+                f32x16 acc1[2] = {biasv, biasv}, acc2[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[b][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) acc1[b] = MFMA32(wA[a][b][ks][jj], fr[ks][jj], acc1[b]);
+                        if (jj & 1) {                                    // behind every fourth MFMA: one combine stage
+                            const int k = 2 * ks + (jj >> 1);
+                            combine_stage(k, prev, lc_prev, rbuf, xc);
+                            if (k == 0) load_x(xn, cur, lc);             // consumed by the NEXT trip's combine
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                // GEMM 1 has issued: this phase's pixels are consumed, take the next phase's (inline asm: as a plain assignment
+                // of a loop-carried value hipcc sinks the copy to the end of the trip) ...
+#pragma unroll
+                for (int c = 0; c < 3; ++c) asm volatile("v_mov_b32 %0, %1" : "=v"(xc[c]) : "v"(xn[c]));
+                __builtin_amdgcn_sched_barrier(0);
+                // ... and if it was this input row's last phase, the row's registers are free: the next input row in sequence
+                // is loaded straight into them (32 MFMAs, the LDS stores and a barrier pass before its first use)
+                if (a == 1) load_row(fr, true, n, strip, iy + 1);        // (a = 1 exists only below r1)
+                else if (iy == r1) load_row(fr, have_next, nn, nstrip, nr0 - 1);   // band end: the next item's first row
+                store_partial(prev, o.ws);
+                __builtin_amdgcn_sched_barrier(0);
+                // ReLU as an INTEGER max with 0 (negative floats are negative integers): one instruction, where fmaxf costs a
+                // canonicalising v_max as well - and, unlike an inline-asm v_max_f32, one whose MFMA hazards hipcc handles
+                // All 32 first, then the 32 MFMAs back to back: interleaved, every MFMA waits two states for the VALU result it reads.
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float t = acc1[b][r];                      // (not __builtin_bit_cast on the element: hipcc then reads element 0)
+                        const int bits = __float_as_int(t);
+                        acc1[b][r] = __int_as_float(bits > 0 ? bits : 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc2[b] = MFMA32(w2f[r], acc1[b][r], acc2[b]);
+                STAMP(1);
+                // P slots 8 g + 4 lh + {0..3} of this lane's two output pixels (b = 0, 1): one 16-byte store per g
+                {
+                    float* dst = wbuf + jl_w * D4_CPITCH + 4 * lh;
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { acc1[b][r] = bias1[r]; acc2[b][r] = 0.f; }
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                            for (int b = 0; b < 2; ++b) acc1[b] = MFMA32(wA[a][b][ks][jj], fr[ks][jj], acc1[b]);
-#pragma unroll
-                    // ReLU as plain fmaxf, NOT the inline-asm v_max of vad_act: hipcc's hazard recogniser does not look inside
-                    // inline asm, so it would put no wait states between the MFMA that writes acc1 and an asm statement that
-                    // reads it (the other kernels' epilogues have address arithmetic in between; here the read follows at once)
-                    for (int r = 0; r < 16; ++r)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) acc2[b] = MFMA32(w2f[r], fmaxf(acc1[b][r], 0.f), acc2[b]);
-                    // P rows m = (r&3) + 8 (r>>2) + 4 lh of this lane's two output pixels (b = 0, 1): one 8-byte store each
-                    if (col_ok) {
-                        float* dst = buf + 4 * lh * D4_PITCH + jl_w;
-#pragma unroll
-                        for (int r = 0; r < 12; ++r)
-                            *(f32x2*)(dst + ((r & 3) + 8 * (r >> 2)) * D4_PITCH) = f32x2{acc2[0][r], acc2[1][r]};
-                        if (lh == 0) {
-#pragma unroll
-                            for (int r = 12; r < 15; ++r)
-                                *(f32x2*)(dst + ((r & 3) + 8 * (r >> 2)) * D4_PITCH) = f32x2{acc2[0][r], acc2[1][r]};
-                        }
-                    }
+                        for (int g = 0; g < 4; ++g)
+                            *(f32x4*)(dst + b * D4_CPITCH + 8 * g) =
+                                f32x4{acc2[b][4 * g], acc2[b][4 * g + 1], acc2[b][4 * g + 2], acc2[b][4 * g + 3]};
                 }
+                if (want_maps) store_maps(prev, lc_prev, o);
+                STAMP(2);
                 __syncthreads();
-                // ---- combine: thread j adds P row yp into its running output rows
-                float s[3][3];
-                if (row_ok) {
-                    const float* q = buf + 1 + j;                        // column jl - 1
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                        for (int co = 0; co < 3; ++co) {
-                            const int m0 = (dy * 3) * 3 + co;
-                            s[dy][co] = (q[m0 * D4_PITCH] + q[(m0 + 3) * D4_PITCH + 1]) + q[(m0 + 6) * D4_PITCH + 2];
-                        }
-                } else {
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                        for (int co = 0; co < 3; ++co) s[dy][co] = 0.f;
-                }
-                float fin[3];
-#pragma unroll
-                for (int co = 0; co < 3; ++co) {
-                    fin[co] = Oa[co] + s[2][co];
-                    Oa[co] = Ob[co] + s[1][co];
-                    Ob[co] = s[0][co];
-                }
-                const int yo = yp - 1;
-                if (yo >= 2 * r0 && yo < 2 * r1) {                       // (uniform) output row yo is complete
-                    float e = 0.f;
-                    if (own) {
-                        const float rc[3] = {vad_tanh(fin[0] + c3b0), vad_tanh(fin[1] + c3b1), vad_tanh(fin[2] + c3b2)};
-                        const size_t o = (size_t)n * 3 * plane + (size_t)yo * W2 + ox;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float xv = XU8 ? vad_norm_u8(xraw[c]) : __uint_as_float(xraw[c]);
-                            const float d = xv - rc[c];
-                            e += d * d;
-                            if (p.recon) p.recon[o + c * plane] = rc[c];
-                        }
-                        if (p.errmap) p.errmap[(size_t)n * plane + (size_t)yo * W2 + ox] = e / 3.0f;
-                    }
-                    if (yo + 1 < 2 * r1) load_x(yo + 1);
-                    const float ws = d4_wave_sum(e);
-                    if (lane == 0)
-                        p.partials[(size_t)n * ((size_t)H2 * p.nstrips * 4) + ((size_t)yo * p.nstrips + strip) * 4 + wave] = ws;
-                }
+                STAMP(3);
+                prev = cur;
+                if (first) { lc_prev = lc; first = false; }
                 ++phase;
             }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fr[ks] = nf[ks];
         }
+        if (!have_next) break;
+        item = nitem; n = nn; strip = nstrip; r0 = nr0; r1 = nr1;
     }
+    // drain: the last phase's combine
+    {
+        const float* rbuf = P + ((phase & 1u) ^ 1u) * D4_BUF;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) combine_stage(k, prev, lc_prev, rbuf, xc);
+        store_partial(prev, o.ws);
+        if (want_maps) store_maps(prev, lc_prev, o);
+    }
+#ifdef VAD_D4_STAMPS
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+        for (int i = 0; i < 4; ++i) d[i] = st_sum[i];
+        d[8] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID
+        d[9] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // XCC_ID
+        d[10] = (__builtin_amdgcn_s_memtime() - st_t0) * 100000ull / (__builtin_amdgcn_s_memrealtime() - st_r0);
+        d[11] = st_n;
+    }
+#endif
 }
 
 int d4_num_cus() {
@@ -245,6 +419,8 @@ int d4_num_cus() {
 }
 }  // namespace
 
+static unsigned long long* g_d4_dbg = nullptr;   // VAD_D4_STAMPS diagnostic build (tools/d4_stamps.py)
+extern "C" int vad_debug_set_dec4_stamps(void* q) { g_d4_dbg = (unsigned long long*)q; return VAD_OK; }
 static std::atomic<int> g_vad_dec4_band{0};     // debug: rows per band (0 = chosen from the batch size)
 extern "C" int vad_debug_set_dec4_band(int rows) { g_vad_dec4_band = rows; return VAD_OK; }
 
@@ -268,14 +444,19 @@ int vad_dec4_score_fmt(const float* in, const float* wt_packed, const float* bt,
     p.partials = partials; p.recon = recon; p.errmap = errmap;
     p.n = n; p.H = h; p.W = w;
     p.nstrips = d4_strips(w);
-    // Band height: the y halo costs one input row per band end ((R + 1) / R of the matrix work), but the grid needs about
-    // two work-groups per CU.  The result does not depend on it (every output pixel's sums are ordered by pixel only).
+    p.dbg = g_d4_dbg;
+    // 73 KB of LDS per work-group (two P buffers): above the 64 KB a kernel gets without asking
     static std::atomic<int> per_cu_cached{0};
     int per_cu = per_cu_cached.load(std::memory_order_relaxed);
     if (!per_cu) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dec4_score_kernel<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        VAD_REQUIRE(hipFuncSetAttribute((const void*)dec4_score_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)dec4_score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES) == hipSuccess,
+                    "dec4_score: this device does not give a work-group %d bytes of LDS", D4_LDS_BYTES);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dec4_score_kernel<false>, 256, D4_LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
         per_cu_cached = per_cu;
     }
+    // Band height: the y halo costs one input row per band end ((R + 1) / R of the matrix work), but the grid needs about
+    // two work-groups per CU.  The result does not depend on it (every output pixel's sums are ordered by pixel only).
     const long long slots = (long long)d4_num_cus() * per_cu;
     int R = g_vad_dec4_band.load(std::memory_order_relaxed);
     if (R <= 0) {
@@ -289,8 +470,8 @@ int vad_dec4_score_fmt(const float* in, const float* wt_packed, const float* bt,
     VAD_REQUIRE(items < (1ll << 31), "dec4_score: %lld work items out of range", items);
     p.nitems = (unsigned)items;
     const unsigned grid = (unsigned)(items < slots ? items : slots);
-    if (fmt == VAD_X_U8_NHWC) hipLaunchKernelGGL(dec4_score_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(dec4_score_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (fmt == VAD_X_U8_NHWC) hipLaunchKernelGGL(dec4_score_kernel<true>, dim3(grid), dim3(256), D4_LDS_BYTES, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(dec4_score_kernel<false>, dim3(grid), dim3(256), D4_LDS_BYTES, (hipStream_t)stream, p);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
