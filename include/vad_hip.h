@@ -382,8 +382,9 @@ int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, 
  * Bit 0: 1 = persistent work-groups with register prefetch of the next stage (default), 0 = one tile per work-group
  * (bit-identical results).  Bit 1: pricing runs whose results are NOT valid - exact kernels drop their epilogue stores,
  * split kernels read no weights.  Bit 2: alternative cout-64 tiling.  Bit 3: never use the small-grid (16x16x4) ConvLSTM
- * kernel, bit 4: always use it, bit 5: never compute the ConvLSTM x halves ahead of the recurrence (bit-identical results
- * either way). */
+ * kernel, bit 4: always use it, bit 5: never compute the ConvLSTM x halves ahead of the recurrence, bit 6: never use the
+ * gate-split form of the small-grid kernel (one gate per wave, for the smallest grids), bit 7: use its 8-wave form wherever the small-grid
+ * kernel would run (bit-identical results either way). */
 int vad_debug_set_conv_variant(int variant);
 /* 0 = run the ConvLSTM layers strictly one after the other on the caller's stream; 1 (default) = small launch groups run
  * them as a wavefront: layer l step t on a library-owned helper stream as soon as layer l-1 step t is done (fork / join by

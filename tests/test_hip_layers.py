@@ -149,7 +149,8 @@ def test_convlstm_step_oracle(cx, hid, h, w, zero_state):
 @pytest.mark.parametrize("n,cx,hid,h,w,zero_state", [(2, 128, 128, 16, 16, False), (3, 64, 64, 5, 9, False), (1, 32, 64, 3, 4, False),
                                                      (2, 128, 128, 16, 16, True), (5, 128, 64, 7, 18, False)])
 def test_convlstm_small_grid_kernel_is_bit_identical(vad, n, cx, hid, h, w, zero_state):
-    """The small-grid ConvLSTM kernel (16x16x4 MFMA, used below one work-group per CU: the reference's batch sizes) against
+    """The small-grid ConvLSTM kernels (16x16x4 MFMA, used below one work-group per CU: the reference's batch sizes; bit 6 = never
+    / bit 7 = always the gate-split form for the smallest grids) against
     the 32x32x2 kernels (vad_debug_set_conv_variant bit 3 = never small; variant 0 = one tile per work-group): torch.equal,
     not a tolerance - it reproduces their k order exactly (csrc/conv_small.h), which is why a clip scored alone equals the
     same clip inside a large batch.  Ragged maps (partial tiles in both directions) and unequal x / h channel counts."""
@@ -162,15 +163,20 @@ def test_convlstm_small_grid_kernel_is_bit_identical(vad, n, cx, hid, h, w, zero
     hp = None if zero_state else (rng.standard_normal((n, hid, h, w)) * 0.5).astype(np.float32)
     cp = None if zero_state else rng.standard_normal((n, hid, h, w)).astype(np.float32)
     try:
+        l.vad_debug_set_conv_variant(1 | 64)           # never the gate-split kernel: the 4-gates-per-wave small-grid kernel
         small = H.convlstm_step(x, hp, cp, wt, b)
+        l.vad_debug_set_conv_variant(1 | 128)          # the gate-split kernel (one gate per wave, the cell through LDS)
+        gate = H.convlstm_step(x, hp, cp, wt, b)
+        l.vad_debug_set_conv_variant(1)                # whatever the cost model picks
+        auto = H.convlstm_step(x, hp, cp, wt, b)
         l.vad_debug_set_conv_variant(1 | 8)
         big = H.convlstm_step(x, hp, cp, wt, b)
         l.vad_debug_set_conv_variant(0)
         tile = H.convlstm_step(x, hp, cp, wt, b)
     finally:
         l.vad_debug_set_conv_variant(1)
-    assert np.array_equal(small[0], big[0]) and np.array_equal(small[1], big[1])
-    assert np.array_equal(small[0], tile[0]) and np.array_equal(small[1], tile[1])
+    for other in (gate, auto, big, tile):
+        assert np.array_equal(small[0], other[0]) and np.array_equal(small[1], other[1])
     rh, rc = c_oracle.convlstm_cell(x, hp if hp is not None else np.zeros((n, hid, h, w), np.float32),
                                     cp if cp is not None else np.zeros((n, hid, h, w), np.float32), wt, b)
     assert max_abs(small[0], rh) < 2e-5 and max_abs(small[1], rc) < 2e-5

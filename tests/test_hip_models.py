@@ -234,7 +234,7 @@ def test_convlstm_x_halves_ahead_of_the_recurrence_change_no_bit(vad, latent, hi
     frames = torch.from_numpy(vad.synth.frames(56, 0, 9, 3, hw, hw)).cuda()
     outs = []
     try:
-        for bits, wf in ((1, 1), (1 | 32, 1), (1, 0), (1 | 32, 0)):
+        for bits, wf in ((1, 1), (1 | 32, 1), (1, 0), (1 | 32, 0), (1 | 64, 1), (1 | 128, 1), (1 | 128 | 32, 0)):   # bit 6 / 7: never / always the gate-split kernels
             l.vad_debug_set_conv_variant(bits)
             l.vad_debug_set_lstm_wavefront(wf)
             with torch.no_grad():

@@ -274,18 +274,20 @@ static std::atomic<int> g_vad_conv_bits{1};   // bit 0: 1 = persistent + registe
                                               // bit 1: pricing runs, results invalid (exact: drop epilogue stores; split: no weight reads);
                                               // bit 2: alternative cout-64 tiling;
                                               // bit 3: never use the small-grid (16x16x4) ConvLSTM kernel; bit 4: always use it;
-                                              // bit 5: never compute the ConvLSTM x halves ahead of the recurrence
-extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 63; return VAD_OK; }
+                                              // bit 5: never compute the ConvLSTM x halves ahead of the recurrence;
+                                              // bit 6: never use the gate-split small-grid kernel; bit 7: use its 8-wave form wherever the small-grid form runs
+extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 255; return VAD_OK; }
 // may the model-level launch sequence split the ConvLSTM steps of small launch groups into x halves (ahead) + h halves?
 bool vad_convlstm_hoist_ok(void) {
     const int b = g_vad_conv_bits.load(std::memory_order_relaxed);
     return (b & 1) && !(b & 8) && !(b & 32);
 }
 struct ConvKnobs {
-    int variant, stagger, conv64, no_small, all_small;
+    int variant, stagger, conv64, no_small, all_small, no_gate, all_gate;
     ConvKnobs() {
         const int b = g_vad_conv_bits.load(std::memory_order_relaxed);
         variant = b & 1; stagger = (b >> 1) & 1; conv64 = (b >> 2) & 1; no_small = (b >> 3) & 1; all_small = (b >> 4) & 1;
+        no_gate = (b >> 6) & 1; all_gate = (b >> 7) & 1;
     }
 };
 #define VAD_REQUIRE_PREC(who) VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, who ": precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1), VAD_PREC_BF16 (2) or VAD_PREC_BF16S (3)", precision)
@@ -302,6 +304,19 @@ static int vad_num_cus() {
     }
     return ncu;
 }
+
+// does the gate-split kernel (conv_small.h) serve n frames best?  cq = output columns / 4 (hid for a ConvLSTM step).  Measured
+// per step on a 16x16 map, hid 128 (tools/gpu_lstm_slope.sh): see DESIGN.md section 4.5.
+static int vad_gate_kernel_wins(int n, int h, int wd, int cq, const ConvKnobs& kn) {   // -> M-tiles per work-group (1, 2) or 0 = no
+    if (kn.no_gate || cq % 16 != 0) return 0;
+    if (kn.all_gate) return 2;                                                            // (debug: the 8-wave form everywhere)
+    const int ncu = vad_num_cus();
+    const long long nb1 = (long long)n * ((wd + 7) / 8) * ((h + 1) / 2) * (cq / 16);      // work-groups of 4 waves
+    if (nb1 <= 2ll * ncu) return 1;
+    const long long nb2 = (long long)n * ((wd + 15) / 16) * ((h + 1) / 2) * (cq / 16);    // of 8 waves
+    return 2 * nb2 <= 3ll * ncu ? 2 : 0;
+}
+
 
 template <typename K>
 static unsigned persistent_grid(K kernel, unsigned nblocks, int max_per_cu = 2) {
@@ -470,6 +485,19 @@ int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const fl
     // work-groups and 123 us.  When the throughput tiling gives fewer work-groups than CUs, a work-group takes 4 rows x 16
     // columns x 64 channels instead (one 32x32 MFMA tile per wave: a quarter of the serial work, 4x the work-groups; same K
     // order, bit-identical results).
+    // The x half of a ConvLSTM step computed ahead of the recurrence (a channel sub-range of the cell's weights, no activation)
+    // on the smallest grids: the gate-split kernel's K loop without the cell (conv_small.h), same values bit for bit.
+    const int mtw = (cin_w > cin && !pool && act == VAD_ACT_NONE && !with_stats && cout % 64 == 0 &&
+                     (long long)h * wd * cin * 4 < (1ll << 31) && 9ll * cin_w * cout * 4 < (1ll << 31)) ? vad_gate_kernel_wins(n, h, wd, cout / 4, kn) : 0;
+    if (mtw) {
+        p.hid = cout / 4;
+        p.tiles_x = (wd + 8 * mtw - 1) / (8 * mtw); p.tiles_y = (h + 1) / 2; p.cblocks = p.hid / 16; p.n = n;
+        p.nblocks = (unsigned)((long long)n * p.tiles_x * p.tiles_y * p.cblocks);
+        if (mtw == 1) hipLaunchKernelGGL((convlstm_gate_kernel<0, 1>), dim3(p.nblocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((convlstm_gate_kernel<0, 2>), dim3(p.nblocks), dim3(512), 0, s, p);
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
     if (cout % 64 == 0) {
         const long long px = (long long)n * ((wd + 15) / 16);
         const long long nb_thr = cout % 128 == 0 ? px * ((h + 7) / 8) * (cout / 128) : px * ((h + 15) / 16) * (cout / 64);
@@ -597,7 +625,15 @@ int vad_convlstm_step_zx(const float* x, long long x_fs, const float* zx, long l
         p.nblocks = (unsigned)nb; p.n = n;
         VAD_REQUIRE((long long)h * wd * (cin_x > hid ? cin_x : hid) * 4 < (1ll << 31) && 9ll * p.cin * p.cout * 4 < (1ll << 31),
                     "convlstm_step: frame or weights too large for 32-bit offsets");
-        hipLaunchKernelGGL(convlstm_small_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+        // the smallest grids: one gate per wave, 8 waves per work-group, twice the work-groups (conv_small.h)
+        if (const int mtw = vad_gate_kernel_wins(n, h, wd, hid, kn)) {
+            p.cblocks = hid / 16; p.tiles_x = (wd + 8 * mtw - 1) / (8 * mtw);
+            p.nblocks = (unsigned)((long long)n * p.tiles_x * p.tiles_y * p.cblocks);
+            if (mtw == 1) hipLaunchKernelGGL((convlstm_gate_kernel<1, 1>), dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL((convlstm_gate_kernel<1, 2>), dim3(p.nblocks), dim3(512), 0, (hipStream_t)stream, p);
+        } else {
+            hipLaunchKernelGGL(convlstm_small_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+        }
         VAD_LAUNCH_CHECK();
         return VAD_OK;
     }

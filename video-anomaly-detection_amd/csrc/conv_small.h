@@ -27,6 +27,7 @@
 #define MFMA16X4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // 4 waves = 2 M-tiles (left / right 8 columns of a 2 x 16 pixel tile) x 2 blocks of 16 hidden channels
+template <int NB>
 __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
     constexpr int CK = 32, LH = 4, LW = 18, PS = CK + 4, NPIX = LH * LW, TOT = NPIX * (CK / 4), NPF = (TOT + 255) / 256;
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
     // B fragments run PB steps ahead in a ring of NB register sets: a step is only 8 MFMAs x 32 cycles, and a weight line that
     // misses L2 comes back from the Infinity Cache in ~550 cycles (one step ahead left ~300 cycles exposed per step: 73 us
     // per launch instead of the 31 us of its MFMAs)
-    constexpr int PB = 3, NB = 4;
+    constexpr int PB = NB - 1;
     static_assert(36 % NB == 0, "ring position must be the same in every chunk");
     f32x2 b[NB][4];
 #define SLOAD_B(buf, chunk, step)                                                                                     \
@@ -152,10 +153,18 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
             if (s + PB < 36) { SLOAD_B(bnxt, ch, s + PB); }
             else if (ch + 1 < nch) { SLOAD_B(bnxt, ch + 1, s + PB - 36); }
             __builtin_amdgcn_sched_barrier(0);         // keep the prefetch above this step's MFMAs
+            // Two gates at a time, each chain's second MFMA two instructions behind its first: four chains taken round-robin
+            // (0 1 2 3 0 1 2 3) issue a 16x16x4 MFMA every 48 clocks instead of every 32 (tools/ubench/mfma_chain.hip; two or
+            // three chains, or this order, reach 32).  The order inside every chain - the k order - is unchanged.
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a[cur][0], b[bcur][g][0], acc[g]);      // channels 0,4,2,6
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = MFMA16X4(a[cur][1], b[bcur][g][1], acc[g]);      // channels 1,5,3,7
+            for (int gp = 0; gp < 4; gp += 2) {
+                acc[gp] = MFMA16X4(a[cur][0], b[bcur][gp][0], acc[gp]);                            // channels 0,4,2,6
+                acc[gp + 1] = MFMA16X4(a[cur][0], b[bcur][gp + 1][0], acc[gp + 1]);
+                __builtin_amdgcn_sched_barrier(0);                                                 // (hipcc re-sorts independent MFMAs)
+                acc[gp] = MFMA16X4(a[cur][1], b[bcur][gp][1], acc[gp]);                            // channels 1,5,3,7
+                acc[gp + 1] = MFMA16X4(a[cur][1], b[bcur][gp + 1][1], acc[gp + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #undef SLOAD_B
@@ -170,6 +179,162 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
             const size_t o = ((size_t)y * W + x) * hid + hc;
             float cn, hn;
             vad_lstm_cell(acc[0][r], acc[1][r], acc[2][r], acc[3][r], cpv[r], cn, hn);
+            cout_[o] = cn;
+            hout[o] = hn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Gate-split form, for the smallest grids (one dense window, up to a few clips: generate_video_output, evaluate_video.py:344).
+// The kernel above is at its limit there: a wave's K loop is a fixed chain of 8 MFMAs per step at ~39 clocks each (4.6 us
+// per 32-channel chunk, tools/gpu_lstm_slope.sh), and with one clip only 32 of 256 CUs hold a work-group.  Here a wave takes
+// ONE gate of its 16 pixels x 16 hidden channels: 8 waves per work-group (2 M-tiles x 4 gates) share the same LDS tile, a
+// step is 2 dependent MFMAs (44 clocks each as a single chain, tools/ubench/mfma_chain.hip) instead of 8, and the grid has
+// twice the work-groups.  The four gates of a cell meet through 6 KB of LDS; the waves of gate 0 apply the cell update.
+// CELL = 0 is the same K loop without the cell: bias + the convolution of channels [0, cin_a) written as pre-activations
+// [n][h][w][cout] (the x halves computed ahead of the recurrence; cout / 4 takes the place of hid).
+// Bit-identical to both other forms: every accumulator chain runs the same k order from the same start value.
+// MTW = M-tiles (2 rows x 8 columns) per work-group: 4 MTW waves.  MTW = 1 doubles the work-groups once more - while they still
+// fit one per CU a wave has its SIMD's matrix pipe to itself (two waves of dependent 2-MFMA steps on one SIMD are pipe-bound).
+template <int CELL, int MTW>
+__global__ __launch_bounds__(256 * MTW) void convlstm_gate_kernel(Conv3P p) {
+    constexpr int NT = 256 * MTW, TW = 8 * MTW;
+    constexpr int CK = 32, LH = 4, LW = TW + 2, PS = CK + 4, NPIX = LH * LW, TOT = NPIX * (CK / 4), NPF = (TOT + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
+    __shared__ __attribute__((aligned(16))) float zbuf[3 * MTW * 64 * 4];        // gates 1..3 of every M-tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % MTW, g = wave / MTW;
+    const int li = lane & 15, kq = lane >> 4;
+    const int H = p.h, W = p.w_, hid = p.hid;                            // (CELL = 0: hid = cout / 4)
+
+    unsigned L = vad_xcd_remap(blockIdx.x, p.nblocks);
+    const int x0 = (L % p.tiles_x) * TW; L /= p.tiles_x;
+    const int y0 = (L % p.tiles_y) * 2; L /= p.tiles_y;
+    const int cb = L % p.cblocks;
+    const int n = L / p.cblocks;
+
+    const int arow = (li >> 1) & 1, acol = 8 * wm + 2 * (li >> 2) + (li & 1);
+    const int kc = ((kq & 1) << 2) | (kq & 2);
+    const int abase = (arow * LW + acol) * PS + kc;
+
+    const int hc = cb * 16 + li;
+    const unsigned wstep = (unsigned)p.cout * 32u;
+    const unsigned wtap = (unsigned)(p.cin / 8) * wstep;
+    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 9u * wtap);
+    const unsigned wl = (unsigned)(g * hid + hc) * 32u + 4u * (unsigned)kc;
+
+    const int nch_a = p.cin_a / CK;
+    const int nch = CELL ? (p.in2 ? p.cin : p.cin_a) / CK : nch_a;
+    const int ch0 = (CELL && p.zx) ? nch_a : 0;
+
+    f32x4 pf[NPF];
+    auto issue = [&](int ch) {
+        const bool a = ch < nch_a;
+        const float* src = a ? p.in + (size_t)n * p.in_fs : p.in2 + (size_t)n * p.in2_fs;
+        const int pstride = a ? p.cin_a : p.cin - p.cin_a;
+        const int coff = (a ? ch : ch - nch_a) * CK;
+        const __amdgpu_buffer_rsrc_t r = vad_rsrc(src, (unsigned)(H * W) * (unsigned)pstride * 4u);
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + NT * i, pix = idx >> 3, c4 = idx & 7;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+            const bool ok = idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            pf[i] = vad_bload4(r, ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, pstride) + coff + c4 * 4) * 4u : VAD_OOB, 0);
+        }
+    };
+    if (ch0 < nch) issue(ch0);
+
+    // B fragments PB steps ahead: a step is two MFMAs (~90 clocks), a weight line from the Infinity Cache ~550
+    constexpr int NB = 12, PB = NB - 1;
+    static_assert(36 % NB == 0, "ring position must be the same in every chunk");
+    f32x2 b[NB];
+#define GLOAD_B(buf, chunk, step) \
+    b[buf] = vad_bload2(rw, wl, (unsigned)((step) >> 2) * wtap + (unsigned)((chunk) * 4 + ((step) & 3)) * wstep)
+    if (ch0 < nch) {
+#pragma unroll
+        for (int s0 = 0; s0 < PB; ++s0) GLOAD_B(s0, ch0, s0);
+    }
+
+    const size_t cfs = (size_t)H * W * hid;
+    float cpv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (CELL && g == 0) {   // (wave-uniform) branch-free inside: a zero-sized descriptor (initial state) or an out-of-range offset reads 0.0
+        const __amdgpu_buffer_rsrc_t rc = vad_rsrc(p.c_prev ? p.c_prev + (size_t)n * cfs : p.c_out, p.c_prev ? (unsigned)cfs * 4u : 0u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+            cpv[r] = vad_bload1(rc, (y < H && x < W) ? (unsigned)(__mul24(__mul24(y, W) + x, hid) + hc) * 4u : VAD_OOB, 0);
+        }
+    }
+    f32x4 acc;
+    if (CELL && p.zx) {
+        const __amdgpu_buffer_rsrc_t rz = vad_rsrc(p.zx + (size_t)n * p.zx_fs, (unsigned)(H * W) * (unsigned)(4 * hid) * 4u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+            acc[r] = vad_bload1(rz, (y < H && x < W) ? (unsigned)(__mul24(__mul24(y, W) + x, 4 * hid) + g * hid + hc) * 4u : VAD_OOB, 0);
+        }
+    } else {
+        const float bv = p.bias[g * hid + hc];
+        acc = f32x4{bv, bv, bv, bv};
+    }
+
+    for (int ch = ch0; ch < nch; ++ch) {
+        __syncthreads();                               // every wave is done reading the previous chunk
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < TOT) *(f32x4*)&tile[(idx >> 3) * PS + (idx & 7) * 4] = pf[i];
+        }
+        __syncthreads();
+        if (ch + 1 < nch) issue(ch + 1);               // in flight during the 36 steps below
+
+        f32x2 a[2];
+        a[0] = *(const f32x2*)&tile[abase];
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {                 // (tap, 8-channel group) steps: same order as the other two kernels
+            const int cur = s & 1, nxt = cur ^ 1;
+            const int bcur = s % NB, bnxt = (s + PB) % NB;
+            if (s + 1 < 36) {
+                const int tap = (s + 1) >> 2;
+                a[nxt] = *(const f32x2*)&tile[abase + ((tap / 3) * LW + tap % 3) * PS + ((s + 1) & 3) * 8];
+            }
+            if (s + PB < 36) { GLOAD_B(bnxt, ch, s + PB); }
+            else if (ch + 1 < nch) { GLOAD_B(bnxt, ch + 1, s + PB - 36); }
+            __builtin_amdgcn_sched_barrier(0);         // keep the prefetch above this step's MFMAs
+            acc = MFMA16X4(a[cur][0], b[bcur][0], acc);                                            // channels 0,4,2,6
+            acc = MFMA16X4(a[cur][1], b[bcur][1], acc);                                            // channels 1,5,3,7
+        }
+    }
+#undef GLOAD_B
+
+    if (!CELL) {          // pre-activations [n][h][w][cout]
+        float* zo = p.out + (size_t)n * p.out_fs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+            if (y < H && x < W) zo[((size_t)y * W + x) * p.cout + g * hid + hc] = acc[r];
+        }
+        return;
+    }
+    // the gates of a cell meet: gates 1..3 through LDS to the wave of gate 0 with the same M-tile (same lane = same pixels, same hc)
+    if (g > 0) *(f32x4*)&zbuf[(((g - 1) * MTW + wm) * 64 + lane) * 4] = acc;
+    __syncthreads();
+    if (g > 0) return;
+    const f32x4 zf = *(const f32x4*)&zbuf[((0 * MTW + wm) * 64 + lane) * 4];
+    const f32x4 zg = *(const f32x4*)&zbuf[((1 * MTW + wm) * 64 + lane) * 4];
+    const f32x4 zo_ = *(const f32x4*)&zbuf[((2 * MTW + wm) * 64 + lane) * 4];
+    float* cout_ = p.c_out + (size_t)n * cfs;
+    float* hout = p.out + (size_t)n * p.out_fs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+        if (y < H && x < W) {
+            const size_t o = ((size_t)y * W + x) * hid + hc;
+            float cn, hn;
+            vad_lstm_cell(acc[r], zf[r], zg[r], zo_[r], cpv[r], cn, hn);
             cout_[o] = cn;
             hout[o] = hn;
         }
