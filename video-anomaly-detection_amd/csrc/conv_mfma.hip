@@ -570,6 +570,8 @@ int vad_conv3x3_c3_fused_fmt(const void* x, int fmt, const float* w0, const floa
     return VAD_OK;
 }
 
+bool vad_convlstm_gate_wins(int n, int h, int wd, int hid) { const ConvKnobs kn; return kn.variant != 0 && !kn.no_small && vad_gate_kernel_wins(n, h, wd, hid, kn) != 0; }
+
 // the cost model of vad_convlstm_step: does the small-grid (16x16x4) form serve n frames of h x w best?
 bool vad_convlstm_small_wins(int n, int h, int wd, int hid) {
     const long long nb_big = (long long)n * ((wd + 15) / 16) * ((h + 3) / 4) * (hid / 64);

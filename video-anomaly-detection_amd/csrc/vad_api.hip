@@ -377,13 +377,14 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         // the step kernel - bit-identical, and the serial K loop of a step halves (models/video_autoencoder.py:67-70 multiplies
         // cat([x, h]) inside the recurrence).
         const bool hoist = precision == VAD_PREC_FP32 && ZX[0] && vad_convlstm_hoist_ok();
+        bool hoist_upper = hoist;
         auto lstm_step = [&](int l, int ti, hipStream_t st) -> int {
             const float* xin_l = (l == 0) ? E : HS[l - 1];
             const long long fs_in = (l == 0) ? fs_lat : fs_hid;
             const long long clip_in = (l == 0) ? (long long)cs * fs_lat : (long long)t * fs_hid;   // layer 0 reads the shared features
             const long long clip_zx = (l == 0) ? (long long)cs * fs_zx : (long long)t * fs_zx;
             VadProfScope ps(4, st);
-            return vad_convlstm_step_zx(xin_l + (size_t)ti * fs_in, clip_in, hoist ? ZX[l] + (size_t)ti * fs_zx : nullptr, clip_zx,
+            return vad_convlstm_step_zx(xin_l + (size_t)ti * fs_in, clip_in, (hoist && (l == 0 || hoist_upper)) ? ZX[l] + (size_t)ti * fs_zx : nullptr, clip_zx,
                                         ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
                                         ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l),
                                         HS[l] + (size_t)ti * fs_hid, (long long)t * fs_hid, CS[l],
@@ -405,17 +406,21 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         const int wf = g_vad_lstm_wavefront.load(std::memory_order_relaxed);
         if (hoist) TRY(lstm_xhalf(0, -1, s));
         if (layers > 1 && ((lstm_groups < 256 && wf) || wf == 2)) {
+            // per-step x halves of the layers above 0 (a helper-stream launch and two event hops per step) pay while a step is a
+            // long serial K loop; with the gate-split kernel (one window: ~11 us per step) they cost more than they save - measured
+            // 0.78 -> 0.70 ms for one 16-frame window, 1.05 -> 0.97 for two clips - so those steps run their whole K loop
+            hoist_upper = hoist && !vad_convlstm_gate_wins(nc, h16, w16, hid);
             VadSideStreams* S = nullptr;
             TRY(side_streams(layers, &S));
             VAD_HIP_TRY(hipEventRecord(S->fork, s));                          // the encoder's output (and layer 0's x halves) are ready
             for (int l = 1; l < layers; ++l) {
                 VAD_HIP_TRY(hipStreamWaitEvent(S->st[l - 1], S->fork, 0));
-                if (hoist) VAD_HIP_TRY(hipStreamWaitEvent(S->xs[l - 1], S->fork, 0));
+                if (hoist_upper) VAD_HIP_TRY(hipStreamWaitEvent(S->xs[l - 1], S->fork, 0));
             }
             for (int ti = 0; ti < t; ++ti)
                 for (int l = 0; l < layers; ++l) {
                     hipStream_t st = l ? S->st[l - 1] : s;
-                    if (l && hoist) {                                                  // (l-1, ti) finished -> x half of (l, ti) -> step (l, ti)
+                    if (l && hoist_upper) {                                            // (l-1, ti) finished -> x half of (l, ti) -> step (l, ti)
                         hipStream_t xs = S->xs[l - 1];
                         VAD_HIP_TRY(hipStreamWaitEvent(xs, S->done[l - 1], 0));
                         TRY(lstm_xhalf(l, ti, xs));

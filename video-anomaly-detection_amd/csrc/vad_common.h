@@ -150,6 +150,7 @@ int vad_conv3x3_stats(const float* in, long long in_fs, const float* w, const fl
 int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs, int n, int h,
                       int wd, int cin, int cin_w, int cout, int act, int pool, int precision, float* stats, int* stats_rows, void* stream);
 bool vad_convlstm_small_wins(int n, int h, int wd, int hid);
+bool vad_convlstm_gate_wins(int n, int h, int wd, int hid);   // would a ConvLSTM step of n frames run the gate-split kernel?
 bool vad_convlstm_hoist_ok(void);
 int vad_convlstm_step_zx(const float* x, long long x_fs, const float* zx, long long zx_fs, const float* h_prev, long long h_prev_fs,
                          const float* c_prev, const float* w, const float* bias, float* h_out, long long h_out_fs,
