@@ -20,14 +20,20 @@
 //     s[dy][co] = sum_dx P[(dy,dx,co)][x+dx-1] into three running output rows held in registers: row y is complete when P
 //     rows y-1, y, y+1 have passed.  Tanh, error, optional recon / error-map stores and the per-row partial sum follow.
 //
-// SOFTWARE PIPELINE.  The combine of phase t-1 (LDS reads, 27 adds, tanh, error, row sum: ~250 VALU / LDS instructions) is
-// issued in the SAME instruction stream as the 64 MFMAs of phase t, one basic block, so that it runs in their shadow.
-// Leaving it to the second work-group of the CU does not work: a wave whose next instruction is an MFMA waiting for the
-// matrix pipe holds the SIMD's VALU issue, and the other wave's plain VALU instructions starve until the MFMA stream ends
-// (tools/ubench/mfma_valu_mix.hip: 12 k fmac next to 4 k back-to-back MFMAs finish 12 k x 5.3 clocks AFTER the MFMAs).
-// Everything in the block is branch-free: invalid rows / columns get a zero bias instead of a skipped GEMM (their P is
-// then exactly 0, the convolution's zero padding), loads use out-of-range offsets or clamped addresses, and only the final
-// stores sit under (uniform) conditions.  The pipeline runs across work items: one fill and one drain per work-group.
+// ONE PIPE.  An exact-fp32 MFMA and a VALU instruction never overlap (tools/ubench/mfma_valu_mix.hip: in one wave every
+// v_fmac behind a 32x32x2_f32 MFMA adds 5.5-7.5 clocks to its 64 - an fp16 MFMA hides four of them - and a second wave's
+// VALU stream next to a wave of back-to-back fp32 MFMAs makes no progress until they end).  So the second work-group of the
+// CU cannot hide the combine, and every VALU instruction of the row loop is matrix time: the loop issues ~110 of them next
+// to its 64 MFMAs (first form: ~330).  What that took: the column-record LDS layout above (16-byte accesses, no register
+// shuffles), zero padding by READING an all-zero column (P rows / columns outside the image are computed like any other and
+// never read: three address selects), the bias as the C operand of each chain's first MFMA, ReLU as one integer max per
+// value, all 32 ahead of GEMM 2, packed adds, a DPP row sum, buffer loads with scalar bases, the next input row loaded
+// straight into the registers GEMM 1 has just read.
+// SOFTWARE PIPELINE.  The combine of phase t-1 is issued between the GEMM-1 MFMAs of phase t (scheduling fences keep its
+// stages in place): its LDS latency and every wait pass while the matrix pipe works, one barrier per phase.  The block is
+// branch-free (loads use out-of-range offsets or clamped addresses, the partial-sum store an out-of-range offset when
+// there is nothing to store; only the optional map stores sit under a uniform condition) and the pipeline runs across
+// work items: one fill and one drain per work-group.
 //
 // Per 256x256 frame: 2 x 0.134 GFLOP on the fp32 matrix pipe (GEMM 2 pads 27 -> 32 rows; the unfused tail ran 0.113 GFLOP on
 // the VALU, the same pipe) and 2.1 MB + 0.79 MB read from HBM: bound by the exact-fp32 matrix pipe at ~1.8 us per frame.
