@@ -312,7 +312,9 @@ static int vad_gate_kernel_wins(int n, int h, int wd, int cq, const ConvKnobs& k
     if (kn.all_gate) return 2;                                                            // (debug: the 8-wave form everywhere)
     const int ncu = vad_num_cus();
     const long long nb1 = (long long)n * ((wd + 7) / 8) * ((h + 1) / 2) * (cq / 16);      // work-groups of 4 waves
-    if (nb1 <= 2ll * ncu) return 1;
+    // (measured per step, 16x16 map, hid 128, tools/gpu_lstm_variants.sh: 4 waves per work-group win or tie up to 6 work-groups
+    // per CU - 5 clips 44.8 -> 36.3 us, 10 clips 78.6 -> 62.8 - and lose at 8: 16 clips 88.6 -> 99.8)
+    if (nb1 <= 6ll * ncu) return 1;
     const long long nb2 = (long long)n * ((wd + 15) / 16) * ((h + 1) / 2) * (cq / 16);    // of 8 waves
     return 2 * nb2 <= 3ll * ncu ? 2 : 0;
 }
