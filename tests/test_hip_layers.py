@@ -52,6 +52,16 @@ def test_conv3x3(cin, cout, h, w, act, pool):
     ref = _ref_conv(x, wt, b, bn, act, pool)
     assert got.shape == ref.shape and np.isfinite(got).all()
     assert max_abs(got, ref) < ATOL
+    # Every exact-fp32 form of the layer is the same bits: whatever the cost model picked above, the persistent 32x32x2 kernels
+    # only (bit 6: never the gate-split small-grid kernel), the gate-split kernel wherever it applies (bit 7: 8-wave form; cin >= 64,
+    # cout % 64 == 0), and one tile per work-group (0).
+    l = H.hip.lib()
+    try:
+        for bits in (1 | 64, 1 | 128, 0):
+            l.vad_debug_set_conv_variant(bits)
+            assert np.array_equal(got, H.conv3x3(x, wt, b, bn, act, pool)), bits
+    finally:
+        l.vad_debug_set_conv_variant(1)
 
 
 @pytest.mark.parametrize("h,w", [(16, 16), (32, 48), (22, 18), (64, 64)])

@@ -489,14 +489,28 @@ int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const fl
     // order, bit-identical results).
     // The x half of a ConvLSTM step computed ahead of the recurrence (a channel sub-range of the cell's weights, no activation)
     // on the smallest grids: the gate-split kernel's K loop without the cell (conv_small.h), same values bit for bit.
-    const int mtw = (cin_w > cin && !pool && act == VAD_ACT_NONE && !with_stats && cout % 64 == 0 &&
-                     (long long)h * wd * cin * 4 < (1ll << 31) && 9ll * cin_w * cout * 4 < (1ll << 31)) ? vad_gate_kernel_wins(n, h, wd, cout / 4, kn) : 0;
+    // Gate-split small-grid kernel without the cell (conv_small.h; same values bit for bit): the x half of a ConvLSTM step
+    // computed ahead of the recurrence (a channel sub-range of the cell's weights), and - the reference's one-image / 16-image
+    // calls - any layer whose throughput tiling leaves CUs idle and whose K loop is long enough to pay for 4x the waves.
+    int mtw = 0;
+    if (!with_stats && cout % 64 == 0 && kn.variant != 0 && (long long)h * wd * cin * 4 < (1ll << 31) && 9ll * cin_w * cout * 4 < (1ll << 31)) {
+        if (cin_w > cin && !pool && act == VAD_ACT_NONE) mtw = vad_gate_kernel_wins(n, h, wd, cout / 4, kn);
+        else if (cin_w == cin && cin >= 64 && !kn.no_gate) {
+            const long long px = (long long)n * ((wd + 15) / 16);
+            const long long nb_thr = cout % 128 == 0 ? px * ((h + 7) / 8) * (cout / 128) : px * ((h + 15) / 16) * (cout / 64);
+            if (nb_thr < vad_num_cus() || kn.all_gate) mtw = vad_gate_kernel_wins(n, h, wd, cout / 4, kn);
+        }
+    }
     if (mtw) {
         p.hid = cout / 4;
         p.tiles_x = (wd + 8 * mtw - 1) / (8 * mtw); p.tiles_y = (h + 1) / 2; p.cblocks = p.hid / 16; p.n = n;
         p.nblocks = (unsigned)((long long)n * p.tiles_x * p.tiles_y * p.cblocks);
-        if (mtw == 1) hipLaunchKernelGGL((convlstm_gate_kernel<0, 1>), dim3(p.nblocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((convlstm_gate_kernel<0, 2>), dim3(p.nblocks), dim3(512), 0, s, p);
+#define GATE_LAUNCH(A_, P_)                                                                                                          \
+        { if (mtw == 1) hipLaunchKernelGGL((convlstm_gate_kernel<0, 1, A_, P_>), dim3(p.nblocks), dim3(256), 0, s, p);                \
+          else hipLaunchKernelGGL((convlstm_gate_kernel<0, 2, A_, P_>), dim3(p.nblocks), dim3(512), 0, s, p); }
+        if (pool) { if (act == VAD_ACT_LEAKY) GATE_LAUNCH(VAD_ACT_LEAKY, 1) else if (act == VAD_ACT_RELU) GATE_LAUNCH(VAD_ACT_RELU, 1) else GATE_LAUNCH(VAD_ACT_NONE, 1) }
+        else { if (act == VAD_ACT_LEAKY) GATE_LAUNCH(VAD_ACT_LEAKY, 0) else if (act == VAD_ACT_RELU) GATE_LAUNCH(VAD_ACT_RELU, 0) else GATE_LAUNCH(VAD_ACT_NONE, 0) }
+#undef GATE_LAUNCH
         VAD_LAUNCH_CHECK();
         return VAD_OK;
     }

@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256) void convlstm_small_kernel(Conv3P p) {
 // Bit-identical to both other forms: every accumulator chain runs the same k order from the same start value.
 // MTW = M-tiles (2 rows x 8 columns) per work-group: 4 MTW waves.  MTW = 1 doubles the work-groups once more - while they still
 // fit one per CU a wave has its SIMD's matrix pipe to itself (two waves of dependent 2-MFMA steps on one SIMD are pipe-bound).
-template <int CELL, int MTW>
+template <int CELL, int MTW, int ACT = VAD_ACT_NONE, int POOL = 0>
 __global__ __launch_bounds__(256 * MTW) void convlstm_gate_kernel(Conv3P p) {
+    static_assert(!CELL || (ACT == VAD_ACT_NONE && !POOL), "activation / pooling belong to the plain-convolution form");
     constexpr int NT = 256 * MTW, TW = 8 * MTW;
     constexpr int CK = 32, LH = 4, LW = TW + 2, PS = CK + 4, NPIX = LH * LW, TOT = NPIX * (CK / 4), NPF = (TOT + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float tile[NPIX * PS];
@@ -310,12 +311,22 @@ __global__ __launch_bounds__(256 * MTW) void convlstm_gate_kernel(Conv3P p) {
     }
 #undef GLOAD_B
 
-    if (!CELL) {          // pre-activations [n][h][w][cout]
+    if (!CELL) {          // [n][h][w][cout] (POOL: [n][h/2][w/2][cout]); ACT / POOL as the 32x32x2 kernels apply them
         float* zo = p.out + (size_t)n * p.out_fs;
+        if (POOL) {       // the lane's four registers are one 2x2 window (H, W even: host-checked); activation is monotonic: act(max) == max(act)
+            const int y = y0, x = x0 + 8 * wm + 2 * kq;
+            const float m = vad_act(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])), ACT);
+            if (y < H && x < W) zo[((size_t)(y >> 1) * (W >> 1) + (x >> 1)) * p.cout + g * hid + hc] = m;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
-            if (y < H && x < W) zo[((size_t)y * W + x) * p.cout + g * hid + hc] = acc[r];
+            for (int r = 0; r < 4; ++r) {
+                const int y = y0 + (r >> 1), x = x0 + 8 * wm + 2 * kq + (r & 1);
+                // plain fmaxf, not vad_act's inline-asm v_max: hipcc's hazard recogniser puts no wait states between an MFMA and an
+                // asm statement that reads its result (same values: maxNum of two non-NaN floats)
+                const float v = acc[r];
+                const float a_ = ACT == VAD_ACT_LEAKY ? fmaxf(v, 0.2f * v) : (ACT == VAD_ACT_RELU ? fmaxf(v, 0.f) : v);
+                if (y < H && x < W) zo[((size_t)y * W + x) * p.cout + g * hid + hc] = a_;
+            }
         }
         return;
     }
