@@ -461,13 +461,22 @@ int vad_dec4_score_fmt(const float* in, const float* wt_packed, const float* bt,
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dec4_score_kernel<false>, 256, D4_LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
         per_cu_cached = per_cu;
     }
-    // Band height: the y halo costs one input row per band end ((R + 1) / R of the matrix work), but the grid needs about
-    // two work-groups per CU.  The result does not depend on it (every output pixel's sums are ordered by pixel only).
-    const long long slots = (long long)d4_num_cus() * per_cu;
+    // Band height R: a band costs 2 R + 2 phases (the y halo is one input row per band end), and the work-groups of a CU share
+    // its matrix pipe - two of them only hide each other's waits (~10 %).  Pick the R with the least phases on the fullest CU.
+    // The result does not depend on it (every output pixel's sums are ordered by pixel only).
+    const long long ncu = d4_num_cus(), slots = ncu * per_cu;
     int R = g_vad_dec4_band.load(std::memory_order_relaxed);
     if (R <= 0) {
-        R = 16;
-        while (R > 1 && (long long)n * p.nstrips * ((h + R - 1) / R) < 2 * slots) R >>= 1;
+        double best = 0.0;
+        for (int r = 1;; r <<= 1) {
+            const int rr = r < h ? r : h;
+            const long long items_r = (long long)n * p.nstrips * ((h + rr - 1) / rr);
+            const long long grid_r = items_r < slots ? items_r : slots;
+            const long long per_wg = (items_r + grid_r - 1) / grid_r, wpc = (grid_r + ncu - 1) / ncu;
+            const double cost = (double)per_wg * (2 * rr + 2) * (double)wpc * (wpc > 1 ? 0.9 : 1.0);
+            if (R <= 0 || cost <= best) { best = cost; R = rr; }       // (ties: the taller band, less halo traffic)
+            if (r >= h) break;
+        }
     }
     if (R > h) R = h;
     p.R = R;
