@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-layer-events", action="store_true", help="do not bracket layers with hipEvents")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the secondary split-precision measurement")
+    ap.add_argument("--no-small", action="store_true", help="skip the secondary measurement of the reference's own call sizes")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (row f-1)")
     ap.add_argument("--graph", action="store_true", help="capture the step's scoring call into a hipGraph once and replay it every step (1 GPU, image / video)")
     ap.add_argument("--no-wavefront", action="store_true", help="video: ConvLSTM layers strictly one after the other (A/B of the small-batch wavefront)")
@@ -300,6 +301,10 @@ def main():
     # configs[2] beside it (1 GPU: the driver's N = 1 line then carries every single-GPU configuration)
     if rank == 0 and world == 1 and default_line and not args.no_video:
         out["video"] = video_config2(vad, hip, lib, dev, hw, args.steps, args.warmup, not args.no_cpu_baseline)
+    # The reference's own call sizes (main.py:274 one image, evaluate.py:240 16 images, evaluate_video.py:416 4 clips x 16 frames,
+    # :344 one 16-frame window), eager launches, per-layer events off.  Never part of `value`.
+    if rank == 0 and world == 1 and default_line and not args.no_small:
+        out["reference_call_sizes"] = reference_call_sizes(vad, lib, model, dev, hw, seed)
     # Secondary measurement (row f-1): the native training step of the ConvLSTM video autoencoder (train_video.py:44-65),
     # exact fp32, 32 clips x 10 frames at the bench resolution.  Never part of `value` / `roofline`.
     if rank == 0 and world == 1 and not args.no_train and args.workload == "image" and args.precision == "fp32":
@@ -569,6 +574,41 @@ def cpu_baseline(vad, state, kind, clip_len, gpu_scores, seed, hw):
     rel = float(((got - ref).abs() / ref.abs()).max())
     return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample,
             "gpu_vs_cpu_max_rel_score_err": rel}
+
+
+def reference_call_sizes(vad, lib, img_model, dev, hw, seed, steps=100, warmup=10):
+    """Latency / throughput of the batch sizes the reference's own scripts use: inputs resident in HBM,
+    `steps` calls back to back after `warmup`, one synchronise at the end."""
+    def timed(fn):
+        with torch.no_grad():
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps
+
+    lib.vad_prof_enable(0)
+    out = {}
+    frames = vad.scoring.synth_frames_device(seed + 5, 0, 16, hw, hw, device=dev)
+    for b, site in ((1, "main.py:274"), (16, "evaluate.py:240")):
+        x = frames[:b].contiguous()
+        dt = timed(lambda: img_model.get_reconstruction_error(x))
+        out[f"image_batch_{b}"] = {"ms": round(dt * 1e3, 4), "frames_per_sec": round(b / dt, 1), "call_site": site}
+    vm = vad.VideoAutoencoder(in_channels=3, latent_dim=128, lstm_hidden_dim=128, lstm_num_layers=2)
+    shapes = {k: tuple(v.shape) for k, v in vm.state_dict().items()}
+    vm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, 8).items()}, strict=True)
+    vm = vm.to(dev).eval()
+    clips = vad.scoring.synth_frames_device(seed + 6, 0, 4 * 16, hw, hw, device=dev).view(4, 16, 3, hw, hw)
+    for b, site in ((4, "evaluate_video.py:416"), (1, "evaluate_video.py:344 (one window)")):
+        x = clips[:b].contiguous()
+        dt = timed(lambda: vm.get_reconstruction_error(x, per_frame=True))
+        out[f"video_{b}x16"] = {"ms": round(dt * 1e3, 4), "frames_per_sec": round(b * 16 / dt, 1), "call_site": site}
+    del vm, clips, frames
+    torch.cuda.empty_cache()
+    return out
 
 
 def video_config2(vad, hip, lib, dev, hw, steps, warmup, with_cpu, clips=64, t=10):
