@@ -452,14 +452,16 @@ int vad_dec4_score_fmt(const float* in, const float* wt_packed, const float* bt,
     p.nstrips = d4_strips(w);
     p.dbg = g_d4_dbg;
     // 73 KB of LDS per work-group (two P buffers): above the 64 KB a kernel gets without asking
-    static std::atomic<int> per_cu_cached{0};
-    int per_cu = per_cu_cached.load(std::memory_order_relaxed);
+    static std::atomic<int> per_cu_cached[64];                            // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int per_cu = per_cu_cached[dev].load(std::memory_order_relaxed);
     if (!per_cu) {
         VAD_REQUIRE(hipFuncSetAttribute((const void*)dec4_score_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute((const void*)dec4_score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES) == hipSuccess,
                     "dec4_score: this device does not give a work-group %d bytes of LDS", D4_LDS_BYTES);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dec4_score_kernel<false>, 256, D4_LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
-        per_cu_cached = per_cu;
+        per_cu_cached[dev] = per_cu;
     }
     // Band height R: a band costs 2 R + 2 phases (the y halo is one input row per band end), and the work-groups of a CU share
     // its matrix pipe - two of them only hide each other's waits (~10 %).  Pick the R with the least phases on the fullest CU.
