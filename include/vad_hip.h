@@ -315,6 +315,9 @@ size_t vad_debug_train_decisions_used(void);
  * kernel (dword loads, 64 x 64 wave tiles) where cin and ncols are multiples of 64; 2 (default) = its LDS-staged work-group
  * form where ncols is a multiple of 128. */
 int vad_debug_set_wgrad_pairs(int on);
+/* 1 (default): the BatchNorm forward / backward-apply passes on bf16 tensors take eight channels per thread (16-byte accesses);
+ * 0: four, like the fp32 form.  Identical results (every element goes through the same expressions). */
+int vad_debug_set_bn_wide(int on);
 int vad_debug_set_train_stop(int stage);   /* debug: stop vad_vid_train_fwd_bwd after a backward stage (see csrc/train_step.hip) */
 int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent, int hid, int layers, long long* out, int cap);
 int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent, int hid, int layers,

@@ -39,9 +39,19 @@ def _nan32(*shape):
     return torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
 
 
+@pytest.mark.parametrize("wide", [1, 0])       # eight / four channels per thread in the bf16 forward and backward-apply passes
 @pytest.mark.parametrize("n,h,w,c,act,pool", [(3, 8, 12, 32, 1, 1), (2, 6, 6, 64, 2, 0), (5, 4, 4, 128, 1, 1), (4, 14, 14, 128, 2, 0),
                                               (4, 6, 10, 64, 1, 1), (16, 32, 32, 32, 1, 1)])
-def test_batchnorm_passes_on_bf16_tensors(vad, n, h, w, c, act, pool):
+def test_batchnorm_passes_on_bf16_tensors(vad, n, h, w, c, act, pool, wide):
+    l = vad.hip.lib()
+    l.vad_debug_set_bn_wide(wide)
+    try:
+        _batchnorm_passes_on_bf16_tensors(vad, n, h, w, c, act, pool)
+    finally:
+        l.vad_debug_set_bn_wide(1)
+
+
+def _batchnorm_passes_on_bf16_tensors(vad, n, h, w, c, act, pool):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(n * 100 + c + act)
     y16, y32 = _rep(rng.standard_normal((n, h, w, c)) * rng.uniform(0.5, 2, (1, 1, 1, c)) + rng.standard_normal((1, 1, 1, c)))

@@ -179,6 +179,60 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(BnFwdP p) {
     }
 }
 
+// bf16 tensors, EIGHT channels per thread (16-byte accesses: twice the bytes in flight per wave, half the index arithmetic);
+// every element goes through the same bn_apply as above: identical results.  c % 8 == 0, strides % 8 == 0 (host-checked).
+__device__ __forceinline__ void bf16_ld8(const vad_bf16* p, f32x4& a, f32x4& b) {
+    const u32x4 r = *(const u32x4*)p;
+    a = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+    b = f32x4{__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16), __uint_as_float(r[3] & 0xffff0000u)};
+}
+__device__ __forceinline__ void bf16_st8(vad_bf16* p, f32x4 a, f32x4 b) {
+    *(u32x4*)p = u32x4{vad_pack_bf16(a[0], a[1]), vad_pack_bf16(a[2], a[3]), vad_pack_bf16(b[0], b[1]), vad_pack_bf16(b[2], b[3])};
+}
+template <int POOL, int ACT>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd8_kernel(BnFwdP p) {
+    const int cg = p.c >> 3, oh = POOL ? p.h / 2 : p.h, ow = POOL ? p.w / 2 : p.w;
+    const unsigned total = (unsigned)(p.total >> 1), ucg = (unsigned)cg, uow = (unsigned)ow, uoh = (unsigned)oh;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned pix = idx / ucg, t_ = pix / uow, un = t_ / uoh;
+        const int c8 = (int)(idx - pix * ucg);
+        const int x = (int)(pix - t_ * uow);
+        const int y = (int)(t_ - un * uoh);
+        const int n = (int)un;
+        f32x4 mean[2], invstd[2], gamma[2], beta[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            mean[hf] = *(const f32x4*)&p.stats[8 * c8 + 4 * hf]; invstd[hf] = *(const f32x4*)&p.stats[p.c + 8 * c8 + 4 * hf];
+            gamma[hf] = *(const f32x4*)&p.gamma[8 * c8 + 4 * hf]; beta[hf] = *(const f32x4*)&p.beta[8 * c8 + 4 * hf];
+        }
+        const vad_bf16* src = (const vad_bf16*)p.y + (size_t)n * p.h * p.w * p.c + 8 * c8;
+        f32x4 v[2];
+        if constexpr (POOL) {
+            const size_t o = ((size_t)(2 * y) * p.w + 2 * x) * p.c;
+            f32x4 w0[2], w1[2], w2[2], w3[2];
+            bf16_ld8(&src[o], w0[0], w0[1]);
+            bf16_ld8(&src[o + p.c], w1[0], w1[1]);
+            bf16_ld8(&src[o + (size_t)p.w * p.c], w2[0], w2[1]);
+            bf16_ld8(&src[o + (size_t)p.w * p.c + p.c], w3[0], w3[1]);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                v[hf] = bn_apply(w0[hf], mean[hf], invstd[hf], gamma[hf], beta[hf], ACT);
+                const f32x4 v1 = bn_apply(w1[hf], mean[hf], invstd[hf], gamma[hf], beta[hf], ACT);
+                const f32x4 v2 = bn_apply(w2[hf], mean[hf], invstd[hf], gamma[hf], beta[hf], ACT);
+                const f32x4 v3 = bn_apply(w3[hf], mean[hf], invstd[hf], gamma[hf], beta[hf], ACT);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[hf][e] = fmaxf(fmaxf(v[hf][e], v1[e]), fmaxf(v2[e], v3[e]));
+            }
+        } else {
+            f32x4 w0[2];
+            bf16_ld8(&src[((size_t)y * p.w + x) * p.c], w0[0], w0[1]);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) v[hf] = bn_apply(w0[hf], mean[hf], invstd[hf], gamma[hf], beta[hf], ACT);
+        }
+        bf16_st8((vad_bf16*)p.out + view_frame(n, p.t, p.b) * p.out_fs + ((size_t)y * ow + x) * p.out_ps + 8 * c8, v[0], v[1]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm backward
 struct BnBwdP {     // y / dout / dy: fp32 or bf16 (the kernels' storage type)
     const void* y; const float* stats; const float* gamma; const float* beta;
@@ -302,6 +356,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdP p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < nwin) io::st(&pdy[off[k]], out[k]);
+        }
+    }
+}
+
+// pass B on bf16 tensors, eight channels per thread (see bn_act_pool_fwd8_kernel): the same bn_route / expressions per element
+template <int POOL, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(BnBwdP p) {
+    const vad_bf16* py = (const vad_bf16*)p.y;
+    const vad_bf16* pdout = (const vad_bf16*)p.dout;
+    vad_bf16* pdy = (vad_bf16*)p.dy;
+    const int cg = p.c >> 3, oh = POOL ? p.h / 2 : p.h, ow = POOL ? p.w / 2 : p.w; constexpr int nwin = POOL ? 4 : 1;
+    const unsigned total = (unsigned)(p.opix * cg), ucg = (unsigned)cg;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned q = idx / ucg, t_ = q / (unsigned)ow, un = t_ / (unsigned)oh;
+        const int c8 = (int)(idx - q * ucg);
+        const int x = (int)(q - t_ * (unsigned)ow), y = (int)(t_ - un * (unsigned)oh), n = (int)un;
+        f32x4 g[2];
+        bf16_ld8(&pdout[view_frame(n, p.t, p.b) * p.dout_fs + ((size_t)y * ow + x) * p.dout_ps + 8 * c8], g[0], g[1]);
+        const size_t fb = (size_t)n * p.h * p.w * p.c + 8 * c8;
+        const size_t o0 = fb + (POOL ? ((size_t)(2 * y) * p.w + 2 * x) : ((size_t)y * p.w + x)) * p.c;
+        const size_t off[4] = {o0, o0 + p.c, o0 + (size_t)p.w * p.c, o0 + (size_t)p.w * p.c + p.c};
+        f32x4 yv[4][2], out[4][2];
+        bf16_ld8(&py[off[0]], yv[0][0], yv[0][1]);
+        if constexpr (POOL) { bf16_ld8(&py[off[1]], yv[1][0], yv[1][1]); bf16_ld8(&py[off[2]], yv[2][0], yv[2][1]); bf16_ld8(&py[off[3]], yv[3][0], yv[3][1]); }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int c4 = 2 * c8 + hf;
+            const f32x4 mean = *(const f32x4*)&p.stats[4 * c4], invstd = *(const f32x4*)&p.stats[p.c + 4 * c4];
+            const f32x4 gamma = *(const f32x4*)&p.gamma[4 * c4], beta = *(const f32x4*)&p.beta[4 * c4];
+            const f32x4 k1 = *(const f32x4*)&p.k[4 * c4], k2 = *(const f32x4*)&p.k[p.c + 4 * c4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y4[4] = {yv[0][hf][e], yv[1][hf][e], yv[2][hf][e], yv[3][hf][e]};
+                const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[hf][e], ACT);
+                const float sc = gamma[e] * invstd[e];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nwin) {
+                        const float xh = bn_xhat(y4[k], mean[e], invstd[e]);
+                        out[k][hf][e] = sc * ((k == r.am ? r.gz : 0.f) - k1[e] - xh * k2[e]);
+                    }
+            }
+        }
+        if (p.s2d) {          // no-pool layers only (checked on the host): pixel (y, x) of an h x w map
+            const size_t o = (((size_t)n * (p.h / 2) + y / 2) * (p.w / 2) + x / 2) * 4 * p.c + ((y & 1) * 2 + (x & 1)) * p.c + 8 * c8;
+            bf16_st8(&pdy[o], out[0][0], out[0][1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nwin) bf16_st8(&pdy[off[k]], out[k][0], out[k][1]);
         }
     }
 }
@@ -1403,6 +1507,8 @@ extern "C" int vad_bn_act_pool_fwd(const float* y, const float* stats, const flo
     return vad_bn_act_pool_fwd_t(y, 0, stats, gamma, beta, out, out_fs, out_ps, remap_t, remap_b, n, h, w, c, act, pool, stream);
 }
 
+static std::atomic<int> g_bn_wide{1};     // debug / A-B: 0 = the bf16 BatchNorm passes at four channels per thread
+extern "C" int vad_debug_set_bn_wide(int on) { g_bn_wide = on; return VAD_OK; }
 int vad_bn_act_pool_fwd_t(const void* y, int io16, const float* stats, const float* gamma, const float* beta, void* out,
                           long long out_fs, int out_ps, int remap_t, int remap_b, int n, int h, int w, int c,
                           int act, int pool, void* stream) {
@@ -1433,6 +1539,18 @@ int vad_bn_act_pool_fwd_t(const void* y, int io16, const float* stats, const flo
             default: hipLaunchKernelGGL((KERNEL<float, 1, 2>), GRID, dim3(256), 0, STREAM, p); break;                      \
         }                                                                                                                  \
     }
+#define BN8_DISPATCH(KERNEL, GRID, STREAM)                                                                                  \
+    switch ((pool ? 3 : 0) + act) {                                                                                        \
+        case 0: hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(256), 0, STREAM, p); break;                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<0, 1>), GRID, dim3(256), 0, STREAM, p); break;                                  \
+        case 2: hipLaunchKernelGGL((KERNEL<0, 2>), GRID, dim3(256), 0, STREAM, p); break;                                  \
+        case 3: hipLaunchKernelGGL((KERNEL<1, 0>), GRID, dim3(256), 0, STREAM, p); break;                                  \
+        case 4: hipLaunchKernelGGL((KERNEL<1, 1>), GRID, dim3(256), 0, STREAM, p); break;                                  \
+        default: hipLaunchKernelGGL((KERNEL<1, 2>), GRID, dim3(256), 0, STREAM, p); break;                                 \
+    }
+    if (io16 && c % 8 == 0 && p.out_ps % 8 == 0 && p.out_fs % 8 == 0 && g_bn_wide.load(std::memory_order_relaxed)) {
+        BN8_DISPATCH(bn_act_pool_fwd8_kernel, dim3(grid_for(p.total / 2)), (hipStream_t)stream)
+    } else
     BN_DISPATCH(bn_act_pool_fwd_kernel, dim3(grid_for(p.total)), (hipStream_t)stream)
     VAD_LAUNCH_CHECK();
     return VAD_OK;
@@ -1490,8 +1608,12 @@ int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const flo
                        (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     p.dec = nullptr;
+    if (io16 && c % 8 == 0 && p.dout_ps % 8 == 0 && p.dout_fs % 8 == 0 && g_bn_wide.load(std::memory_order_relaxed)) {
+        BN8_DISPATCH(bn_bwd_apply8_kernel, dim3(grid_for(p.opix * (c / 8))), s)
+    } else
     BN_DISPATCH(bn_bwd_apply_kernel, dim3(grid_for(p.opix * (c / 4))), s)
 #undef BN_DISPATCH
+#undef BN8_DISPATCH
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
