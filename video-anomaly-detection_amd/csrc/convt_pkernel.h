@@ -197,24 +197,31 @@ __global__ __launch_bounds__(256, (MT * NT * (PREC == 1 ? 2 : 1) <= 4) ? 4 : 2) 
             const unsigned vlane = (unsigned)(__mul24(sc * 4 * lh, p.cout) + co[nt]) * ES;
             const unsigned ubase = ((unsigned)__mul24(sc * y0 + qa, ow) + (unsigned)(sc * x0 + qb)) * ecol;
             float ts = 0.f, tq = 0.f;
+            // ONE uniform branch per N-tile, not one per element: interior tiles (nearly all) store through the lane offset as it
+            // is - a ReLU and a store with a scalar offset per element, nothing else on the pipe the fp32 MFMAs use (with the test
+            // inside the loop hipcc emitted a branch, a compare and a select around every store)
+            auto store_tile = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dy = 2 * mt + (r >> 3), dx = (r & 3) + 8 * ((r >> 2) & 1);      // + 4*lh in the lane part
-                    const bool ok = full || ((y0 + dy) < H && (x0 + dx + 4 * lh) < W);
-                    const unsigned so = ubase + (unsigned)(sc * dy) * erow + (unsigned)(sc * dx) * ecol;
-                    if constexpr (IO16) vad_bstore_h(vad_f_bf16(vad_act(acc[mt][nt][r], ACT)), ro, ok ? vlane : VAD_OOB, so);
-                    else vad_bstore1(vad_act(acc[mt][nt][r], ACT), ro, ok ? vlane : VAD_OOB, so);
-                    if constexpr (STATS) {
-                        if (p.stats) {   // (uniform)
-                            const float d = ok ? acc[mt][nt][r] - bvv[nt] : 0.f;
-                            ts += d;
-                            tq = fmaf(d, d, tq);
+                    for (int r = 0; r < 16; ++r) {
+                        const int dy = 2 * mt + (r >> 3), dx = (r & 3) + 8 * ((r >> 2) & 1);      // + 4*lh in the lane part
+                        const bool ok = FULL || ((y0 + dy) < H && (x0 + dx + 4 * lh) < W);
+                        const unsigned so = ubase + (unsigned)(sc * dy) * erow + (unsigned)(sc * dx) * ecol;
+                        if constexpr (IO16) vad_bstore_h(vad_f_bf16(vad_act(acc[mt][nt][r], ACT)), ro, ok ? vlane : VAD_OOB, so);
+                        else vad_bstore1(vad_act(acc[mt][nt][r], ACT), ro, ok ? vlane : VAD_OOB, so);
+                        if constexpr (STATS) {
+                            if (p.stats) {   // (uniform)
+                                const float d = ok ? acc[mt][nt][r] - bvv[nt] : 0.f;
+                                ts += d;
+                                tq = fmaf(d, d, tq);
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (full) store_tile(std::true_type{}); else store_tile(std::false_type{});
             if constexpr (STATS) {
                 const int ct = (ng * NT + nt) % ctiles;                                   // wave-uniform
                 if (ct == 0) { st_s[0] += ts; st_q[0] += tq; }
