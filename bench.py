@@ -298,6 +298,21 @@ def main():
                          "config": {"workload": f"configs[3]: {stream_frames}-frame synthetic {hw}x{hw}x3 stream, block-partitioned over {world} rank(s), "
                                                 "generated on the device in chunks of 512, one all_gather of the score vector at the end"},
                          "includes": "on-device frame generation, scoring, one all_gather", "checksum": float(sv.double().sum())}
+        if rank == 0 and not args.no_cpu_baseline:
+            # the GATHERED stream vector against the CPU oracle on one frame out of every rank's block (its first, a middle
+            # one, or - last rank - the stream's very last frame): a wrong block, a wrong order or a lost tail fails here
+            from oracle import torch_oracle
+            torch.set_num_threads(host_cores())
+            per = -(-stream_frames // world)
+            picks = sorted({min(stream_frames - 1, r * per + (0 if r == 0 else per // 2)) for r in range(world)} | {stream_frames - 1})
+            xs = torch.from_numpy(np.concatenate([vad.synth.frames(seed + 2, i, 1, 3, hw, hw) for i in picks]))
+            with torch.no_grad():
+                ref = torch_oracle.img_scores(state, xs)["scores"]
+            rel = float(((sv[picks].cpu() - ref).abs() / ref.abs()).max())
+            out["stream"]["parity"] = {"checked_frames": picks, "oracle": "oracle/torch_oracle.py on rank 0's host cores",
+                                       "max_rel_score_err_vs_cpu": rel, "within_1e-4": bool(rel < 1e-4)}
+            if not rel < 1e-4:
+                raise SystemExit(f"stream parity check failed: scores differ from the CPU oracle by {rel:.3e} on frames {picks}")
     # configs[2] beside it (1 GPU: the driver's N = 1 line then carries every single-GPU configuration)
     if rank == 0 and world == 1 and default_line and not args.no_video:
         out["video"] = video_config2(vad, hip, lib, dev, hw, args.steps, args.warmup, not args.no_cpu_baseline)
@@ -362,11 +377,20 @@ def layers_and_roofline(hip, lib, kind, hw, per_gpu, steps, t, stride, default_s
     ach = mf_flop / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
     # (tools/pmc_traffic.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); only valid for the default shape.
+    # The file records the sha256 of the kernel sources it was measured on (hip.source_digest): when a kernel has changed
+    # since, the figure is stale and `traffic` is null with the reason - never a number from other code.
     traffic, traffic_source = None, None
     pmcs = sorted((REPO / "profiles").glob(f"r*_pmc_traffic_{kind}.json"))     # newest round last
     if pmcs and default_shape:
-        traffic = round(json.loads(pmcs[-1].read_text())["traffic_bytes_per_launch"])
-        traffic_source = f"profiles/{pmcs[-1].name} (separate rocprofv3 --pmc passes of this command, not this run)"
+        rec = json.loads(pmcs[-1].read_text())
+        if rec.get("source_sha256") == hip.source_digest():
+            traffic = round(rec["traffic_bytes_per_launch"])
+            traffic_source = f"profiles/{pmcs[-1].name} (separate rocprofv3 --pmc passes of this command on these kernel sources, not this run)"
+        else:
+            traffic_source = (f"null: profiles/{pmcs[-1].name} was measured on other kernel sources (its source_sha256 "
+                              f"{str(rec.get('source_sha256'))[:12]} != {hip.source_digest()[:12]}); re-run tools/pmc_traffic.sh")
+    elif not default_shape:
+        traffic_source = "null: the committed counter passes cover the default shape only"
     roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_pkernel (fp32 32x32x2 MFMA; all launches)",
                 "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -15,7 +15,10 @@
 extern "C" {
 #endif
 
-#define VAD_ABI_VERSION 2   /* 2: the arithmetic mode is an argument of every packer / launcher; no process-wide switch */
+#define VAD_ABI_VERSION 3   /* 2: the arithmetic mode is an argument of every packer / launcher; no process-wide switch.
+                             * 3: packed-blob layout of round 3 (tail slot carries the GEMM form the fused dec4 kernel reads, dec4.0 is fp32 in
+                             *    every blob, latent / hidden widths zero-padded to the channel tiling): blobs and libraries of ABI 2 are
+                             *    rejected by vad_blob_precision and by the device-side tag check */
 #define VAD_OK 0
 #define VAD_ERR_ARG (-1)   /* bad argument / unsupported shape */
 #define VAD_ERR_HIP (-2)   /* HIP runtime error */

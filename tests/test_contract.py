@@ -144,6 +144,26 @@ def test_inference_has_no_cpu_fallback(vad):
         v(torch.zeros(1, 2, 3, 32, 32))
 
 
+def test_input_contract_is_checked_before_anything_is_packed(vad):
+    """Shape, dtype and the uint8 / in_channels combination are rejected at the top of every inference entry point
+    (capture included) - before weights are packed or uploaded - and the message names only formats the model accepts."""
+    m1 = vad.ConvAutoencoder(in_channels=1, latent_dim=24).eval()
+    v2 = vad.VideoAutoencoder(in_channels=2, latent_dim=32, lstm_hidden_dim=40).eval()
+    with torch.no_grad():
+        with pytest.raises(vad.hip.VadError, match="uint8 input needs in_channels == 3") as e:
+            m1.get_reconstruction_error(torch.zeros(2, 32, 32, 1, dtype=torch.uint8))
+        assert "uint8 input [" not in str(e.value).split("expected", 1)[1]      # no uint8 form advertised for this model
+        with pytest.raises(vad.hip.VadError, match="uint8 input needs in_channels == 3"):
+            m1.capture(torch.zeros(2, 32, 32, 1, dtype=torch.uint8))
+        with pytest.raises(vad.hip.VadError, match="uint8 frames needs in_channels == 3"):
+            v2.score_windows(torch.zeros(9, 32, 32, 2, dtype=torch.uint8), sequence_length=4)
+        with pytest.raises(vad.hip.VadError, match=r"expected float input \[B,T,2,H,W\], got"):
+            v2.get_reconstruction_error(torch.zeros(1, 3, 3, 32, 32))
+        with pytest.raises(vad.hip.VadError, match=r"expected float input \[B,3,H,W\] or uint8 input \[B,H,W,3\]"):
+            vad.ConvAutoencoder(latent_dim=32).eval().get_reconstruction_error(torch.zeros(1, 1, 32, 32))
+    assert m1._hip.packed is None and v2._hip.packed is None
+
+
 def test_losses_match_reference(vad, golden):
     g = golden("losses.npz")
     x = torch.from_numpy(vad.synth.frames(77, 0, 2, 3, 32, 32))
@@ -169,7 +189,7 @@ def test_library_exports_every_declared_symbol(vad):
         assert hasattr(lib, name), f"{name} declared in include/vad_hip.h but not exported"
         assert name in vad.hip.SIGNATURES, f"{name} has no ctypes signature in hip.py"
     assert set(vad.hip.SIGNATURES) == set(declared)
-    assert lib.vad_abi_version() == vad.hip.ABI_VERSION == 2
+    assert lib.vad_abi_version() == vad.hip.ABI_VERSION == 3
 
 
 def test_argument_errors_without_gpu(vad):

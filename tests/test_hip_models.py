@@ -181,6 +181,35 @@ def test_clip_loop_matches_reference_golden(vad, golden):
     assert vad.scoring.roc_auc(lab, seq) == vad.scoring.roc_auc(g["labels"], g["seq_scores"])
 
 
+def test_image_config1_full_size_vs_oracle(vad):
+    """BASELINE configs[1] at its stated size - 512 frames x 256x256 in ONE launch group of 512 (the persistent grids, frame
+    strides and tile variants the headline benchmark runs, evaluate.py:56-64 at the bench's batch): frames 0 / 255 / 511
+    against the CPU oracle at 1e-5, and bit-equality with the same frames scored alone (a launch group of 1: the latency
+    tilings and the gate-split kernel forms)."""
+    m, st = _img_model(vad, 256, 7)
+    assert int(m.chunk) == 512
+    seed = 0xC0FFEE + 1
+    x = vad.scoring.synth_frames_device(seed, 0, 512)
+    idx = [0, 255, 511]
+    with torch.no_grad():
+        scores = m.get_reconstruction_error(x)
+        alone = [m.get_reconstruction_error(x[i:i + 1]) for i in idx]
+        emap = m.get_reconstruction_error(x[idx], per_pixel=True)
+    assert scores.shape == (512,) and bool(torch.isfinite(scores).all())
+    for i, a in zip(idx, alone):
+        assert torch.equal(a, scores[i:i + 1]), i
+    xs = torch.from_numpy(np.concatenate([vad.synth.frames(seed, i, 1, 3, 256, 256) for i in idx]))
+    assert torch.equal(xs, x[idx].cpu())                           # device generator == numpy generator
+    torch.set_num_threads(16)
+    ref = torch_oracle.img_scores({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, xs)
+    assert rel_err(scores[idx].cpu().numpy(), ref["scores"].numpy()) < SCORE_RTOL
+    assert max_abs(emap.cpu().numpy(), ref["errmap"].numpy()) < ACT_ATOL
+    # size-independent property at the full size: the score vector of the batch in reverse order is the reverse, bit for bit
+    with torch.no_grad():
+        rev = m.get_reconstruction_error(x.flip(0).contiguous())
+    assert torch.equal(rev.flip(0), scores)
+
+
 def test_video_config2_full_size_vs_oracle(vad):
     """BASELINE configs[2] at its stated size - 64 clips x 10 frames x 256x256, default model, one launch group of 64
     clips (the grids and tile variants the benchmark runs): first / middle / last clip against the CPU oracle at 1e-5,
@@ -415,6 +444,67 @@ def test_captured_graph_replays_bit_identically(vad):
                 for k in ("seq", "frame", "recon"):
                     assert torch.equal(got[k], want[k]), (b, t, k)
     torch.cuda.synchronize()
+
+
+def test_one_and_two_channel_models_capture_latent_and_windows(vad, golden):
+    """1- and 2-channel models (models/autoencoder.py:161, models/video_autoencoder.py:290 take any in_channels) through the
+    entry points the per-call narrowing does not cover by itself: hipGraph capture / replay (the captured kernels work on 3
+    planes: the input buffer is widened once outside the capture, the outputs are narrowed and rescaled after each replay),
+    `get_latent`, and `score_windows`.  Every result equals the eager call or the reference's golden values."""
+    g = golden("img_c1_l24_32.npz")
+    mi, _ = _img_model(vad, int(g["latent_dim"]), int(g["wseed"]), 1)
+    n, hw = int(g["n"]), int(g["hw"])
+    xa = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, n, 1, hw, hw)).cuda()
+    xb = torch.from_numpy(vad.synth.frames(int(g["xseed"]) + 1, 0, n, 1, hw, hw)).cuda()
+    with torch.no_grad():
+        cap = mi.capture(xa, scores=True, errmap=True, recon=True, latent=True)
+        ea, eb = mi.score_all(xa), mi.score_all(xb)
+        lat_b = mi.get_latent(xb)
+        for _ in range(2):
+            ob = cap.replay(xb)
+            assert ob["recon"].shape == xb.shape and ob["errmap"].shape == (n, 1, hw, hw)
+            for k in ("scores", "errmap", "recon"):
+                assert torch.equal(ob[k], eb[k]), k
+            assert torch.equal(ob["latent"], lat_b)
+        oa = cap.replay(xa)
+        assert torch.equal(oa["scores"], ea["scores"]) and not torch.equal(ea["scores"], eb["scores"])
+    assert rel_err(oa["scores"].cpu().numpy(), g["scores"]) < SCORE_RTOL            # the reference's own scores, through a replay
+    assert max_abs(oa["recon"].cpu().numpy(), g["recon"]) < ACT_ATOL
+
+    gv = golden("vid_c2_l32_h40_32.npz")
+    mv, stv = _vid_model(vad, int(gv["latent_dim"]), int(gv["hid"]), int(gv["layers"]), int(gv["wseed"]), 2)
+    b, t, hw = int(gv["b"]), int(gv["t"]), int(gv["hw"])
+    ca = torch.from_numpy(vad.synth.clips(int(gv["xseed"]), 0, b, t, 2, hw, hw)).cuda()
+    cb = torch.from_numpy(vad.synth.clips(int(gv["xseed"]) + 1, 0, b, t, 2, hw, hw)).cuda()
+    with torch.no_grad():
+        cap = mv.capture(ca, seq=True, frame=True, errmap=True, recon=True)
+        wa, wb = mv.score_all(ca), mv.score_all(cb)
+        for _ in range(2):
+            ob = cap.replay(cb)
+            assert ob["recon"].shape == cb.shape
+            for k in ("seq", "frame", "errmap", "recon"):
+                assert torch.equal(ob[k], wb[k]), k
+        oa = cap.replay(ca)
+    assert rel_err(oa["frame"].cpu().numpy(), gv["frame"]) < SCORE_RTOL
+    assert max_abs(oa["recon"].cpu().numpy(), gv["recon"]) < ACT_ATOL
+    # dense windows over one 2-channel video == every window scored as its own clip
+    frames = torch.from_numpy(vad.synth.frames(77, 0, 9, 2, hw, hw)).cuda()
+    tw = 4
+    with torch.no_grad():
+        dense = mv.score_windows(frames, sequence_length=tw, stride=1, errmap=True, recon=True)
+        clips = torch.stack([frames[k:k + tw] for k in range(9 - tw + 1)])
+        each = mv.score_all(clips)
+    assert dense["recon"].shape == clips.shape
+    for k in ("seq", "frame", "errmap", "recon"):
+        assert torch.equal(dense[k], each[k]), k
+    ref = torch_oracle.vid_scores({k: torch.from_numpy(np.asarray(v)) for k, v in stv.items()}, frames[:tw][None].cpu(),
+                                  int(gv["hid"]), int(gv["layers"]))
+    assert rel_err(dense["frame"][0].cpu().numpy(), ref["frame"][0].numpy()) < SCORE_RTOL
+    # uint8 frames are offered for 3-channel models only, and say so before anything is packed
+    with torch.no_grad(), pytest.raises(vad.hip.VadError, match="uint8 .* needs in_channels == 3"):
+        mv.score_windows(torch.zeros(9, hw, hw, 2, dtype=torch.uint8).cuda(), sequence_length=tw)
+    with torch.no_grad(), pytest.raises(vad.hip.VadError, match="uint8 .* needs in_channels == 3"):
+        mi.get_reconstruction_error(torch.zeros(2, hw, hw, 1, dtype=torch.uint8).cuda())
 
 
 def test_blob_launched_under_the_wrong_precision_is_rejected_on_the_device(vad):

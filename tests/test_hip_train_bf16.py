@@ -258,3 +258,24 @@ def test_lstm_gates_on_bf16_tensors(vad, nb, hw, hid, first):
                                              dcn.data_ptr(), dz.data_ptr(), dcp.data_ptr(), nb, hw, hid, H.stream()))
         outs[io] = (dz, dcp)
     assert torch.equal(outs[1][0], outs[0][0].to(torch.bfloat16)) and torch.equal(outs[1][1], outs[0][1])
+
+
+def test_bf16_tensor_step_is_refused_before_its_first_launch_without_the_statistics_kernels(vad):
+    """The bf16-tensor step has no stand-alone statistics pass: it needs the convolutions' own BatchNorm partial sums.  With the
+    persistent kernels switched off (`vad_debug_set_conv_variant` bit 0 cleared) the step must be refused BEFORE anything is
+    launched - parameters, gradients and running statistics untouched - not abort half way through its launch sequence."""
+    m = vad.VideoAutoencoder(latent_dim=32, lstm_hidden_dim=32, lstm_num_layers=1).cuda()
+    tr = vad.VideoTrainer(m, precision="bf16")
+    x = vad.scoring.synth_frames_device(3, 0, 4, 32, 32).view(2, 2, 3, 32, 32)
+    flat, grad, running = tr.flat.clone(), tr.grad.clone(), tr.running.clone()
+    l = vad.hip.lib()
+    try:
+        l.vad_debug_set_conv_variant(0)
+        with pytest.raises(vad.hip.VadError, match="BatchNorm partial sums"):
+            tr.forward_backward(x)
+    finally:
+        l.vad_debug_set_conv_variant(1)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.flat, flat) and torch.equal(tr.grad, grad) and torch.equal(tr.running, running)
+    loss, _ = tr.forward_backward(x)                     # and the same trainer steps normally afterwards
+    assert torch.isfinite(loss)

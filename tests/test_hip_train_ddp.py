@@ -94,23 +94,38 @@ def _rank(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_with_averaged_gradients(vad, tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_equal_one_process_with_averaged_gradients(vad, tmp_path, world):
+    """World 2: bit-equal to one process that sums the two halves' gradients (a two-term sum has one order).  World 4 (one
+    clip per rank; the most ranks a GPU box admits beside the test session): every rank ends bit-identical to every other,
+    and equal to the one-process result up to the summation order of the four-term all-reduce (1e-6 of the largest entry)."""
     mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
-    assert np.array_equal(p0, p1), "ranks diverged"
+    p0 = np.load(tmp_path / "p0.npy")
+    for r in range(1, world):
+        assert np.array_equal(p0, np.load(tmp_path / f"p{r}.npy")), f"rank {r} diverged from rank 0"
     # one process: per-half gradients from two replicas, averaged, one optimiser step; twice
     x = _clips(vad).cuda()
     per = CFG["b"] // world
     reps = [vad.VideoTrainer(_build(vad), lr=CFG["lr"], weight_decay=CFG["wd"]) for _ in range(world)]
     for _ in range(2):
         losses = [float(tr.forward_backward(x[r * per:(r + 1) * per])[0]) for r, tr in enumerate(reps)]
-        total = reps[0].grad + reps[1].grad
+        total = reps[0].grad.clone()
+        for tr in reps[1:]:
+            total += tr.grad
         for tr in reps:
             tr.grad.copy_(total)
             tr.optimizer_step(1.0 / world)
-    assert np.array_equal(reps[0].flat.cpu().numpy(), p0), f"max diff {np.abs(reps[0].flat.cpu().numpy() - p0).max():.3e}"
+    one = reps[0].flat.cpu().numpy()
+    if world == 2:
+        assert np.array_equal(one, p0), f"max diff {np.abs(one - p0).max():.3e}"
+    else:
+        assert np.abs(one - p0).max() < 1e-6 * np.abs(one).max(), f"max diff {np.abs(one - p0).max():.3e}"
     for r in range(world):
-        assert abs(np.load(tmp_path / f"l{r}.npy")[-1] - losses[r]) < 1e-7 * losses[r]
-        assert np.array_equal(np.load(tmp_path / f"s{r}.npy"), reps[r].running.cpu().numpy())      # per-rank BatchNorm statistics
+        srun, want = np.load(tmp_path / f"s{r}.npy"), reps[r].running.cpu().numpy()                 # per-rank BatchNorm statistics
+        if world == 2:
+            assert abs(np.load(tmp_path / f"l{r}.npy")[-1] - losses[r]) < 1e-7 * losses[r]
+            assert np.array_equal(srun, want)
+        else:     # the second step starts from parameters that differ in the last bits (summation order of the first all-reduce)
+            assert abs(np.load(tmp_path / f"l{r}.npy")[-1] - losses[r]) < 1e-5 * losses[r]
+            assert np.allclose(srun, want, rtol=1e-4, atol=1e-6)
     assert not np.array_equal(np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy"))

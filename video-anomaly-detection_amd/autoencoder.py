@@ -130,6 +130,23 @@ class _HipScorer:
         return params
 
     @staticmethod
+    def check_input(x: torch.Tensor, ndim: int, in_channels: int, what: str = "input") -> None:
+        """Shape / dtype / device contract of a scoring call, checked BEFORE anything is packed or uploaded.  Float input
+        is [..., C, H, W]; uint8 input [..., H, W, C] is offered for 3-channel models only (see `widen_input`)."""
+        lead = "B," if ndim == 4 else "B,T,"
+        if what != "input":
+            lead = "F,"
+        u8 = x.dtype == torch.uint8
+        forms = f"float {what} [{lead}{in_channels},H,W]" + (f" or uint8 {what} [{lead}H,W,3]" if in_channels == 3 else "")
+        if u8 and in_channels != 3:
+            raise hip.VadError(f"uint8 {what} needs in_channels == 3 (this model has {in_channels}): expected {forms}")
+        if x.dim() != ndim or (x.shape[-1] if u8 else x.shape[-3]) != in_channels:
+            raise hip.VadError(f"expected {forms}, got {x.dtype} {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise hip.VadError("inference runs only on the MI355X HIP path: move the model and input to 'cuda' "
+                               "(there is no CPU fallback)")
+
+    @staticmethod
     def widen_input(x: torch.Tensor, in_channels: int, u8: bool) -> torch.Tensor:
         """Zero planes appended to a 1- or 2-channel input (channel axis: last for uint8 NHWC, -3 for float NCHW)."""
         if in_channels == 3:
@@ -231,20 +248,25 @@ class ConvAutoencoder(nn.Module):
         if not self._use_hip():
             raise hip.VadError("capture is an inference entry point: call under eval() and torch.no_grad()")
         want = dict(scores=scores, errmap=errmap, recon=recon, latent=latent)
-        xs = x.clone()
-        eager = self._run_hip(xs, **want)                 # packs weights, sizes the workspace, creates helper state
+        _HipScorer.check_input(x, 4, self.in_channels)
+        # the captured kernels read and write 3 planes: a 1- / 2-channel batch is widened ONCE, outside the capture, into the
+        # persistent buffer the graph reads (`replay(x)` copies into its first planes); the outputs are captured at kernel
+        # shape and narrowed / rescaled after every replay.  (Widening inside the capture would record a `torch.cat` into
+        # a temporary that is freed when the capture ends.)
+        xs3 = _HipScorer.widen_input(x.contiguous() if x.dtype == torch.uint8 else x.contiguous().float(), self.in_channels,
+                                     x.dtype == torch.uint8).clone()
+        eager = self._run_hip(xs3, prewidened=True, **want)   # packs weights, sizes the workspace, creates helper state
         out = {k: torch.empty_like(v) for k, v in eager.items()}
-        return hip.CapturedCall(lambda: self._run_hip(xs, out=out, **want), xs, out, keep=(self._hip.packed, self._hip.ws))
+        view = xs3 if self.in_channels == 3 else xs3[:, :self.in_channels]
+        return hip.CapturedCall(lambda: self._run_hip(xs3, out=out, prewidened=True, **want), view, out,
+                                keep=(self._hip.packed, self._hip.ws, xs3),
+                                post=None if self.in_channels == 3 else self._narrow_outputs)
 
-    def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False, out=None):
+    def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False, out=None, prewidened=False):
+        """`prewidened` (captured calls): `x` already has the kernels' 3 planes and the outputs stay at kernel shape."""
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,H,W,3]: normalised inside the kernels (row f-3)
-        cin = self.in_channels
-        if x.dim() != 4 or (x.shape[3] if u8 else x.shape[1]) != cin:
-            raise hip.VadError(f"expected float input [B,{cin},H,W] or uint8 input [B,H,W,{cin}], got {x.dtype} {tuple(x.shape)}")
-        if not x.is_cuda:
-            raise hip.VadError(
-                "ConvAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
-                "'cuda' (there is no CPU fallback)")
+        cin = 3 if prewidened else self.in_channels
+        _HipScorer.check_input(x, 4, cin)
         if u8:
             b, h, w, _ = x.shape
             x = x.contiguous()
@@ -279,13 +301,20 @@ class ConvAutoencoder(nn.Module):
                                         hip.ptr(out.get("recon")), hip.ptr(out.get("latent")), hip.current_stream()),
                       "vad_img_score")
         hip.calls["img_score"] += 1
-        if cin != 3:          # the kernels averaged over 3 planes of which 3 - cin are exactly zero
-            out = dict(out)
-            for k in ("scores", "errmap"):
-                if k in out:
-                    out[k] = out[k] * (3.0 / cin)
-            if "recon" in out:
-                out["recon"] = out["recon"][:, :cin].contiguous()
+        return out if prewidened else self._narrow_outputs(out)
+
+    def _narrow_outputs(self, out: dict) -> dict:
+        """Undo the 3-plane view of a 1- / 2-channel model (`_HipScorer.widen_to_rgb`): the kernels averaged over 3
+        planes of which 3 - in_channels are exactly zero."""
+        cin = self.in_channels
+        if cin == 3:
+            return out
+        out = dict(out)
+        for k in ("scores", "errmap"):
+            if k in out:
+                out[k] = out[k] * (3.0 / cin)
+        if "recon" in out:
+            out["recon"] = out["recon"][:, :cin].contiguous()
         return out
 
     # ------------------------------------------------------------------ reference API

@@ -277,6 +277,9 @@ static std::atomic<int> g_vad_conv_bits{1};   // bit 0: 1 = persistent + registe
                                               // bit 5: never compute the ConvLSTM x halves ahead of the recurrence;
                                               // bit 6: never use the gate-split small-grid kernel; bit 7: use its 8-wave form wherever the small-grid form runs
 extern "C" int vad_debug_set_conv_variant(int v) { g_vad_conv_bits = v & 255; return VAD_OK; }
+// do un-activated convolution launches return their own BatchNorm partial sums (the persistent kernels' statistics
+// instantiations)?  The bf16-tensor training step has no other source of statistics and asks BEFORE its first launch.
+bool vad_conv_stats_available(void) { return (g_vad_conv_bits.load(std::memory_order_relaxed) & 1) != 0; }
 // may the model-level launch sequence split the ConvLSTM steps of small launch groups into x halves (ahead) + h halves?
 bool vad_convlstm_hoist_ok(void) {
     const int b = g_vad_conv_bits.load(std::memory_order_relaxed);

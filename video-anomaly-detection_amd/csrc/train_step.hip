@@ -243,6 +243,12 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
                 "latent and hidden multiples of 32, hidden <= 256, 1..8 layers", b, t, h, w, latent, hid, layers);
     if (workspace_bytes < p.ws_floats * sizeof(float))
         return vad_fail(VAD_ERR_WS, "vid_train_fwd_bwd: workspace %zu bytes < %zu needed", workspace_bytes, p.ws_floats * sizeof(float));
+    // bf16 tensors: the BatchNorm statistics come from the convolutions' accumulators and from nowhere else (there is no
+    // bf16 form of the stand-alone statistics pass).  Say so BEFORE anything is launched - a refusal in the middle of the
+    // step would leave the workspace and the running statistics half-updated.
+    VAD_REQUIRE(precision != VAD_PREC_BF16S || vad_conv_stats_available(),
+                "vid_train_fwd_bwd: VAD_PREC_BF16S needs the persistent convolution kernels' own BatchNorm partial sums "
+                "(vad_debug_set_conv_variant bit 0 is cleared)");
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     const float* P = params;

@@ -152,6 +152,7 @@ int vad_conv3x3_kpart(const float* in, long long in_fs, const float* w, const fl
 bool vad_convlstm_small_wins(int n, int h, int wd, int hid);
 bool vad_convlstm_gate_wins(int n, int h, int wd, int hid);   // would a ConvLSTM step of n frames run the gate-split kernel?
 bool vad_convlstm_hoist_ok(void);
+bool vad_conv_stats_available(void);
 int vad_convlstm_step_zx(const float* x, long long x_fs, const float* zx, long long zx_fs, const float* h_prev, long long h_prev_fs,
                          const float* c_prev, const float* w, const float* bias, float* h_out, long long h_out_fs,
                          float* c_out, int n, int h, int wd, int cin_x, int hid, int precision, void* stream);

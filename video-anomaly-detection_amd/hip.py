@@ -19,11 +19,25 @@ LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
 SOURCES = ["conv_mfma.hip", "dec4_fused.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
 
 VAD_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_FP32, PREC_SPLIT, PREC_BF16, PREC_BF16S = 0, 1, 2, 3
 # bf16 modes: training entry points only.  "bf16_operands" = bf16 MFMA operands converted from fp32 tensors; "bf16_tensors" =
 # the activation / gradient tensors themselves are bf16 in HBM (VAD_PREC_BF16S, video training step only)
-PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16, "bf16_operands": PREC_BF16, "bf16_tensors": PREC_BF16S}
+# "bf16" is an alias of "bf16_tensors" EVERYWHERE (BASELINE.json configs[4]'s dtype); a trainer without a bf16-tensor form
+# (ImageTrainer) rejects it by name instead of quietly running other arithmetic under the same string.
+PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16S, "bf16_operands": PREC_BF16, "bf16_tensors": PREC_BF16S}
+
+
+def training_precision(name: str, trainer: str, tensors: bool) -> str:
+    """The ONE place the trainers' `precision=` strings are resolved: returns 'fp32', 'split', 'bf16_operands' or
+    'bf16_tensors' ('bf16' -> 'bf16_tensors').  `tensors`: does this trainer have the bf16-tensor form?"""
+    ok = ("fp32", "split", "bf16_operands") + (("bf16", "bf16_tensors") if tensors else ())
+    if name in ("bf16", "bf16_tensors") and not tensors:
+        raise VadError(f"{trainer}: precision {name!r} means bf16 TENSORS (activations / gradients bf16 in HBM), which this "
+                       f"trainer does not implement; its bf16 form is 'bf16_operands' (fp32 tensors, bf16 MFMA operands)")
+    if name not in ok:
+        raise VadError(f"{trainer}: precision must be one of {ok}, got {name!r}")
+    return "bf16_tensors" if name == "bf16" else name
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 X_F32_NCHW, X_U8_NHWC = 0, 1
 PROF_SLOTS = 32
@@ -67,6 +81,19 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     return LIB_PATH
+
+
+def source_digest() -> str:
+    """sha256 over the library's sources (csrc/*, include/vad_hip.h), in name order: what a committed counter file
+    (profiles/r*_pmc_traffic_*.json, written by tools/pmc_traffic_summary.py) was measured on.  `bench.py` prints a committed
+    `roofline.traffic` only while this still matches, so the figure cannot go stale behind a kernel change."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(CSRC.iterdir()) + [REPO_DIR / "include" / "vad_hip.h"]:
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()
 
 
 _f32p = C.POINTER(C.c_float)
@@ -224,9 +251,12 @@ class CapturedCall:
     """One scoring call captured into a hipGraph (vad_graph_*): `replay()` relaunches it on the current stream with the
     same buffers; `outputs` are the tensors it writes.  Built by `model.capture(...)`."""
 
-    def __init__(self, run, inputs, outputs, keep):
+    def __init__(self, run, inputs, outputs, keep, post=None):
+        """`inputs` = the tensor `replay(x)` copies into (a view of the captured input buffer shaped like the caller's
+        batch); `outputs` = the tensors the captured kernels write; `post` (optional) maps them to what `replay` returns
+        (1- / 2-channel models: the kernels work on 3 planes, the caller sees `in_channels`)."""
         import torch
-        self.inputs, self.outputs, self._keep = inputs, outputs, keep
+        self.inputs, self.outputs, self._keep, self._post = inputs, outputs, keep, post
         self._exec = _vp()
         l = lib()
         side = torch.cuda.Stream()                       # capture on a side stream, never on the legacy default stream
@@ -247,7 +277,7 @@ class CapturedCall:
             self.inputs.copy_(x)
         check(lib().vad_graph_launch(self._exec, current_stream()), "vad_graph_launch")
         calls["graph_replay"] = calls.get("graph_replay", 0) + 1
-        return self.outputs
+        return self._post(self.outputs) if self._post else self.outputs
 
     __call__ = replay
 

@@ -210,8 +210,6 @@ class VideoTrainer(_FlatTrainer):
     def __init__(self, model: VideoAutoencoder, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999),
                  eps: float = 1e-8, process_group=None, precision: str = "fp32"):
         self._check_model(model, VideoAutoencoder, "VideoTrainer")
-        if precision not in ("fp32", "split", "bf16", "bf16_operands", "bf16_tensors"):
-            raise hip.VadError(f"precision must be 'fp32', 'split', 'bf16' (= 'bf16_tensors') or 'bf16_operands', got {precision!r}")
         #: "fp32": exact fp32 everywhere (default, the parity path).  "split": the 3x3 / transposed convolutions (forward
         #: and data gradients) use split-fp16 operands - 22-bit products, fp32 accumulate - everything else stays fp32.
         #: "bf16" (BASELINE.json configs[4]) = "bf16_tensors": every activation and activation-gradient tensor between the
@@ -219,7 +217,7 @@ class VideoTrainer(_FlatTrainer):
         #: operands with fp32 accumulation; arithmetic inside the kernels, BatchNorm statistics, cell states, master weights,
         #: parameter gradients, loss and Adam stay fp32.  "bf16_operands" (round 2's form, kept for A/B): fp32 tensors in
         #: HBM, converted to bf16 while they are staged.  Both are gated by loss-curve agreement, not parity
-        self.precision = "bf16_tensors" if precision == "bf16" else precision
+        self.precision = hip.training_precision(precision, "VideoTrainer", tensors=True)
         l = hip.lib()
         self.cfg = (model.latent_dim, model.lstm_hidden_dim, model.lstm_num_layers)
         super().__init__(model, l.vad_vid_train_nparams(*self.cfg), l.vad_vid_train_nstats(*self.cfg), lr, weight_decay, betas, eps,
@@ -260,9 +258,10 @@ class ImageTrainer(_FlatTrainer):
                  process_group=None, loss: str = "mse", ssim_weight: float = 0.5, window_size: int = 11, precision: str = "fp32"):
         from .autoencoder import ConvAutoencoder
         self._check_model(model, ConvAutoencoder, "ImageTrainer")
-        if precision not in ("fp32", "split", "bf16"):
-            raise hip.VadError(f"precision must be 'fp32', 'split' or 'bf16', got {precision!r}")
-        self.precision = precision
+        #: "fp32" | "split" | "bf16_operands" (fp32 tensors, bf16 MFMA operands in the convolutions and weight gradients).
+        #: "bf16" / "bf16_tensors" name the bf16-TENSOR mode of `VideoTrainer` and are rejected here by name: the image
+        #: step has no such form (round 3 accepted "bf16" here with the operand meaning - the same string, other arithmetic)
+        self.precision = hip.training_precision(precision, "ImageTrainer", tensors=False)
         if loss not in self._KINDS:
             raise hip.VadError(f"loss must be one of {sorted(self._KINDS)}, got {loss!r}")
         self.loss, self.ssim_weight, self.window_size = loss, float(ssim_weight), int(window_size)

@@ -191,20 +191,22 @@ class VideoAutoencoder(nn.Module):
         if not self._use_hip():
             raise hip.VadError("capture is an inference entry point: call under eval() and torch.no_grad()")
         want = dict(seq=seq, frame=frame, errmap=errmap, recon=recon)
-        xs = x.clone()
-        eager = self._run_hip(xs, **want)
+        _HipScorer.check_input(x, 5, self.in_channels)
+        # 1- / 2-channel models: widened once outside the capture, outputs at kernel shape (see ConvAutoencoder.capture)
+        xs3 = _HipScorer.widen_input(x.contiguous() if x.dtype == torch.uint8 else x.contiguous().float(), self.in_channels,
+                                     x.dtype == torch.uint8).clone()
+        eager = self._run_hip(xs3, prewidened=True, **want)
         out = {k: torch.empty_like(v) for k, v in eager.items()}
-        return hip.CapturedCall(lambda: self._run_hip(xs, out=out, **want), xs, out, keep=(self._hip.packed, self._hip.ws))
+        view = xs3 if self.in_channels == 3 else xs3[:, :, :self.in_channels]
+        return hip.CapturedCall(lambda: self._run_hip(xs3, out=out, prewidened=True, **want), view, out,
+                                keep=(self._hip.packed, self._hip.ws, xs3),
+                                post=None if self.in_channels == 3 else self._narrow_outputs)
 
-    def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False, out=None):
+    def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False, out=None, prewidened=False):
+        """`prewidened` (captured calls): `x` already has the kernels' 3 planes and the outputs stay at kernel shape."""
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,T,H,W,3]: normalised inside the kernels (row f-3)
-        cin = self.in_channels
-        if x.dim() != 5 or (x.shape[4] if u8 else x.shape[2]) != cin:
-            raise hip.VadError(f"expected float input [B,T,{cin},H,W] or uint8 input [B,T,H,W,{cin}], got {x.dtype} {tuple(x.shape)}")
-        if not x.is_cuda:
-            raise hip.VadError(
-                "VideoAutoencoder inference runs only on the MI355X HIP path: move the model and input to "
-                "'cuda' (there is no CPU fallback)")
+        cin = 3 if prewidened else self.in_channels
+        _HipScorer.check_input(x, 5, cin)
         if u8:
             b, t, h, w, _ = x.shape
             x = x.contiguous()
@@ -240,7 +242,7 @@ class VideoAutoencoder(nn.Module):
                                       hip.ptr(out.get("errmap")), hip.ptr(out.get("recon")), hip.current_stream()),
                       "vad_vid_score")
         hip.calls["vid_score"] += 1
-        return self._narrow_outputs(out)
+        return out if prewidened else self._narrow_outputs(out)
 
     def _narrow_outputs(self, out: dict) -> dict:
         """Undo the 3-plane view of a 1- / 2-channel model (`_HipScorer.widen_to_rgb`): the kernels averaged over 3
@@ -300,10 +302,7 @@ class VideoAutoencoder(nn.Module):
             raise hip.VadError("score_windows is an inference entry point: call under eval() and torch.no_grad()")
         u8 = frames.dtype == torch.uint8
         cin = self.in_channels
-        if frames.dim() != 4 or (frames.shape[3] if u8 else frames.shape[1]) != cin:
-            raise hip.VadError(f"expected float frames [F,{cin},H,W] or uint8 frames [F,H,W,{cin}], got {tuple(frames.shape)}")
-        if not frames.is_cuda:
-            raise hip.VadError("score_windows runs only on the MI355X HIP path (there is no CPU fallback)")
+        _HipScorer.check_input(frames, 4, cin, what="frames")
         if u8:
             f, h, w, _ = frames.shape
         else:
