@@ -98,7 +98,7 @@ def _rank(rank, world, port, out_dir):
 def test_ranks_equal_one_process_with_averaged_gradients(vad, tmp_path, world):
     """World 2: bit-equal to one process that sums the two halves' gradients (a two-term sum has one order).  World 4 (one
     clip per rank; the most ranks a GPU box admits beside the test session): every rank ends bit-identical to every other,
-    and equal to the one-process result up to the summation order of the four-term all-reduce (1e-6 of the largest entry)."""
+    and equal to the one-process result up to the summation order of the four-term all-reduce."""
     mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     p0 = np.load(tmp_path / "p0.npy")
     for r in range(1, world):
@@ -119,7 +119,12 @@ def test_ranks_equal_one_process_with_averaged_gradients(vad, tmp_path, world):
     if world == 2:
         assert np.array_equal(one, p0), f"max diff {np.abs(one - p0).max():.3e}"
     else:
-        assert np.abs(one - p0).max() < 1e-6 * np.abs(one).max(), f"max diff {np.abs(one - p0).max():.3e}"
+        # Adam normalises every entry by its own gradient history (update = lr * m / (sqrt(v) + eps), |update| <= ~lr): where a
+        # gradient entry is ~0 the last bits of the four-term sum decide the update's size, so the comparison is "almost every
+        # entry to 1e-6, no entry further than the two steps could move it" rather than a uniform bound
+        diff = np.abs(one - p0)
+        assert diff.max() <= 2 * 2 * CFG["lr"], f"max diff {diff.max():.3e}"
+        assert np.mean(diff <= 1e-6 * np.abs(one).max()) > 0.99, f"{np.mean(diff <= 1e-6 * np.abs(one).max()):.4f} of the entries agree"
     for r in range(world):
         srun, want = np.load(tmp_path / f"s{r}.npy"), reps[r].running.cpu().numpy()                 # per-rank BatchNorm statistics
         if world == 2:

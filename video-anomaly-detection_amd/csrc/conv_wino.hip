@@ -1,0 +1,309 @@
+// Winograd F(2x2, 3x3) form of the 3x3 convolution on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32), gfx950.
+// OPT-IN arithmetic (model.precision = "winograd"): every multiply and add is fp32, but a 2x2 block of outputs is computed from
+// 16 products per input channel instead of 36, so the results are NOT bit-identical to the direct kernels of conv_pkernel.h
+// (they differ by fp32 rounding, ~1e-6 relative on a layer's outputs); `value` of bench.py is always the direct path.
+//
+// Reference ops restated: nn.Conv2d(k3,p1)+BatchNorm2d(eval, folded)+LeakyReLU/ReLU(+MaxPool2d) for the layers with
+// cin = cout >= 64 or cin >= 32 (models/autoencoder.py:49-79,103-128; models/video_autoencoder.py:197-215).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A,   d = 4x4 input patch, g = 3x3 filter, Y = 2x2 outputs (Lavin & Gray)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// The 16 element-wise products, summed over input channels, are 16 independent GEMMs
+//   M_f[tile][cout] = sum_cin V_f[tile][cin] * U_f[cin][cout],   f = (fr, fc) = 4 x 4 "frequencies"
+// with U = G g G^T packed on the host (pack.cpp, [16][cin/8][cout][8]) and V = B^T d B computed on the fly.
+//
+// Work split.  A work-group (4 waves) owns 4 x 8 Winograd tiles = 8 rows x 16 columns of outputs and 32*NT output channels and
+// walks the frames of the batch (persistent, like conv3x3_mfma_pkernel).  Wave r owns frequency ROW fr = r for all 32 tiles:
+//   * its A operands need only TWO of a patch's four rows (fr 0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3): per 4 channels 8
+//     ds_read_b128 + 16 row adds + 16 column adds give the 16 A values (4 fc x 4 channels) of 16*NT MFMAs - the transform is
+//     ~6 % of the wave's matrix-pipe time at NT = 2 (fp32 VALU work shares the pipe with the fp32 MFMAs);
+//   * its accumulators are 4 fc x NT tiles x 16 registers = 128 registers at NT = 2;
+//   * the output transform's column half (over fc) happens in registers; the row half (over fr = over the four waves) goes
+//     through LDS once per tile: 64 KB that alias the input tile, XOR-swizzled 16-byte slots, conflict-free both ways.  Wave w
+//     then finishes tile row w: bias, activation, (the 2x2 outputs of a tile ARE one MaxPool2d window) pooling, stores.
+// B operands come straight from L2 (buffer_load_dwordx4, a ring of NB register sets, PB steps ahead) as in the direct kernels.
+#include <atomic>
+
+#include "vad_common.h"
+
+#define MFMA32W(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+struct ConvWP {
+    const float* in;  long long in_fs;     // NHWC fp32 [n][h][w][cin], frame stride in floats
+    const float* w;                        // vad_pack_conv3x3_wino: [16][cin/8][cout][8]
+    const float* bias;                     // [cout] (BatchNorm folded)
+    float* out;       long long out_fs;    // NHWC [n][h or h/2][w or w/2][cout]
+    int n, h, w_, cin, cout;
+    int tiles_x, tiles_y, cblocks;
+};
+
+template <int NT, int POOL, int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
+    constexpr int CK = 32, LW = 18, LH = 10, PS = CK + 4, NPIX = LW * LH;
+    constexpr int TOT = NPIX * (CK / 4), NPF = (TOT + 255) / 256;
+    constexpr int XF = 4 * 2 * NT * 64 * 16;                        // exchange floats
+    constexpr int SMEM = (NPIX * PS > XF) ? NPIX * PS : XF;
+    constexpr int NS = 16;                                          // (k-group, fc) steps per 32-channel chunk
+    constexpr int PB = 3, NB = 4;                                   // B ring: PB steps ahead, NB register sets (NS % NB == 0)
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* tile = smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- geometry of this work-group (fixed for its whole life)
+    const unsigned per_frame = (unsigned)(p.tiles_x * p.tiles_y * p.cblocks);
+    unsigned L = vad_xcd_remap(blockIdx.x % per_frame, per_frame);
+    const int fg = blockIdx.x / per_frame, fgroups = gridDim.x / per_frame;
+    const int cb = L % p.cblocks; L /= p.cblocks;
+    const int x0 = (L % p.tiles_x) * 16, y0 = (L / p.tiles_x) * 8;
+    const int H = p.h, W = p.w_;
+    const int nch = p.cin / CK;
+
+    // ---- staging slots (input tile + 1-pixel halo, NHWC chunk of 32 channels): slot i = float4 number tid + 256 i
+    unsigned svo[NPF];
+    const int c4 = tid & 7, pix0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int pix = pix0 + 32 * i;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        svo[i] = ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, p.cin) + c4 * 4) * 4u : VAD_OOB;
+    }
+    const unsigned in_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u;
+    f32x4 pf[NPF];
+#define ISSUE(n_, ch_)                                                                                   \
+    {                                                                                                    \
+        const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(p.in + (size_t)(n_) * p.in_fs + (ch_) * CK, in_bytes - (unsigned)(ch_) * CK * 4u); \
+        _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf[i_] = vad_bload4(r_, svo[i_], 0);          \
+    }
+
+    // ---- A side: this wave's frequency row needs patch rows (ia, ib) combined as d[ia] + sgn * d[ib]
+    const int tr = li >> 3, tc = li & 7;
+    const int ia = (wave == 0) ? 0 : (wave == 2) ? 2 : 1;
+    const int ib = (wave == 0) ? 2 : (wave == 1) ? 2 : (wave == 2) ? 1 : 3;
+    const float sgn = (wave == 1) ? 1.f : -1.f;
+    const int rowa = ((2 * tr + ia) * LW + 2 * tc) * PS + 4 * lh;
+    const int rowb = ((2 * tr + ib) * LW + 2 * tc) * PS + 4 * lh;
+
+    // ---- B side
+    const unsigned wf = (unsigned)p.cout * 32u;                     // bytes per (frequency, 8-channel group) slab
+    const unsigned ftap = (unsigned)(p.cin / 8) * wf;               // bytes per frequency
+    const __amdgpu_buffer_rsrc_t rw = vad_rsrc(p.w, 16u * ftap);
+    unsigned wl[NT];
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (cb * NT + nt) * 32 + li;
+        wl[nt] = (unsigned)(wave * 4) * ftap + (unsigned)co * 32u + 16u * lh;
+        bv[nt] = p.bias[co];
+    }
+    f32x4 b[NB][NT];
+#define LOAD_B(buf, chunk, step)   /* step = kg * 4 + fc */                                              \
+    {                                                                                                    \
+        const unsigned soff_ = (unsigned)((step) & 3) * ftap + (unsigned)((chunk) * 4 + ((step) >> 2)) * wf; \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) b[buf][nt] = vad_bload4(rw, wl[nt], soff_);    \
+    }
+
+    // ---- epilogue geometry: wave w finishes tile row w; lane = (channel li, column half lh), kk = tile column 4 lh + kk
+    const int ech = p.cout;
+    const int ow = POOL ? (W >> 1) : W, oh = POOL ? (H >> 1) : H;
+    const int ey0 = POOL ? (y0 >> 1) + wave : y0 + 2 * wave;
+    const int ex0 = POOL ? (x0 >> 1) + 4 * lh : x0 + 8 * lh;
+    const unsigned erow = (unsigned)__mul24(ow, ech) * 4u, ecol = (unsigned)ech * 4u;
+    const unsigned eoff = (unsigned)(__mul24(__mul24(ey0, ow) + ex0, ech) + cb * NT * 32 + li) * 4u;
+    const unsigned out_bytes = (unsigned)__mul24(oh, ow) * (unsigned)ech * 4u;
+    const bool full_tile = (y0 + 8 <= H) && (x0 + 16 <= W);
+    const int sw = (lane >> 2) & 3;                                 // 16-byte slot swizzle of the exchange records
+
+    int n = fg;
+    if (n >= p.n) return;
+    ISSUE(n, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < PB; ++s0) LOAD_B(s0, 0, s0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bv[nt]));
+
+    while (true) {
+        f32x16 acc[4][NT];
+#pragma unroll
+        for (int fc = 0; fc < 4; ++fc)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[fc][nt][r] = 0.f;
+        const int nn = n + fgroups;
+        const bool has_next = nn < p.n;
+
+        for (int ch = 0; ch < nch; ++ch) {
+            __syncthreads();                       // every wave is done reading the previous stage (tile or exchange records)
+#pragma unroll
+            for (int i = 0; i < NPF; ++i)
+                if (pix0 + 32 * i < NPIX) *(f32x4*)&tile[(pix0 + 32 * i) * PS + c4 * 4] = pf[i];
+            __syncthreads();
+            if (ch + 1 < nch) { ISSUE(n, ch + 1); }
+            else if (has_next) { ISSUE(nn, 0); }
+
+            // V[fc][channel j of this lane's quad] of one 8-channel group: row combination, then the column transform
+            f32x4 v[2][4];
+#define COMPUTE_V(buf, kg)                                                                               \
+    {                                                                                                    \
+        f32x4 t_[4];                                                                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                               \
+            const f32x4 da_ = *(const f32x4*)&tile[rowa + j_ * PS + (kg) * 8];                           \
+            const f32x4 db_ = *(const f32x4*)&tile[rowb + j_ * PS + (kg) * 8];                           \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[j_][e_] = __builtin_fmaf(sgn, db_[e_], da_[e_]); \
+        }                                                                                                \
+        v[buf][0] = t_[0] - t_[2];                                                                       \
+        v[buf][1] = t_[1] + t_[2];                                                                       \
+        v[buf][2] = t_[2] - t_[1];                                                                       \
+        v[buf][3] = t_[1] - t_[3];                                                                       \
+    }
+            COMPUTE_V(0, 0);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const int cur = kg & 1;
+#pragma unroll
+                for (int fc = 0; fc < 4; ++fc) {
+                    const int s = kg * 4 + fc, bcur = s % NB, bnxt = (s + PB) % NB;
+                    if (s + PB < NS) { LOAD_B(bnxt, ch, s + PB); }
+                    else if (ch + 1 < nch) { LOAD_B(bnxt, ch + 1, s + PB - NS); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[fc][nt] = MFMA32W(v[cur][fc][j], b[bcur][nt][j], acc[fc][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (fc == 1 && kg + 1 < 4) { COMPUTE_V(cur ^ 1, kg + 1); }     // next group's A values under this group's MFMAs
+                }
+            }
+#undef COMPUTE_V
+        }
+
+        // ---- output transform, column half (over fc) in registers: P0 = M0 + M1 + M2, P1 = M1 - M2 - M3
+        f32x16 P[2][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            P[0][nt] = acc[0][nt] + acc[1][nt] + acc[2][nt];
+            P[1][nt] = acc[1][nt] - acc[2][nt] - acc[3][nt];
+        }
+        // next frame's first B fragments go out BEFORE this frame's stores (vmcnt retires in order)
+        if (has_next) {
+#pragma unroll
+            for (int s0 = 0; s0 < PB; ++s0) LOAD_B(s0, 0, s0);
+        }
+        __syncthreads();                           // every wave is done reading the input tile: its space takes the records
+        // record of (frequency row r, j, nt, lane): 16 floats = the lane's 16 tiles, as four 16-byte slots q = tile row
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(f32x4*)&smem[((((wave * 2 + j) * NT + nt) * 64 + lane) * 4 + (q ^ sw)) * 4] =
+                        f32x4{P[j][nt][4 * q], P[j][nt][4 * q + 1], P[j][nt][4 * q + 2], P[j][nt][4 * q + 3]};
+        __syncthreads();
+        // ---- row half (over the four waves' frequency rows) for tile row `wave`: Y0 = P0 + P1 + P2, Y1 = P1 - P2 - P3
+        const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 y[2][2];                         // [dy][dx], components kk = tile column 4 lh + kk
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 pr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[r] = *(const f32x4*)&smem[((((r * 2 + j) * NT + nt) * 64 + lane) * 4 + (wave ^ sw)) * 4];
+                y[0][j] = pr[0] + pr[1] + pr[2];
+                y[1][j] = pr[1] - pr[2] - pr[3];
+            }
+            if (POOL) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bool ok = full_tile || (ey0 < oh && (ex0 + kk) < ow);
+                    const float m = fmaxf(fmaxf(y[0][0][kk], y[0][1][kk]), fmaxf(y[1][0][kk], y[1][1][kk]));
+                    vad_bstore1(vad_act(m + bv[nt], ACT), ro, ok ? eoff : VAD_OOB, kk * ecol + nt * 128u);
+                }
+            } else {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + 2 * kk + dx) < ow);
+                            vad_bstore1(vad_act(y[dy][dx][kk] + bv[nt], ACT), ro, ok ? eoff : VAD_OOB, dy * erow + (2 * kk + dx) * ecol + nt * 128u);
+                        }
+            }
+        }
+        if (!has_next) break;
+        n = nn;
+    }
+#undef ISSUE
+#undef LOAD_B
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int wino_num_cus() {
+    static std::atomic<int> cached{0};
+    int ncu = cached.load(std::memory_order_relaxed);
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+        cached = ncu;
+    }
+    return ncu;
+}
+
+template <int NT, int POOL, int ACT>
+static void launch_wino(const ConvWP& p, hipStream_t s) {
+    static std::atomic<unsigned> cap_{0};
+    unsigned cap = cap_.load(std::memory_order_relaxed);
+    if (!cap) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_wino_pkernel<NT, POOL, ACT>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        cap_ = cap = (unsigned)wino_num_cus() * (unsigned)per_cu;
+    }
+    const unsigned per_frame = (unsigned)(p.tiles_x * p.tiles_y * p.cblocks);
+    unsigned fgroups = cap / per_frame;
+    if (fgroups < 1) fgroups = 1;
+    if (fgroups > (unsigned)p.n) fgroups = (unsigned)p.n;
+    hipLaunchKernelGGL((conv3x3_wino_pkernel<NT, POOL, ACT>), dim3(per_frame * fgroups), dim3(256), 0, s, p);
+}
+
+template <int NT>
+static int launch_wino_nt(const ConvWP& p, int act, int pool, hipStream_t s) {
+#define W_(P_, A_) launch_wino<NT, P_, A_>(p, s)
+    if (pool) { if (act == VAD_ACT_LEAKY) W_(1, VAD_ACT_LEAKY); else if (act == VAD_ACT_RELU) W_(1, VAD_ACT_RELU); else W_(1, VAD_ACT_NONE); }
+    else { if (act == VAD_ACT_LEAKY) W_(0, VAD_ACT_LEAKY); else if (act == VAD_ACT_RELU) W_(0, VAD_ACT_RELU); else W_(0, VAD_ACT_NONE); }
+#undef W_
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// include/vad_hip.h: vad_conv3x3_wino
+extern "C" int vad_conv3x3_wino(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs,
+                                int n, int h, int wd, int cin, int cout, int act, int pool, void* stream) {
+    VAD_REQUIRE(in && w && bias && out, "conv3x3_wino: null pointer");
+    VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "conv3x3_wino: bad shape n=%d h=%d w=%d", n, h, wd);
+    VAD_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0, "conv3x3_wino: cin=%d cout=%d must be positive multiples of 32", cin, cout);
+    VAD_REQUIRE(h % 2 == 0 && wd % 2 == 0, "conv3x3_wino: 2x2 output tiles need even H, W (got %dx%d)", h, wd);
+    VAD_REQUIRE(act >= 0 && act <= 2, "conv3x3_wino: bad act %d", act);
+    const long long chmax = cin > cout ? cin : cout;
+    VAD_REQUIRE((long long)h * wd * chmax * 4 < (1ll << 31) && 16ll * cin * cout * 4 < (1ll << 31),
+                "conv3x3_wino: frame %dx%dx%lld or weights %dx%d too large for 32-bit offsets", h, wd, chmax, cin, cout);
+    ConvWP p{};
+    p.in = in; p.in_fs = in_fs ? in_fs : (long long)h * wd * cin;
+    p.w = w; p.bias = bias; p.out = out;
+    const int ho = pool ? h / 2 : h, wo = pool ? wd / 2 : wd;
+    p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
+    p.n = n; p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout;
+    p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 7) / 8;
+    const bool two = cout % 64 == 0;
+    p.cblocks = cout / (two ? 64 : 32);
+    VAD_REQUIRE((long long)p.tiles_x * p.tiles_y * p.cblocks < (1ll << 24), "conv3x3_wino: %d x %d x %d work-group positions out of range", p.tiles_x, p.tiles_y, p.cblocks);
+    return two ? launch_wino_nt<2>(p, act, pool, (hipStream_t)stream) : launch_wino_nt<1>(p, act, pool, (hipStream_t)stream);
+}
