@@ -104,6 +104,17 @@ int vad_conv3x3(const float* in_nhwc, long long in_fs, const float* w_packed, co
                 float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,
                 int act, int pool, int precision, void* stream);
 
+/* Winograd F(2x2,3x3) form of vad_conv3x3 on the exact-fp32 matrix pipe (csrc/conv_wino.hip): OPT-IN arithmetic - all fp32,
+ * 16 instead of 36 multiplies per 2x2 outputs and input channel, NOT bit-identical to vad_conv3x3 (fp32 rounding differs).
+ * Same operation as the nn.Conv2d(k3,p1)+BatchNorm2d+activation(+MaxPool2d) pairs of models/autoencoder.py:49-79,103-128.
+ * w_packed from vad_pack_conv3x3_wino ([16][Cin/8][Cout][8], U = G g G^T).  Cin, Cout multiples of 32; even H, W. */
+size_t vad_pack_conv3x3_wino_floats(int cout, int cin);
+int vad_pack_conv3x3_wino(const float* w_oihw, const float* bias, const float* const* bn, int cout, int cin,
+                          float* w_packed, float* bias_out);
+int vad_conv3x3_wino(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
+                     float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,
+                     int act, int pool, void* stream);
+
 /* NHWC ConvTranspose2d k2 s2 + bias + act: [N,H,W,Cin] -> [N,2H,2W,Cout]. */
 int vad_convt2x2(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
                  float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,

@@ -46,6 +46,26 @@ def pack_conv3x3(w, b, bn=None):
     return dev(wp), dev(bo)
 
 
+def conv3x3_wino(x_nchw, w, b, bn=None, act=0, pool=False):
+    """Winograd F(2x2,3x3) form of the same layer (opt-in arithmetic; csrc/conv_wino.hip)."""
+    l = hip.lib()
+    n, cin, h, wd = x_nchw.shape
+    cout = w.shape[0]
+    w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+    keep, bnp = _bn_ptrs(bn)
+    wp = np.empty(l.vad_pack_conv3x3_wino_floats(cout, cin), np.float32)
+    bo = np.empty(cout, np.float32)
+    hip.check(l.vad_pack_conv3x3_wino(w.ctypes.data, b.ctypes.data, bnp, cout, cin, wp.ctypes.data, bo.ctypes.data))
+    wp, bo = dev(wp), dev(bo)
+    ho, wo = (h // 2, wd // 2) if pool else (h, wd)
+    out = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+    xin = nhwc(x_nchw)
+    hip.check(l.vad_conv3x3_wino(xin.data_ptr(), 0, wp.data_ptr(), bo.data_ptr(), out.data_ptr(), 0, n, h, wd, cin, cout,
+                                 act, int(pool), stream()))
+    torch.cuda.synchronize()
+    return to_nchw(out)
+
+
 def pack_convt(w, b, bn=None):
     l = hip.lib()
     cin, cout = w.shape[:2]

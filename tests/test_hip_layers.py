@@ -64,6 +64,28 @@ def test_conv3x3(cin, cout, h, w, act, pool):
         l.vad_debug_set_conv_variant(1)
 
 
+@pytest.mark.parametrize("cin,cout,h,w,act,pool,n", [
+    (32, 32, 16, 16, 1, True, 2), (32, 32, 18, 22, 2, False, 3), (32, 64, 24, 40, 1, False, 2), (64, 64, 16, 32, 1, True, 5),
+    (64, 128, 8, 8, 1, False, 2), (128, 128, 12, 20, 2, False, 2), (128, 256, 4, 4, 1, False, 7), (256, 256, 6, 10, 1, True, 2),
+    (32, 96, 10, 10, 0, False, 2), (64, 192, 2, 6, 2, False, 2), (64, 64, 128, 128, 1, True, 3), (128, 128, 32, 32, 2, False, 9),
+])
+def test_conv3x3_winograd(cin, cout, h, w, act, pool, n):
+    """Winograd F(2x2,3x3) on the exact-fp32 MFMA (opt-in arithmetic): the same layer as `test_conv3x3`, against the same
+    oracle.  All-fp32, but 16 products per 2x2 outputs instead of 36 with +-1 / 0.5 transforms around them: not bit-identical to
+    the direct kernel, within fp32 rounding of it - held to the direct kernels' own bound against the oracle.  Covers ragged
+    tiles (H, W not multiples of 8 / 16), one and two N-tiles per wave, every activation, pooling, frames > work-group groups."""
+    import hip_helpers as H
+    rng = _rng(cin * 1000 + cout + h + 77)
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt, b, bn = _conv_params(rng, cout, cin)
+    got = H.conv3x3_wino(x, wt, b, bn, act, pool)
+    ref = _ref_conv(x, wt, b, bn, act, pool)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert max_abs(got, ref) < ATOL
+    direct = H.conv3x3(x, wt, b, bn, act, pool)
+    assert max_abs(got, direct) < ATOL and not np.array_equal(got, direct)       # another rounding order, stated as such
+
+
 @pytest.mark.parametrize("h,w", [(16, 16), (32, 48), (22, 18), (64, 64)])
 def test_conv3x3_c3_fused(h, w):
     """Fused enc1 block == the two separate layers of the oracle (halo recompute, zero padding of conv #2)."""

@@ -47,6 +47,12 @@ def run(kind, n, h, w, cin, cout, pool, iters, warm=3, prec=0):
         fn = lambda: l.vad_conv3x3(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 1, pool, prec, s)
         flop = 2.0 * n * h * w * 9 * cin * cout
         byts = 4.0 * (x.numel() + out.numel())
+    elif kind == "wino":                    # Winograd F(2x2,3x3) form of conv3x3 (random, unpacked weights: timing only)
+        x = rnd(n, h, w, cin); wt = rnd(16 * cin * cout) * 0.05; b = rnd(cout)
+        out = torch.empty(n, h // (2 if pool else 1), w // (2 if pool else 1), cout, device="cuda")
+        fn = lambda: l.vad_conv3x3_wino(x.data_ptr(), 0, wt.data_ptr(), b.data_ptr(), out.data_ptr(), 0, n, h, w, cin, cout, 1, pool, s)
+        flop = 2.0 * n * h * w * 9 * cin * cout          # ALGORITHMIC (direct-convolution) FLOPs; executed MFMA FLOPs are 16/36 of them
+        byts = 4.0 * (x.numel() + out.numel())
     elif kind == "convt":
         x = rnd(n, h, w, cin); wt = rnd(4 * cin * cout) * 0.05; b = rnd(cout)
         out = torch.empty(n, 2 * h, 2 * w, cout, device="cuda")
@@ -122,7 +128,15 @@ if __name__ == "__main__":
         hip.lib().vad_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
         dbg = torch.zeros(1024 * 4 * 12, dtype=torch.int64, device="cuda")
         hip.lib().vad_debug_set_stamp_buffer(dbg.data_ptr())
-    if a.kind == "image":
+    if a.kind == "winoab":                  # every 3x3 layer of the image path behind enc1: direct vs Winograd
+        for name, kind, h, cin, cout, pool in IMAGE_LAYERS:
+            if kind != "conv3x3":
+                continue
+            ms0, tf0, _ = run("conv3x3", a.n, h, h, cin, cout, pool, a.iters)
+            ms1, tf1, _ = run("wino", a.n, h, h, cin, cout, pool, a.iters)
+            print(f"{name:8s} {cin:3d}->{cout:3d} @{h:3d} pool={pool}: direct {ms0:7.4f} ms {tf0:6.1f} TF | winograd {ms1:7.4f} ms "
+                  f"{tf1:6.1f} TF algorithmic ({tf1 * 16 / 36:6.1f} executed) | speed-up {ms0 / ms1:5.2f}x", flush=True)
+    elif a.kind == "image":
         tot = 0.0
         for name, kind, h, cin, cout, pool in IMAGE_LAYERS:
             ms, tf, gbs = run(kind, a.n, h, h, cin, cout, pool, a.iters, prec=a.precision)

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
     constexpr int XF = 4 * 2 * NT * 64 * 16;                        // exchange floats
     constexpr int SMEM = (NPIX * PS > XF) ? NPIX * PS : XF;
     constexpr int NS = 16;                                          // (k-group, fc) steps per 32-channel chunk
-    constexpr int PB = 3, NB = 4;                                   // B ring: PB steps ahead, NB register sets (NS % NB == 0)
+    constexpr int PB = 1, NB = 2;                                   // B ring: PB steps ahead, NB register sets (NS % NB == 0)
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* tile = smem;
 

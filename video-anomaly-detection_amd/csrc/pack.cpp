@@ -84,6 +84,32 @@ extern "C" int vad_pack_conv3x3(const float* w, const float* bias, const float* 
     return VAD_OK;
 }
 
+// Winograd F(2x2,3x3) form (csrc/conv_wino.hip; opt-in arithmetic): U = G g G^T per (cout, cin) with the BatchNorm scale folded,
+// computed in double and rounded once -> [16 frequencies f = 4 fr + fc][cin/8][cout][8], the layout of the direct form with 16
+// "taps".  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
+extern "C" size_t vad_pack_conv3x3_wino_floats(int cout, int cin) { return (size_t)16 * ((cin + 7) / 8) * cout * 8; }
+
+extern "C" int vad_pack_conv3x3_wino(const float* w, const float* bias, const float* const* bn, int cout, int cin, float* out, float* bias_out) {
+    REQ(w && out && bias_out && cout > 0 && cin > 0, "pack_conv3x3_wino: bad arguments");
+    std::vector<double> s;
+    bn_scale_shift(bias, bn, cout, s, bias_out);
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int c8n = (cin + 7) / 8;
+    memset(out, 0, vad_pack_conv3x3_wino_floats(cout, cin) * sizeof(float));
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = w + ((size_t)co * cin + ci) * 9;
+            for (int fr = 0; fr < 4; ++fr)
+                for (int fc = 0; fc < 4; ++fc) {
+                    double u = 0.0;
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) u += G[fr][a] * (double)g[a * 3 + b] * G[fc][b];
+                    out[(((size_t)(fr * 4 + fc) * c8n + ci / 8) * cout + co) * 8 + (ci & 7)] = (float)(u * s[co]);
+                }
+        }
+    return VAD_OK;
+}
+
 // [28][cout] fp32 (K = 27 padded to 28) followed by the split-fp16 form for the fused first stage in split mode:
 // [2 k-steps][cout][half h][8 x hi | 8 x lo] fp16 (K padded to 32), 32*cout halves*2 = 32*cout floats.
 extern "C" size_t vad_pack_conv3x3_c3_floats(int cout) { return (size_t)(28 + 32) * cout; }

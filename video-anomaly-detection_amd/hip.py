@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
-SOURCES = ["conv_mfma.hip", "dec4_fused.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_wino.hip", "dec4_fused.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
 
 VAD_OK = 0
 ABI_VERSION = 3
@@ -121,6 +121,9 @@ SIGNATURES = {
     "vad_conv3x3_c3_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_conv3x3": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_convt2x2": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_pack_conv3x3_wino_floats": (_sz, [_i, _i]),
+    "vad_pack_conv3x3_wino": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "vad_conv3x3_wino": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_conv1x1": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "vad_convlstm_step": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_score_partials": (_i, [_i, _i, _i]),
