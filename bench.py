@@ -69,8 +69,9 @@ def main():
                          "-1 = 100000 in the default line (image, fp32, default batch / size), 0 = skip")
     ap.add_argument("--no-video", action="store_true", help="skip the secondary configs[2] measurement of the default line")
     ap.add_argument("--stride", type=int, default=1, help="dense workload: window stride")
-    ap.add_argument("--precision", choices=["fp32", "split"], default="fp32",
-                    help="fp32 = exact fp32 MFMA (headline); split = opt-in 3 x fp16 MFMA with fp32 accumulate")
+    ap.add_argument("--precision", choices=["fp32", "split", "winograd"], default="fp32",
+                    help="fp32 = exact fp32 MFMA, direct convolutions (headline); split = opt-in 3 x fp16 MFMA with fp32 accumulate; "
+                         "winograd = opt-in Winograd F(2x2,3x3) on the exact-fp32 MFMA")
     ap.add_argument("--ingest", choices=["f32", "u8"], default="f32",
                     help="row f-3: u8 = raw uint8 NHWC frames, normalised inside the kernels (image workload)")
     ap.add_argument("--batch", type=int, default=0, help="frames (image) or clips (video) per GPU per step")
@@ -242,7 +243,8 @@ def main():
         "metric": "frames/sec/GPU (256x256 autoencoder scoring) + AUROC parity vs reference",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 via 3 x f16 split MFMA (opt-in)",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "split": "f32 via 3 x f16 split MFMA (opt-in)",
+                                       "winograd": "f32, Winograd F(2x2,3x3) 3x3 convolutions (opt-in)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": workload, "frames_per_gpu_per_step": frames_per_step,
                    "chunk": int(model.window_chunk if args.workload == "dense" else model.chunk),
@@ -254,28 +256,42 @@ def main():
     if layers is not None:
         out["layers"] = layers
 
-    # Secondary measurement, same workload and step count: the opt-in split-fp16 arithmetic (3 x fp16 MFMA, fp32
-    # accumulate).  `value` above is always the exact-fp32 path.
+    # Secondary measurements, same workload and step count: the opt-in arithmetic modes - split-fp16 (3 x fp16 MFMA, fp32
+    # accumulate) and Winograd F(2x2,3x3) on the exact-fp32 MFMA (all-fp32, 16 instead of 36 products
+    # per 2x2 outputs).  `value` above is always the exact-fp32 direct path.
     if args.precision == "fp32" and not args.no_split:
         exact_scores = scores.clone()
-        model.precision = "split"
-        for _ in range(max(1, args.warmup)):
-            scores = step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            scores = step()
-        fence()
-        el2 = time.perf_counter() - t1
-        if dist is not None:
-            tt = torch.tensor([el2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = float(tt.item())
-        diff = float(((scores - exact_scores).abs() / exact_scores.abs()).max())
-        out["split_precision"] = {"value": round(total_frames / el2, 1), "unit": "frames/s",
-                                  "ms_per_step": round(el2 / args.steps * 1e3, 3),
-                                  "max_rel_score_diff_vs_exact_fp32": diff,
-                                  "arithmetic": "a*b = ah*bh + (ah*bl + al*bh)*2^-11, fp16 hi/lo operands, fp32 accumulate"}
+        for mode in ("split", "winograd"):
+            if mode == "winograd" and args.workload == "dense":
+                continue
+            model.precision = mode
+            for _ in range(max(1, args.warmup)):
+                scores = step()
+            fence()
+            if mode == "winograd" and events:
+                lib.vad_prof_reset()
+                lib.vad_prof_enable(1)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                scores = step()
+            fence()
+            el2 = time.perf_counter() - t1
+            lib.vad_prof_enable(0)
+            if dist is not None:
+                tt = torch.tensor([el2], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el2 = float(tt.item())
+            diff = float(((scores - exact_scores).abs() / exact_scores.abs()).max())
+            res = {"value": round(total_frames / el2, 1), "unit": "frames/s", "ms_per_step": round(el2 / args.steps * 1e3, 3),
+                   "max_rel_score_diff_vs_exact_fp32": diff, "speedup_vs_direct": round(elapsed / el2, 3)}
+            if mode == "split":
+                res["arithmetic"] = "a*b = ah*bh + (ah*bl + al*bh)*2^-11, fp16 hi/lo operands, fp32 accumulate"
+            else:
+                res["arithmetic"] = ("Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: every 3x3 convolution behind the first layer computes 2x2 outputs "
+                                     "from 16 products per input channel instead of 36; all-fp32, another rounding order than the direct form")
+                if events:
+                    res.update(winograd_roofline(hip, lib, args.workload, hw, per_gpu, args.steps, t if args.workload != "image" else 0))
+            out[mode + "_precision"] = res
         model.precision = "fp32"
         scores = exact_scores
     # configs[3]: the frame stream generated on the device in chunks of 512, block-partitioned over the ranks, ONE all_gather
@@ -400,6 +416,35 @@ def layers_and_roofline(hip, lib, kind, hw, per_gpu, steps, t, stride, default_s
                 "whole_path_hbm_gbs": round(fps_per_gpu * bytes_per_frame / 1e9, 1),
                 "whole_path_hbm_frac": round(fps_per_gpu * bytes_per_frame / 1e9 / PEAK_HBM_GBS, 4)}
     return layers, roofline
+
+
+def winograd_roofline(hip, lib, kind, hw, per_gpu, steps, t):
+    """`roofline` of the Winograd launches of the timed region just recorded (vad_prof_*): EXECUTED matrix FLOPs (16/36 of a
+    layer's direct-convolution FLOPs) against the fp32 MFMA peak, so `frac` <= 1; the direct-equivalent rate beside it."""
+    import ctypes as C
+    ms = (C.c_float * hip.PROF_SLOTS)()
+    cnt = (C.c_int * hip.PROF_SLOTS)()
+    hip.check(lib.vad_prof_read(ms, cnt), "vad_prof_read")
+    if kind == "image":
+        lf = image_mfma_layer_flops(hw, hw, 256)
+        lf[1] = conv3x3_flops(hw, hw, 32, 32)                   # enc1.3 alone: the first layer is its own (direct) launch in this mode
+        frames = per_gpu * steps
+        names = {i: lib.vad_prof_slot_name(0, i).decode() for i in lf}
+    else:
+        lf = {1: conv3x3_flops(hw // 2, hw // 2, 32, 64), 2: conv3x3_flops(hw // 4, hw // 4, 64, 128), 3: conv3x3_flops(hw // 8, hw // 8, 128, 128)}
+        frames = per_gpu * t * steps
+        names = {i: lib.vad_prof_slot_name(1, i).decode() for i in lf}
+    w_ms = sum(ms[i] for i in lf)
+    direct_flop = sum(lf.values()) * frames
+    layers = {names[i]: {"ms": round(ms[i] / max(cnt[i], 1), 4),
+                         "direct_equivalent_tflops": round(lf[i] * frames / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else None} for i in lf}
+    ach = direct_flop * 16.0 / 36.0 / (w_ms * 1e-3) / 1e12 if w_ms > 0 else 0.0
+    return {"roofline": {"bound": "mfma", "kernel": "conv3x3_wino_pkernel (fp32 32x32x2 MFMA; all launches)", "achieved": round(ach, 2),
+                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                         "flops": "executed matrix FLOPs = 16/36 of the direct-convolution FLOPs of these layers",
+                         "direct_equivalent_tflops": round(direct_flop / (w_ms * 1e-3) / 1e12, 2) if w_ms > 0 else None,
+                         "launches": sum(cnt[i] for i in lf), "ms": round(w_ms / steps, 3)},
+            "layers": layers}
 
 
 # Algorithmic work of the kernel groups of one training step (vad_prof_slot_name(2, .)), per 256x256 frame of a T = 10 clip of
@@ -669,6 +714,24 @@ def video_config2(vad, hip, lib, dev, hw, steps, warmup, with_cpu, clips=64, t=1
            "roofline": roofline, "layers": layers}
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(vad, state, "video", t, scores, seed, hw)
+    # the opt-in Winograd mode on the same clips (the encoder's 3x3 convolutions; the ConvLSTM cell stays direct)
+    exact = scores.clone()
+    model.precision = "winograd"
+    with torch.no_grad():
+        for _ in range(max(1, warmup)):
+            scores = model.get_reconstruction_error(x, per_frame=True)
+        torch.cuda.synchronize(dev)
+        lib.vad_prof_reset()
+        lib.vad_prof_enable(1)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            scores = model.get_reconstruction_error(x, per_frame=True)
+        torch.cuda.synchronize(dev)
+        el2 = time.perf_counter() - t1
+        lib.vad_prof_enable(0)
+    out["winograd_precision"] = dict({"value": round(clips * t * steps / el2, 1), "unit": "frames/s", "ms_per_step": round(el2 / steps * 1e3, 3),
+                                      "max_rel_score_diff_vs_exact_fp32": float(((scores - exact).abs() / exact.abs()).max()),
+                                      "speedup_vs_direct": round(elapsed / el2, 3)}, **winograd_roofline(hip, lib, "video", hw, clips, steps, t))
     del model, x
     torch.cuda.empty_cache()
     return out

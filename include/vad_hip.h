@@ -52,6 +52,13 @@ extern "C" {
  *      states, parameters, parameter gradients, loss and Adam stay fp32.  Layer entry points that take `precision` read /
  *      write bf16 tensors through their `float*` arguments in this mode (element strides stay in elements). */
 #define VAD_PREC_BF16S 3
+/*   VAD_PREC_WINO  Winograd F(2x2,3x3), scoring only, OPT-IN (`model.precision = "winograd"`): every 3x3 convolution behind
+ *                  the first layer computes a 2x2 block of outputs from 16 instead of 36 products per input channel
+ *                  (csrc/conv_wino.hip) on the exact-fp32 matrix pipe - all-fp32 arithmetic, but another rounding order than the
+ *                  direct form, so NOT bit-identical to VAD_PREC_FP32 (scores differ by ~1e-6 relative; every parity gate
+ *                  holds at 1e-5).  Everything else (first layer, transposed convolutions, tails, ConvLSTM cell) is the
+ *                  VAD_PREC_FP32 arithmetic.  bench.py's `value` is always VAD_PREC_FP32. */
+#define VAD_PREC_WINO 4
 
 int vad_abi_version(void);
 const char* vad_last_error(void);   /* per thread */

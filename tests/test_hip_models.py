@@ -372,6 +372,66 @@ def test_split_precision_mode_holds_parity(vad, golden):
     assert rel_err(s2.cpu().numpy(), g["scores"]) < SCORE_RTOL and torch.equal(s2, s3)
 
 
+def test_winograd_mode_holds_parity(vad, golden):
+    """Opt-in Winograd arithmetic (`model.precision = "winograd"` -> VAD_PREC_WINO: every 3x3 convolution behind the first
+    layer as F(2x2,3x3) on the exact-fp32 MFMA, csrc/conv_wino.hip).  All-fp32 but another rounding order than the direct
+    kernels, so not bit-identical to them; every score gate of the exact path must hold at the same 1e-5: the reference's golden
+    vectors on random weights (latent 256 and a latent the channel tiling pads), the trained-model gate on raw uint8 frames
+    (scores, ranking, AUROC), configs[0]'s 64 scores, and the ConvLSTM video model (its encoder's convolutions)."""
+    for name in ("img_l256_64.npz", "img_l100_32.npz", "img_c1_l24_32.npz"):
+        g = golden(name)
+        cin = in_channels_of(g)
+        m, _ = _img_model(vad, int(g["latent_dim"]), int(g["wseed"]), cin)
+        x = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, int(g["n"]), cin, int(g["hw"]), int(g["hw"]))).cuda()
+        with torch.no_grad():
+            exact = m.score_all(x)
+            m.precision = "winograd"
+            out = m.score_all(x)
+            lat = m.get_latent(x)
+        assert rel_err(out["scores"].cpu().numpy(), g["scores"]) < SCORE_RTOL, name
+        assert max_abs(out["recon"].cpu().numpy(), g["recon"]) < ACT_ATOL and max_abs(out["errmap"].cpu().numpy(), g["errmap"]) < ACT_ATOL
+        assert max_abs(lat.cpu().numpy(), g["latent"]) < 2e-4
+        assert not torch.equal(out["recon"], exact["recon"])                    # it IS other arithmetic, and says so
+    t = golden("img_trained_l64.npz")
+    mt = vad.ConvAutoencoder(in_channels=3, latent_dim=64)
+    mt.load_state_dict({k[2:]: torch.from_numpy(t[k]) for k in t.files if k.startswith("w.")}, strict=True)
+    mt = mt.cuda().eval()
+    mt.precision = "winograd"
+    with torch.no_grad():
+        s = mt.get_reconstruction_error(torch.from_numpy(t["test_u8"]).cuda()).cpu().numpy()
+    assert rel_err(s, t["scores"]) < SCORE_RTOL
+    assert np.array_equal(np.argsort(s), np.argsort(t["scores"]))
+    assert vad.scoring.roc_auc(t["labels"], s) == pytest.approx(float(t["auroc"]), abs=1e-12)
+    a = golden("auroc_cfg0.npz")
+    ma, _ = _img_model(vad, 256, int(a["wseed"]))
+    ma.precision = "winograd"
+    with torch.no_grad():                                                        # batches of 16, evaluate.py:240
+        sa = torch.cat([ma.get_reconstruction_error(vad.scoring.synth_frames_device(int(a["seed"]), i, 16, anomalies=int(a["patch"])))
+                        for i in range(0, 64, 16)]).cpu().numpy()
+    assert rel_err(sa, a["scores"]) < SCORE_RTOL
+    for name in ("vid_default_64.npz", "vid_l48_h96_32.npz"):
+        v = golden(name)
+        mv, _ = _vid_model(vad, int(v["latent_dim"]), int(v["hid"]), int(v["layers"]), int(v["wseed"]))
+        mv.precision = "winograd"
+        xv = torch.from_numpy(vad.synth.clips(int(v["xseed"]), 0, int(v["b"]), int(v["t"]), 3, int(v["hw"]), int(v["hw"]))).cuda()
+        with torch.no_grad():
+            ov = mv.score_all(xv)
+        assert rel_err(ov["frame"].cpu().numpy(), v["frame"]) < SCORE_RTOL, name
+        assert rel_err(ov["seq"].cpu().numpy(), v["seq"]) < SCORE_RTOL
+        assert max_abs(ov["recon"].cpu().numpy(), v["recon"]) < ACT_ATOL
+    # frame-independence holds in this mode too: a frame's score does not depend on its batch or position
+    g = golden("img_l256_64.npz")
+    m, _ = _img_model(vad, 256, int(g["wseed"]))
+    m.precision = "winograd"
+    xs = vad.scoring.synth_frames_device(21, 0, 37, 64, 64)
+    with torch.no_grad():
+        whole = m.get_reconstruction_error(xs)
+        m.chunk = 5
+        parts = m.get_reconstruction_error(xs)
+        single = torch.cat([m.get_reconstruction_error(xs[i:i + 1]) for i in (0, 17, 36)])
+    assert torch.equal(whole, parts) and torch.equal(single, whole[[0, 17, 36]])
+
+
 def test_two_threads_with_different_precision_do_not_interfere(vad):
     """SURVEY.md section 8(b) threading contract (the reference's UI calls one global model from worker threads,
     main.py:50,274): an exact-fp32 model and a split-fp16 model scored CONCURRENTLY from two Python threads on two

@@ -187,8 +187,10 @@ class ConvAutoencoder(nn.Module):
     #: configs[1] in one group - every launch has a ramp-up and a tail, and 16 launches per step instead of 64 measured +1.1 %
     #: (64 / 128 / 256 / 512 frames per group: 16.13 / 16.39 / 16.54 / 16.57 k frames/s)
     chunk = 512
-    #: "fp32" = exact fp32 MFMA (default, the parity path); "split" = 3 x fp16 MFMA with fp32 accumulate (opt-in,
-    #: 22-bit products; see include/vad_hip.h VAD_PREC_SPLIT).  Per model: the mode travels with every call as an argument
+    #: "fp32" = exact fp32 MFMA, direct convolutions (default, the parity path); "split" = 3 x fp16 MFMA with fp32 accumulate
+    #: (opt-in, 22-bit products; include/vad_hip.h VAD_PREC_SPLIT); "winograd" = the 3x3 convolutions behind the first layer as
+    #: Winograd F(2x2,3x3) on the exact-fp32 MFMA (opt-in: all-fp32 arithmetic, 16 instead of 36 products per 2x2 outputs, not
+    #: bit-identical to "fp32"; VAD_PREC_WINO).  Per model: the mode travels with every call as an argument
     precision = "fp32"
 
     def __init__(self, in_channels: int = 3, latent_dim: int = 256):
@@ -210,7 +212,7 @@ class ConvAutoencoder(nn.Module):
         l = hip.lib()
         mode = hip.precision_mode(self.precision)
         if mode in (hip.PREC_BF16, hip.PREC_BF16S):
-            raise hip.VadError("precision 'bf16' / 'bf16_operands' / 'bf16_tensors' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32' or 'split'")
+            raise hip.VadError("precision 'bf16' / 'bf16_operands' / 'bf16_tensors' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32', 'split' or 'winograd'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_img_packed_floats(3, self.latent_dim) if 1 <= self.in_channels <= 3 else 0

@@ -42,7 +42,9 @@ static void bn_scale_shift(const float* bias, const float* const* bn, int cout,
 }
 
 // The arithmetic mode is an ARGUMENT of every packer and launcher (ABI 2): there is no process-wide switch.
-#define REQ_PREC(who) REQ(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, who ": precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision)
+#define REQ_PREC(who) REQ(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT || precision == VAD_PREC_WINO, who ": precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1) or VAD_PREC_WINO (4)", precision)
+// arithmetic of everything that is not a Winograd 3x3 convolution in VAD_PREC_WINO blobs
+static int base_prec(int precision) { return precision == VAD_PREC_WINO ? VAD_PREC_FP32 : precision; }
 
 extern "C" size_t vad_pack_conv3x3_floats(int cout, int cin) { return (size_t)9 * ((cin + 7) / 8) * cout * 8; }
 
@@ -67,6 +69,7 @@ extern "C" int vad_pack_conv3x3(const float* w, const float* bias, const float* 
                                 int cout, int cin, int precision, float* out, float* bias_out) {
     REQ(w && out && bias_out && cout > 0 && cin > 0, "pack_conv3x3: bad arguments");
     REQ_PREC("pack_conv3x3");
+    REQ(precision != VAD_PREC_WINO, "pack_conv3x3: the Winograd form of a layer is packed by vad_pack_conv3x3_wino");
     REQ(precision != VAD_PREC_SPLIT || cin % 16 == 0, "pack_conv3x3: split precision needs cin %% 16 == 0 (got %d)", cin);
     std::vector<double> s;
     bn_scale_shift(bias, bn, cout, s, bias_out);
@@ -140,6 +143,7 @@ extern "C" int vad_pack_convt2x2(const float* w, const float* bias, const float*
                                  int cin, int cout, int precision, float* out, float* bias_out) {
     REQ(w && out && bias_out && cout > 0 && cin > 0 && cin % 8 == 0, "pack_convt2x2: bad arguments");
     REQ_PREC("pack_convt2x2");
+    REQ(precision != VAD_PREC_WINO, "pack_convt2x2: transposed convolutions have no Winograd form (pack them as VAD_PREC_FP32)");
     REQ(precision != VAD_PREC_SPLIT || cin % 16 == 0, "pack_convt2x2: split precision needs cin %% 16 == 0 (got %d)", cin);
     std::vector<double> s;
     bn_scale_shift(bias, bn, cout, s, bias_out);
@@ -237,15 +241,20 @@ const auto same = [](int c) { return c; };
 }  // namespace
 
 // conv3x3 / convT / conv1x1 whose real widths (cout, cin) sit in slots of (s.cout, s.cin) channels
+static int pack_conv3x3_any(const float* w, const float* b, const float* const* bn, int cout, int cin, int precision, float* wo, float* bo) {
+    if (precision == VAD_PREC_WINO) return vad_pack_conv3x3_wino(w, b, bn, cout, cin, wo, bo);     // U = G g G^T, 16 "taps"
+    return vad_pack_conv3x3(w, b, bn, cout, cin, precision, wo, bo);
+}
 static int pack_conv3x3_slot(const float* w, const float* b, const float* const* bn, int cout, int cin, const LayerSlot& s,
                              int precision, float* out) {
-    if (cout == s.cout && cin == s.cin) return vad_pack_conv3x3(w, b, bn, cout, cin, precision, out + s.w, out + s.b);
+    if (cout == s.cout && cin == s.cin) return pack_conv3x3_any(w, b, bn, cout, cin, precision, out + s.w, out + s.b);
     PaddedLayer P;
     pad_layer(w, b, bn, cout, cin, 9, false, s.cout, s.cin, same, same, P);
-    return vad_pack_conv3x3(P.w.data(), P.bias.data(), bn ? P.bn : nullptr, s.cout, s.cin, precision, out + s.w, out + s.b);
+    return pack_conv3x3_any(P.w.data(), P.bias.data(), bn ? P.bn : nullptr, s.cout, s.cin, precision, out + s.w, out + s.b);
 }
 static int pack_convt2x2_slot(const float* w, const float* b, const float* const* bn, int cin, int cout, const LayerSlot& s,
                               int precision, float* out) {
+    precision = base_prec(precision);
     if (cout == s.cout && cin == s.cin) return vad_pack_convt2x2(w, b, bn, cin, cout, precision, out + s.w, out + s.b);
     PaddedLayer P;
     pad_layer(w, b, bn, cout, cin, 4, true, s.cout, s.cin, same, same, P);
@@ -272,6 +281,10 @@ extern "C" int vad_blob_precision(const float* packed_host) {
     return (int)((h[1] >> 8) & 0xff);
 }
 
+// A 3x3 layer's slot holds either form of its weights: direct [9][cin/8][cout][8] or Winograd [16][cin/8][cout][8]
+// (VAD_PREC_WINO blobs); one layout for every arithmetic mode keeps the size queries of the C ABI mode-free.
+static size_t conv3x3_slot_floats(int cout, int cin) { return vad_pack_conv3x3_wino_floats(cout, cin); }
+
 ImgLayout img_layout(int latent_real) {
     ImgLayout L{};
     const int latent = L.latent_p = vad_img_latent_p(latent_real);
@@ -286,13 +299,13 @@ ImgLayout img_layout(int latent_real) {
     };
     for (int b = 0; b < 4; ++b) {   // encoder blocks (models/autoencoder.py:38-79)
         if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
-        else add(LK_CONV, ch[b], ch[b + 1], vad_pack_conv3x3_floats(ch[b + 1], ch[b]));
-        add(LK_CONV, ch[b + 1], ch[b + 1], vad_pack_conv3x3_floats(ch[b + 1], ch[b + 1]));
+        else add(LK_CONV, ch[b], ch[b + 1], conv3x3_slot_floats(ch[b + 1], ch[b]));
+        add(LK_CONV, ch[b + 1], ch[b + 1], conv3x3_slot_floats(ch[b + 1], ch[b + 1]));
     }
     const int dch[5] = {latent, 128, 64, 32, 32};
     for (int b = 0; b < 4; ++b) {   // decoder blocks (models/autoencoder.py:103-139)
         add(LK_CONVT, dch[b], dch[b + 1], vad_pack_convt2x2_floats(dch[b], dch[b + 1]));
-        if (b < 3) add(LK_CONV, dch[b + 1], dch[b + 1], vad_pack_conv3x3_floats(dch[b + 1], dch[b + 1]));
+        if (b < 3) add(LK_CONV, dch[b + 1], dch[b + 1], conv3x3_slot_floats(dch[b + 1], dch[b + 1]));
         else add(LK_TAIL_CONV, 32, 3, vad_pack_conv3x3_to3_floats(32));
     }
     L.nlayers = li;
@@ -356,7 +369,7 @@ VidLayout vid_layout(int latent_real, int hid_real, int layers) {
     const int ch[5] = {3, 32, 64, 128, latent};
     for (int b = 0; b < 4; ++b) {   // VideoEncoder (models/video_autoencoder.py:191-215)
         if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
-        else add(LK_CONV, ch[b], ch[b + 1], vad_pack_conv3x3_floats(ch[b + 1], ch[b]));
+        else add(LK_CONV, ch[b], ch[b + 1], conv3x3_slot_floats(ch[b + 1], ch[b]));
     }
     for (int l = 0; l < layers; ++l) {   // ConvLSTM cells (models/video_autoencoder.py:118-125)
         const int cin = (l == 0 ? latent : hid) + hid;
@@ -412,11 +425,11 @@ extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int 
             rc = pack_convt2x2_slot(w, b, bn, li == first_convt ? latent : s.cin, s.cout, s, precision, out); pi += 6; break;
         case LK_LSTM: {   // weight (4*hid, x + hid, 3, 3): gate blocks i,f,g,o and the x / h input halves are padded separately
             const int xr = (li == 4) ? latent : hid, xp = (li == 4) ? L.latent_p : L.hid_p, hp = L.hid_p;
-            if (xr == xp && hid == hp) { rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 2; break; }
+            if (xr == xp && hid == hp) { rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, base_prec(precision), out + s.w, out + s.b); pi += 2; break; }
             PaddedLayer Q;
             pad_layer(w, b, nullptr, 4 * hid, xr + hid, 9, false, s.cout, s.cin,
                       [=](int co) { return (co / hid) * hp + co % hid; }, [=](int ci) { return ci < xr ? ci : xp + (ci - xr); }, Q);
-            rc = vad_pack_conv3x3(Q.w.data(), Q.bias.data(), nullptr, s.cout, s.cin, precision, out + s.w, out + s.b); pi += 2; break; }
+            rc = vad_pack_conv3x3(Q.w.data(), Q.bias.data(), nullptr, s.cout, s.cin, base_prec(precision), out + s.w, out + s.b); pi += 2; break; }
         case LK_PROJ: {
             if (latent == s.cout && hid == s.cin) { rc = vad_pack_conv1x1(w, b, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break; }
             PaddedLayer Q;

@@ -120,7 +120,15 @@ extern "C" int vad_graph_destroy(void* exec) {
 
 static std::atomic<int> g_vad_tail_group{0};   // debug: frames per dec4.0 -> tail sub-group (0 = the whole launch group)
 extern "C" int vad_debug_set_tail_group(int frames) { g_vad_tail_group = frames; return VAD_OK; }
-#define REQ_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, who ": precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", precision)
+#define REQ_PREC(who) VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT || precision == VAD_PREC_WINO, who ": precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1) or VAD_PREC_WINO (4)", precision)
+
+// A 3x3 convolution behind the first layer in the model's arithmetic mode: VAD_PREC_WINO blobs hold the Winograd form of these
+// layers (csrc/conv_wino.hip); every other kernel of such a model runs the VAD_PREC_FP32 arithmetic (`bprec`).
+static int conv3x3_mode(const float* in, const float* w, const float* bias, float* out, int n, int h, int wd, int cin, int cout, int act, int pool,
+                        int precision, hipStream_t s) {
+    if (precision == VAD_PREC_WINO) return vad_conv3x3_wino(in, 0, w, bias, out, 0, n, h, wd, cin, cout, act, pool, s);
+    return vad_conv3x3(in, 0, w, bias, out, 0, n, h, wd, cin, cout, act, pool, precision, s);
+}
 
 static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -183,6 +191,7 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
     const bool need_decoder = scores || errmap || recon;
     const int ch[5] = {3, 32, 64, 128, latent};
     const int dch[5] = {latent, 128, 64, 32, 32};
+    const int bprec = precision == VAD_PREC_WINO ? VAD_PREC_FP32 : precision;   // arithmetic of the kernels that are not 3x3 convolutions
 #define W_(i) (packed + L.layer[i].w)
 #define B_(i) (packed + L.layer[i].b)
 
@@ -191,13 +200,18 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
         const char* xin = x + (size_t)f0 * 3 * h * w * xelem;
         int hh = h, ww = w;
         // encoder: 4 x [conv-BN-LeakyReLU, conv-BN-LeakyReLU-MaxPool] (models/autoencoder.py:38-79)
-        { VadProfScope ps(1, s); TRY(vad_conv3x3_c3_fused_fmt(xin, x_format, W_(0), B_(0), W_(1), B_(1), B, n, hh, ww, precision, s)); }
+        if (precision == VAD_PREC_WINO) {   // first layer on its own (K = 27: nothing to gain from Winograd), then enc1.3 + pool in Winograd form
+            { VadProfScope ps(0, s); TRY(vad_conv3x3_c3_fmt(xin, x_format, W_(0), B_(0), A, n, hh, ww, 32, VAD_ACT_LEAKY, 0, s)); }
+            { VadProfScope ps(1, s); TRY(conv3x3_mode(A, W_(1), B_(1), B, n, hh, ww, 32, 32, VAD_ACT_LEAKY, 1, precision, s)); }
+        } else {
+            VadProfScope ps(1, s); TRY(vad_conv3x3_c3_fused_fmt(xin, x_format, W_(0), B_(0), W_(1), B_(1), B, n, hh, ww, precision, s));
+        }
         for (int blk = 1; blk < 4; ++blk) {
             hh /= 2; ww /= 2;
             { VadProfScope ps(2 * blk, s);
-              TRY(vad_conv3x3(B, 0, W_(2 * blk), B_(2 * blk), A, 0, n, hh, ww, ch[blk], ch[blk + 1], VAD_ACT_LEAKY, 0, precision, s)); }
+              TRY(conv3x3_mode(B, W_(2 * blk), B_(2 * blk), A, n, hh, ww, ch[blk], ch[blk + 1], VAD_ACT_LEAKY, 0, precision, s)); }
             { VadProfScope ps(2 * blk + 1, s);
-              TRY(vad_conv3x3(A, 0, W_(2 * blk + 1), B_(2 * blk + 1), B, 0, n, hh, ww, ch[blk + 1], ch[blk + 1], VAD_ACT_LEAKY, 1, precision, s)); }
+              TRY(conv3x3_mode(A, W_(2 * blk + 1), B_(2 * blk + 1), B, n, hh, ww, ch[blk + 1], ch[blk + 1], VAD_ACT_LEAKY, 1, precision, s)); }
         }
         hh /= 2; ww /= 2;   // B = latent code [n, H/16, W/16, latent]
         if (latent_out) {
@@ -208,10 +222,10 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
         // decoder: 3 x [convT-BN-ReLU, conv-BN-ReLU] + [convT-BN-ReLU, conv-Tanh] (models/autoencoder.py:103-139)
         for (int blk = 0; blk < 3; ++blk) {
             { VadProfScope ps(8 + 2 * blk, s);
-              TRY(vad_convt2x2(B, 0, W_(8 + 2 * blk), B_(8 + 2 * blk), A, 0, n, hh, ww, dch[blk], dch[blk + 1], VAD_ACT_RELU, precision, s)); }
+              TRY(vad_convt2x2(B, 0, W_(8 + 2 * blk), B_(8 + 2 * blk), A, 0, n, hh, ww, dch[blk], dch[blk + 1], VAD_ACT_RELU, bprec, s)); }
             hh *= 2; ww *= 2;
             { VadProfScope ps(9 + 2 * blk, s);
-              TRY(vad_conv3x3(A, 0, W_(9 + 2 * blk), B_(9 + 2 * blk), B, 0, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, precision, s)); }
+              TRY(conv3x3_mode(A, W_(9 + 2 * blk), B_(9 + 2 * blk), B, n, hh, ww, dch[blk + 1], dch[blk + 1], VAD_ACT_RELU, 0, precision, s)); }
         }
         // dec4.0 + dec4.3 + score: ONE kernel, the 8.4 MB per frame map between the two layers never exists in memory
         // (dec4_fused.hip), in BOTH arithmetic modes: these layers are HBM-bound, so the split mode keeps them exact fp32
@@ -328,7 +342,10 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
             const float* packed, void* ws, size_t ws_bytes, int chunk, float* seq_scores, float* frame_scores,
             float* errmap, float* recon, hipStream_t s, const char* who) {
     VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "%s: unknown input format %d", who, x_format);
-    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT, "%s: precision=%d must be VAD_PREC_FP32 (0) or VAD_PREC_SPLIT (1)", who, precision);
+    VAD_REQUIRE(precision == VAD_PREC_FP32 || precision == VAD_PREC_SPLIT || precision == VAD_PREC_WINO, "%s: precision=%d must be VAD_PREC_FP32 (0), VAD_PREC_SPLIT (1) or VAD_PREC_WINO (4)", who, precision);
+    const int mprec = precision;                                                  // the blob's mode (device-side tag check)
+    const bool wino = precision == VAD_PREC_WINO;
+    if (wino) precision = VAD_PREC_FP32;                                          // everything but the encoder's 3x3 convolutions
     const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
     const char* x = (const char*)xv;
     const VidWs Z = vid_ws(chunk, t, cs, h, w, latent_real, hid_real, layers);
@@ -366,9 +383,9 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         // VideoEncoder: 4 x conv-BN-LeakyReLU-MaxPool on the flattened frames
         // (models/video_autoencoder.py:191-215, :222-228)
         { VadProfScope ps(0, s); TRY(vad_conv3x3_c3_fmt(xin, x_format, W_(0), B_(0), A, nf, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
-        { VadProfScope ps(1, s); TRY(vad_conv3x3(A, 0, W_(1), B_(1), Bf, 0, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, precision, s)); }
-        { VadProfScope ps(2, s); TRY(vad_conv3x3(Bf, 0, W_(2), B_(2), A, 0, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, precision, s)); }
-        { VadProfScope ps(3, s); TRY(vad_conv3x3(A, 0, W_(3), B_(3), E, 0, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, precision, s)); }
+        { VadProfScope ps(1, s); TRY(conv3x3_mode(A, W_(1), B_(1), Bf, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, mprec, s)); }
+        { VadProfScope ps(2, s); TRY(conv3x3_mode(Bf, W_(2), B_(2), A, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, mprec, s)); }
+        { VadProfScope ps(3, s); TRY(conv3x3_mode(A, W_(3), B_(3), E, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, mprec, s)); }
         // ConvLSTM, zero initial state (models/video_autoencoder.py:144-166).  Step (l, t) needs (l, t-1) and (l-1, t) only.
         const long long fs_zx = (long long)h16 * w16 * 4 * hid;
         // x halves ahead of the recurrence (small launch groups, exact fp32): a step's accumulator chain runs over the x chunks
@@ -464,7 +481,7 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
             VadProfScope ps(10, s);
             TRY(vad_score_finalize_tagged(parts, nparts, n, h, w, frame_scores ? frame_scores + (size_t)c0 * t : nullptr,
                                           seq_scores ? seq_scores + c0 : nullptr, t, (const unsigned*)packed,
-                                          vad_blob_tag(VAD_BLOB_VID, precision), s));
+                                          vad_blob_tag(VAD_BLOB_VID, mprec), s));
         }
     }
 #undef W_

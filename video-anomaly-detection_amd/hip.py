@@ -20,12 +20,14 @@ SOURCES = ["conv_mfma.hip", "conv_wino.hip", "dec4_fused.hip", "tail.hip", "ssim
 
 VAD_OK = 0
 ABI_VERSION = 3
-PREC_FP32, PREC_SPLIT, PREC_BF16, PREC_BF16S = 0, 1, 2, 3
+PREC_FP32, PREC_SPLIT, PREC_BF16, PREC_BF16S, PREC_WINO = 0, 1, 2, 3, 4
 # bf16 modes: training entry points only.  "bf16_operands" = bf16 MFMA operands converted from fp32 tensors; "bf16_tensors" =
 # the activation / gradient tensors themselves are bf16 in HBM (VAD_PREC_BF16S, video training step only)
 # "bf16" is an alias of "bf16_tensors" EVERYWHERE (BASELINE.json configs[4]'s dtype); a trainer without a bf16-tensor form
 # (ImageTrainer) rejects it by name instead of quietly running other arithmetic under the same string.
-PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16S, "bf16_operands": PREC_BF16, "bf16_tensors": PREC_BF16S}
+# "winograd" (scoring only, opt-in): the 3x3 convolutions behind the first layer as Winograd F(2x2,3x3) on the exact-fp32 MFMA
+PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16S, "bf16_operands": PREC_BF16, "bf16_tensors": PREC_BF16S,
+              "winograd": PREC_WINO}
 
 
 def training_precision(name: str, trainer: str, tensors: bool) -> str:

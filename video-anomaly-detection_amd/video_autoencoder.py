@@ -125,7 +125,7 @@ class VideoAutoencoder(nn.Module):
 
     #: clips per launch group
     chunk = 64
-    #: "fp32" (default) or "split": see ConvAutoencoder.precision
+    #: "fp32" (default), "split" or "winograd" (the encoder's 3x3 convolutions; the ConvLSTM cell stays direct): see ConvAutoencoder.precision
     precision = "fp32"
 
     def __init__(self, in_channels: int = 3, latent_dim: int = 128, lstm_hidden_dim: int = 128,
@@ -155,7 +155,7 @@ class VideoAutoencoder(nn.Module):
         l = hip.lib()
         mode = hip.precision_mode(self.precision)
         if mode in (hip.PREC_BF16, hip.PREC_BF16S):
-            raise hip.VadError("precision 'bf16' / 'bf16_operands' / 'bf16_tensors' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32' or 'split'")
+            raise hip.VadError("precision 'bf16' / 'bf16_operands' / 'bf16_tensors' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32', 'split' or 'winograd'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
             n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
