@@ -431,14 +431,25 @@ def winograd_roofline(hip, lib, kind, hw, per_gpu, steps, t):
         frames = per_gpu * steps
         names = {i: lib.vad_prof_slot_name(0, i).decode() for i in lf}
     else:
-        lf = {1: conv3x3_flops(hw // 2, hw // 2, 32, 64), 2: conv3x3_flops(hw // 4, hw // 4, 64, 128), 3: conv3x3_flops(hw // 8, hw // 8, 128, 128)}
+        # slot 4: the ConvLSTM steps (gate convolution in Winograd form + the pointwise cell launch); per frame: 2 layers x one
+        # 256 -> 512 convolution on the 16x16 map, the h half of K skipped at t = 0
+        h16 = hw // 16
+        lf = {1: conv3x3_flops(hw // 2, hw // 2, 32, 64), 2: conv3x3_flops(hw // 4, hw // 4, 64, 128), 3: conv3x3_flops(hw // 8, hw // 8, 128, 128),
+              4: conv3x3_flops(h16, h16, 256, 512) * 2 * (t - 0.5) / t}
         frames = per_gpu * t * steps
         names = {i: lib.vad_prof_slot_name(1, i).decode() for i in lf}
     w_ms = sum(ms[i] for i in lf)
     direct_flop = sum(lf.values()) * frames
-    layers = {names[i]: {"ms": round(ms[i] / max(cnt[i], 1), 4),
+    layers = {names[i]: {"ms": round(ms[i] / steps, 4),
                          "direct_equivalent_tflops": round(lf[i] * frames / (ms[i] * 1e-3) / 1e12, 1) if ms[i] > 0 else None} for i in lf}
     ach = direct_flop * 16.0 / 36.0 / (w_ms * 1e-3) / 1e12 if w_ms > 0 else 0.0
+    model_id = 0 if kind == "image" else 1
+    for i in range(hip.PROF_SLOTS):          # the launches of the step that are not Winograd convolutions, for the whole picture
+        nm = lib.vad_prof_slot_name(model_id, i).decode()
+        if cnt[i] and nm not in layers:
+            layers[nm] = {"ms": round(ms[i] / steps, 4)}
+    for i in lf:
+        layers[names[i]]["ms"] = round(ms[i] / steps, 4)
     return {"roofline": {"bound": "mfma", "kernel": "conv3x3_wino_pkernel (fp32 32x32x2 MFMA; all launches)", "achieved": round(ach, 2),
                          "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
                          "flops": "executed matrix FLOPs = 16/36 of the direct-convolution FLOPs of these layers",

@@ -121,6 +121,12 @@ int vad_pack_conv3x3_wino(const float* w_oihw, const float* bias, const float* c
 int vad_conv3x3_wino(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,
                      float* out_nhwc, long long out_fs, int n, int h, int w, int cin, int cout,
                      int act, int pool, void* stream);
+/* One ConvLSTMCell step (models/video_autoencoder.py:54-85) with the gate convolution in Winograd form: arguments as
+ * vad_convlstm_step, w_packed = vad_pack_conv3x3_wino of the (4*hid, cin_x+hid, 3, 3) weight, cin_x == hid, plus
+ * z_ws = n*h*w*4*hid floats of scratch for the gate pre-activations (the cell is a second, pointwise launch). */
+int vad_convlstm_step_wino(const float* x, long long x_fs, const float* h_prev, long long h_prev_fs, const float* c_prev,
+                           const float* w_packed, const float* bias, float* h_out, long long h_out_fs, float* c_out,
+                           float* z_ws, int n, int h, int w, int cin_x, int hid, void* stream);
 
 /* NHWC ConvTranspose2d k2 s2 + bias + act: [N,H,W,Cin] -> [N,2H,2W,Cout]. */
 int vad_convt2x2(const float* in_nhwc, long long in_fs, const float* w_packed, const float* bias,

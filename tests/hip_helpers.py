@@ -66,6 +66,28 @@ def conv3x3_wino(x_nchw, w, b, bn=None, act=0, pool=False):
     return to_nchw(out)
 
 
+def convlstm_step_wino(x_nchw, h_nchw, c_nchw, w, b):
+    """One ConvLSTMCell step with the gate convolution in Winograd form (h / c None = zero initial state) -> (h', c') NCHW."""
+    l = hip.lib()
+    n, cx, h, wd = x_nchw.shape
+    hid = w.shape[0] // 4
+    w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+    wp = np.empty(l.vad_pack_conv3x3_wino_floats(4 * hid, cx + hid), np.float32)
+    bo = np.empty(4 * hid, np.float32)
+    hip.check(l.vad_pack_conv3x3_wino(w.ctypes.data, b.ctypes.data, None, 4 * hid, cx + hid, wp.ctypes.data, bo.ctypes.data))
+    wp, bo = dev(wp), dev(bo)
+    xin = nhwc(x_nchw)
+    hp = nhwc(h_nchw) if h_nchw is not None else None
+    cp = nhwc(c_nchw) if c_nchw is not None else None
+    ho = torch.full((n, h, wd, hid), float("nan"), device="cuda")
+    co = torch.full((n, h, wd, hid), float("nan"), device="cuda")
+    z = torch.empty(n * h * wd * 4 * hid, device="cuda")
+    hip.check(l.vad_convlstm_step_wino(xin.data_ptr(), 0, hip.ptr(hp), 0, hip.ptr(cp), wp.data_ptr(), bo.data_ptr(), ho.data_ptr(), 0,
+                                       co.data_ptr(), z.data_ptr(), n, h, wd, cx, hid, stream()))
+    torch.cuda.synchronize()
+    return to_nchw(ho), to_nchw(co)
+
+
 def pack_convt(w, b, bn=None):
     l = hip.lib()
     cin, cout = w.shape[:2]

@@ -178,6 +178,27 @@ def test_convlstm_step_oracle(cx, hid, h, w, zero_state):
     assert max_abs(gh, rh) < 2e-5 and max_abs(gc, rc) < 2e-5
 
 
+@pytest.mark.parametrize("n,hid,h,w,zero_state", [(2, 128, 16, 16, False), (2, 128, 16, 16, True), (3, 64, 6, 10, False), (70, 64, 4, 4, False),
+                                                  (1, 64, 2, 2, True)])
+def test_convlstm_step_winograd(n, hid, h, w, zero_state):
+    """ConvLSTMCell step with the gate convolution as ONE two-source Winograd launch (x and h halves of K; the h half skipped at
+    t = 0) + the pointwise cell (vad_convlstm_step_wino; VAD_PREC_WINO models): against the oracle at the direct kernels' bound,
+    and against the direct fused step."""
+    import hip_helpers as H
+    rng = _rng(n + hid + h + 5)
+    x = rng.standard_normal((n, hid, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((4 * hid, 2 * hid, 3, 3)) * np.sqrt(1.0 / (2 * hid * 9))).astype(np.float32)
+    b = (rng.standard_normal(4 * hid) * 0.1).astype(np.float32)
+    hp = None if zero_state else (rng.standard_normal((n, hid, h, w)) * 0.5).astype(np.float32)
+    cp = None if zero_state else rng.standard_normal((n, hid, h, w)).astype(np.float32)
+    zeros = np.zeros((n, hid, h, w), np.float32)
+    rh, rc = c_oracle.convlstm_cell(x, hp if hp is not None else zeros, cp if cp is not None else zeros, wt, b)
+    gh, gc = H.convlstm_step_wino(x, hp, cp, wt, b)
+    assert np.isfinite(gh).all() and max_abs(gh, rh) < 2e-5 and max_abs(gc, rc) < 2e-5
+    dh, dc = H.convlstm_step(x, hp, cp, wt, b)
+    assert max_abs(gh, dh) < 2e-5 and max_abs(gc, dc) < 2e-5
+
+
 @pytest.mark.parametrize("n,cx,hid,h,w,zero_state", [(2, 128, 128, 16, 16, False), (3, 64, 64, 5, 9, False), (1, 32, 64, 3, 4, False),
                                                      (2, 128, 128, 16, 16, True), (5, 128, 64, 7, 18, False)])
 def test_convlstm_small_grid_kernel_is_bit_identical(vad, n, cx, hid, h, w, zero_state):

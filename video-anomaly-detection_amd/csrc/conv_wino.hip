@@ -29,7 +29,9 @@
 #define MFMA32W(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 struct ConvWP {
-    const float* in;  long long in_fs;     // NHWC fp32 [n][h][w][cin], frame stride in floats
+    const float* in;  long long in_fs;     // NHWC fp32 [n][h][w][cin_a], frame stride in floats: input channels [0, cin_a)
+    const float* in2; long long in2_fs;    // channels [cin_a, cin) (the h half of a ConvLSTM step; NULL: the layer has cin_a channels)
+    int cin_a;
     const float* w;                        // vad_pack_conv3x3_wino: [16][cin/8][cout][8]
     const float* bias;                     // [cout] (BatchNorm folded)
     float* out;       long long out_fs;    // NHWC [n][h or h/2][w or w/2][cout]
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
     const int cb = L % p.cblocks; L /= p.cblocks;
     const int x0 = (L % p.tiles_x) * 16, y0 = (L / p.tiles_x) * 8;
     const int H = p.h, W = p.w_;
-    const int nch = p.cin / CK;
+    const int nch_a = p.cin_a / CK;
+    const int nch = (p.in2 ? p.cin : p.cin_a) / CK;     // in2 == NULL with cin > cin_a: the missing channels are zeros (ConvLSTM at t = 0), skipped
 
     // ---- staging slots (input tile + 1-pixel halo, NHWC chunk of 32 channels): slot i = float4 number tid + 256 i
     unsigned svo[NPF];
@@ -69,13 +72,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
         const int ly = pix / LW, lx = pix - ly * LW;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
         const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        svo[i] = ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, p.cin) + c4 * 4) * 4u : VAD_OOB;
+        svo[i] = ok ? (unsigned)(__mul24(__mul24(gy, W) + gx, p.cin_a) + c4 * 4) * 4u : VAD_OOB;
     }
-    const unsigned in_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u;
+    // both sources of a two-source launch have the same channel count (host-checked), so svo serves both
+    const unsigned in_bytes = (unsigned)(H * W) * (unsigned)p.cin_a * 4u;
     f32x4 pf[NPF];
 #define ISSUE(n_, ch_)                                                                                   \
     {                                                                                                    \
-        const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(p.in + (size_t)(n_) * p.in_fs + (ch_) * CK, in_bytes - (unsigned)(ch_) * CK * 4u); \
+        const float* src_ = ((ch_) < nch_a) ? p.in + (size_t)(n_) * p.in_fs + (ch_) * CK                 \
+                                            : p.in2 + (size_t)(n_) * p.in2_fs + ((ch_) - nch_a) * CK;    \
+        const unsigned skip_ = (unsigned)(((ch_) < nch_a) ? (ch_) : (ch_) - nch_a) * CK * 4u;            \
+        const __amdgpu_buffer_rsrc_t r_ = vad_rsrc(src_, in_bytes - skip_);                              \
         _Pragma("unroll") for (int i_ = 0; i_ < NPF; ++i_) pf[i_] = vad_bload4(r_, svo[i_], 0);          \
     }
 
@@ -125,28 +132,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bv[nt]));
 
-    while (true) {
-        f32x16 acc[4][NT];
-#pragma unroll
-        for (int fc = 0; fc < 4; ++fc)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[fc][nt][r] = 0.f;
-        const int nn = n + fgroups;
-        const bool has_next = nn < p.n;
-
-        for (int ch = 0; ch < nch; ++ch) {
-            __syncthreads();                       // every wave is done reading the previous stage (tile or exchange records)
-#pragma unroll
-            for (int i = 0; i < NPF; ++i)
-                if (pix0 + 32 * i < NPIX) *(f32x4*)&tile[(pix0 + 32 * i) * PS + c4 * 4] = pf[i];
-            __syncthreads();
-            if (ch + 1 < nch) { ISSUE(n, ch + 1); }
-            else if (has_next) { ISSUE(nn, 0); }
-
-            // V[fc][channel j of this lane's quad] of one 8-channel group: row combination, then the column transform
-            f32x4 v[2][4];
+    // One 32-channel chunk: publish the staged tile, request the next stage, 16 (k-group, fc) steps.  FIRST (a tile's first chunk):
+    // the first MFMA of every accumulator chain takes C = 0 as an inline constant - no accumulator is ever zeroed (128 v_mov per tile
+    // on the pipe the MFMAs use).
+    f32x16 acc[4][NT];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define COMPUTE_V(buf, kg)                                                                               \
     {                                                                                                    \
         f32x4 t_[4];                                                                                     \
@@ -160,27 +150,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
         v[buf][2] = t_[2] - t_[1];                                                                       \
         v[buf][3] = t_[1] - t_[3];                                                                       \
     }
-            COMPUTE_V(0, 0);
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                const int cur = kg & 1;
-#pragma unroll
-                for (int fc = 0; fc < 4; ++fc) {
-                    const int s = kg * 4 + fc, bcur = s % NB, bnxt = (s + PB) % NB;
-                    if (s + PB < NS) { LOAD_B(bnxt, ch, s + PB); }
-                    else if (ch + 1 < nch) { LOAD_B(bnxt, ch + 1, s + PB - NS); }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[fc][nt] = MFMA32W(v[cur][fc][j], b[bcur][nt][j], acc[fc][nt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (fc == 1 && kg + 1 < 4) { COMPUTE_V(cur ^ 1, kg + 1); }     // next group's A values under this group's MFMAs
-                }
-            }
-#undef COMPUTE_V
-        }
+#define CHUNK(FIRST, ch, n_, nn_, has_next_)                                                             \
+    {                                                                                                    \
+        __syncthreads();                       /* every wave is done reading the previous stage (tile or exchange records) */ \
+        _Pragma("unroll") for (int i = 0; i < NPF; ++i)                                                  \
+            if (pix0 + 32 * i < NPIX) *(f32x4*)&tile[(pix0 + 32 * i) * PS + c4 * 4] = pf[i];             \
+        __syncthreads();                                                                                 \
+        if ((ch) + 1 < nch) { ISSUE(n_, (ch) + 1); }                                                     \
+        else if (has_next_) { ISSUE(nn_, 0); }                                                           \
+        f32x4 v[2][4];                         /* V[fc][channel j of this lane's quad] of one 8-channel group */ \
+        COMPUTE_V(0, 0);                                                                                 \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) {                                               \
+            const int cur = kg & 1;                                                                      \
+            _Pragma("unroll") for (int fc = 0; fc < 4; ++fc) {                                           \
+                const int s_ = kg * 4 + fc, bcur = s_ % NB, bnxt = (s_ + PB) % NB;                       \
+                if (s_ + PB < NS) { LOAD_B(bnxt, ch, s_ + PB); }                                         \
+                else if ((ch) + 1 < nch) { LOAD_B(bnxt, (ch) + 1, s_ + PB - NS); }                       \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+                        acc[fc][nt] = MFMA32W(v[cur][fc][j], b[bcur][nt][j], ((FIRST) && kg == 0 && j == 0) ? zero16 : acc[fc][nt]); \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                if (fc == 1 && kg + 1 < 4) { COMPUTE_V(cur ^ 1, kg + 1); }   /* next group's A values under this group's MFMAs */ \
+            }                                                                                            \
+        }                                                                                                \
+    }
+
+    while (true) {
+        const int nn = n + fgroups;
+        const bool has_next = nn < p.n;
+        CHUNK(1, 0, n, nn, has_next);
+        for (int ch = 1; ch < nch; ++ch) CHUNK(0, ch, n, nn, has_next);
 
         // ---- output transform, column half (over fc) in registers: P0 = M0 + M1 + M2, P1 = M1 - M2 - M3
         f32x16 P[2][NT];
@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
     }
 #undef ISSUE
 #undef LOAD_B
+#undef CHUNK
+#undef COMPUTE_V
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -284,6 +286,8 @@ static int launch_wino_nt(const ConvWP& p, int act, int pool, hipStream_t s) {
     return VAD_OK;
 }
 
+#define TRYW(call) do { int rc_ = (call); if (rc_ != VAD_OK) return rc_; } while (0)
+
 // include/vad_hip.h: vad_conv3x3_wino
 extern "C" int vad_conv3x3_wino(const float* in, long long in_fs, const float* w, const float* bias, float* out, long long out_fs,
                                 int n, int h, int wd, int cin, int cout, int act, int pool, void* stream) {
@@ -296,7 +300,7 @@ extern "C" int vad_conv3x3_wino(const float* in, long long in_fs, const float* w
     VAD_REQUIRE((long long)h * wd * chmax * 4 < (1ll << 31) && 16ll * cin * cout * 4 < (1ll << 31),
                 "conv3x3_wino: frame %dx%dx%lld or weights %dx%d too large for 32-bit offsets", h, wd, chmax, cin, cout);
     ConvWP p{};
-    p.in = in; p.in_fs = in_fs ? in_fs : (long long)h * wd * cin;
+    p.in = in; p.in_fs = in_fs ? in_fs : (long long)h * wd * cin; p.cin_a = cin;
     p.w = w; p.bias = bias; p.out = out;
     const int ho = pool ? h / 2 : h, wo = pool ? wd / 2 : wd;
     p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
@@ -306,4 +310,67 @@ extern "C" int vad_conv3x3_wino(const float* in, long long in_fs, const float* w
     p.cblocks = cout / (two ? 64 : 32);
     VAD_REQUIRE((long long)p.tiles_x * p.tiles_y * p.cblocks < (1ll << 24), "conv3x3_wino: %d x %d x %d work-group positions out of range", p.tiles_x, p.tiles_y, p.cblocks);
     return two ? launch_wino_nt<2>(p, act, pool, (hipStream_t)stream) : launch_wino_nt<1>(p, act, pool, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ ConvLSTM step, Winograd form
+// ConvLSTMCell (reference models/video_autoencoder.py:54-85): cat([x, h]) -> Conv3x3(-> 4*hid, bias) -> i, f, g, o -> cell.  The
+// gate convolution runs as ONE Winograd launch over the two sources (x: channels [0, cin_x), h: [cin_x, cin_x + hid); at t = 0
+// the h half is zeros and skipped) writing the pre-activations z [n][h][w][4*hid] (bias added); the cell is a pointwise pass
+// (vad_lstm_cell of vad_common.h: the one every fused form uses).  z costs 2 x 2 KB per pixel of HBM traffic per step: ~10 % of
+// the step at 64 clips - the price of keeping every accumulator of a hidden channel's four gates out of one wave.
+struct CellP {
+    const float* z; const float* c_prev; float* c_out; float* h_out;
+    long long h_fs;        // frame stride of h_out in floats
+    int hw, hid;           // pixels per frame, hidden channels
+    long long total;       // n * hw * hid / 4
+};
+
+__global__ __launch_bounds__(256) void wino_lstm_cell_kernel(CellP p) {
+    const int hq = p.hid >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < p.total; idx += (long long)gridDim.x * 256) {
+        const long long pix = idx / hq;
+        const int c4 = (int)(idx - pix * hq) * 4;
+        const long long n = pix / p.hw;
+        const int q = (int)(pix - n * p.hw);
+        const float* z = p.z + pix * 4 * p.hid + c4;
+        const f32x4 zi = *(const f32x4*)z, zf = *(const f32x4*)(z + p.hid), zg = *(const f32x4*)(z + 2 * p.hid), zo = *(const f32x4*)(z + 3 * p.hid);
+        const f32x4 cp = p.c_prev ? *(const f32x4*)(p.c_prev + pix * p.hid + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 cn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float c1, h1;
+            vad_lstm_cell(zi[e], zf[e], zg[e], zo[e], cp[e], c1, h1);
+            cn[e] = c1; hn[e] = h1;
+        }
+        *(f32x4*)(p.c_out + pix * p.hid + c4) = cn;
+        *(f32x4*)(p.h_out + n * p.h_fs + (long long)q * p.hid + c4) = hn;
+    }
+}
+
+// include/vad_hip.h: vad_convlstm_step_wino.  z_ws: n*h*w*4*hid floats of scratch.
+extern "C" int vad_convlstm_step_wino(const float* x, long long x_fs, const float* h_prev, long long h_prev_fs, const float* c_prev,
+                                      const float* w, const float* bias, float* h_out, long long h_out_fs, float* c_out, float* z_ws,
+                                      int n, int h, int wd, int cin_x, int hid, void* stream) {
+    VAD_REQUIRE(x && w && bias && h_out && c_out && z_ws, "convlstm_step_wino: null pointer");
+    VAD_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), "convlstm_step_wino: h_prev and c_prev must both be given or both NULL");
+    VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && h % 2 == 0 && wd % 2 == 0, "convlstm_step_wino: bad shape %d x %dx%d (even H, W)", n, h, wd);
+    VAD_REQUIRE(cin_x > 0 && hid > 0 && hid % 16 == 0 && cin_x % 32 == 0 && cin_x == hid,
+                "convlstm_step_wino: cin_x=%d and hid=%d must be equal multiples of 32 (one set of staging offsets serves both sources)", cin_x, hid);
+    const int cin = cin_x + hid, cout = 4 * hid;
+    VAD_REQUIRE((long long)h * wd * cout * 4 < (1ll << 31) && 16ll * cin * cout * 4 < (1ll << 31), "convlstm_step_wino: frame or weights too large for 32-bit offsets");
+    ConvWP p{};
+    p.in = x; p.in_fs = x_fs ? x_fs : (long long)h * wd * cin_x; p.cin_a = cin_x;
+    p.in2 = h_prev; p.in2_fs = h_prev_fs ? h_prev_fs : (long long)h * wd * hid;
+    p.w = w; p.bias = bias; p.out = z_ws; p.out_fs = (long long)h * wd * cout;
+    p.n = n; p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout;
+    p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 7) / 8; p.cblocks = cout / 64;
+    TRYW(launch_wino_nt<2>(p, VAD_ACT_NONE, 0, (hipStream_t)stream));
+    CellP c{};
+    c.z = z_ws; c.c_prev = c_prev; c.c_out = c_out; c.h_out = h_out;
+    c.h_fs = h_out_fs ? h_out_fs : (long long)h * wd * hid;
+    c.hw = h * wd; c.hid = hid; c.total = (long long)n * h * wd * (hid / 4);
+    const long long blocks = (c.total + 255) / 256;
+    hipLaunchKernelGGL(wino_lstm_cell_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, c);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
 }

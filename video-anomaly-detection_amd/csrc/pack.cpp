@@ -373,7 +373,7 @@ VidLayout vid_layout(int latent_real, int hid_real, int layers) {
     }
     for (int l = 0; l < layers; ++l) {   // ConvLSTM cells (models/video_autoencoder.py:118-125)
         const int cin = (l == 0 ? latent : hid) + hid;
-        add(LK_LSTM, cin, 4 * hid, vad_pack_conv3x3_floats(4 * hid, cin));
+        add(LK_LSTM, cin, 4 * hid, conv3x3_slot_floats(4 * hid, cin));
     }
     L.has_proj = hid_real != latent_real;          // models/video_autoencoder.py:311-312
     if (L.has_proj) add(LK_PROJ, hid, latent, vad_pack_conv1x1_floats(latent, hid));
@@ -425,11 +425,14 @@ extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int 
             rc = pack_convt2x2_slot(w, b, bn, li == first_convt ? latent : s.cin, s.cout, s, precision, out); pi += 6; break;
         case LK_LSTM: {   // weight (4*hid, x + hid, 3, 3): gate blocks i,f,g,o and the x / h input halves are padded separately
             const int xr = (li == 4) ? latent : hid, xp = (li == 4) ? L.latent_p : L.hid_p, hp = L.hid_p;
-            if (xr == xp && hid == hp) { rc = vad_pack_conv3x3(w, b, nullptr, s.cout, s.cin, base_prec(precision), out + s.w, out + s.b); pi += 2; break; }
+            // VAD_PREC_WINO: the gate convolution in Winograd form when both sources have one width (vad_convlstm_step_wino's
+            // requirement; vid_run makes the same test), else the direct form
+            const int lprec = (precision == VAD_PREC_WINO && xp == hp) ? VAD_PREC_WINO : base_prec(precision);
+            if (xr == xp && hid == hp) { rc = pack_conv3x3_any(w, b, nullptr, s.cout, s.cin, lprec, out + s.w, out + s.b); pi += 2; break; }
             PaddedLayer Q;
             pad_layer(w, b, nullptr, 4 * hid, xr + hid, 9, false, s.cout, s.cin,
                       [=](int co) { return (co / hid) * hp + co % hid; }, [=](int ci) { return ci < xr ? ci : xp + (ci - xr); }, Q);
-            rc = vad_pack_conv3x3(Q.w.data(), Q.bias.data(), nullptr, s.cout, s.cin, base_prec(precision), out + s.w, out + s.b); pi += 2; break; }
+            rc = pack_conv3x3_any(Q.w.data(), Q.bias.data(), nullptr, s.cout, s.cin, lprec, out + s.w, out + s.b); pi += 2; break; }
         case LK_PROJ: {
             if (latent == s.cout && hid == s.cin) { rc = vad_pack_conv1x1(w, b, s.cout, s.cin, out + s.w, out + s.b); pi += 2; break; }
             PaddedLayer Q;

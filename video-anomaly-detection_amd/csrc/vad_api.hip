@@ -274,7 +274,7 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
 // models/video_autoencoder.py:144-145).
 namespace {
 struct VidWs {
-    size_t act, enc, hseq, cst, proj, parts, zx0, zxl, total;
+    size_t act, enc, hseq, cst, proj, parts, zx0, zxl, zw, total;
 };
 // work-groups of one ConvLSTM step in the large (32x32x2) tiling: below one per CU the layers run as a wavefront on helper
 // streams and the steps' x halves are computed ahead of the recurrence
@@ -295,7 +295,8 @@ VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_re
     const bool small = vid_lstm_groups(chunk, h / 16, w / 16, hid) < 256;
     z.zx0 = small ? up256(sizeof(float) * nf * p16 * 4 * hid) : 0;
     z.zxl = small ? up256(sizeof(float) * n * p16 * 4 * hid) : 0;
-    z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst) + z.proj + z.parts + z.zx0 + (size_t)(layers - 1) * z.zxl;   // h sequence + cell state per layer
+    z.zw = up256(sizeof(float) * (size_t)chunk * p16 * 4 * hid);   // VAD_PREC_WINO: one step's gate pre-activations (vad_convlstm_step_wino)
+    z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst) + z.proj + z.parts + z.zx0 + (size_t)(layers - 1) * z.zxl + z.zw;   // h sequence + cell state per layer
     return z;
 }
 
@@ -369,6 +370,7 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         ZX[0] = (float*)base; base += Z.zx0;
         for (int l = 1; l < layers; ++l) { ZX[l] = (float*)base; base += Z.zxl; }
     }
+    float* ZW = (float*)base; base += Z.zw;
     const int nparts = vad_score_partials(1, h, w);
     const int h16 = h / 16, w16 = w / 16;
     const long long fs_lat = (long long)h16 * w16 * latent, fs_hid = (long long)h16 * w16 * hid;
@@ -393,7 +395,11 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         // (per source frame: overlapping windows share it) and per step for the layers above, stored as fp32 and resumed by
         // the step kernel - bit-identical, and the serial K loop of a step halves (models/video_autoencoder.py:67-70 multiplies
         // cat([x, h]) inside the recurrence).
-        const bool hoist = precision == VAD_PREC_FP32 && ZX[0] && vad_convlstm_hoist_ok();
+        // VAD_PREC_WINO: every step's gate convolution in Winograd form (both sources of every layer have one width), whatever
+        // the launch group's size - the arithmetic of a model never depends on the batch
+        // (layer 0 stays direct when latent_dim and lstm_hidden_dim pad to different widths - the packer makes the same test)
+        auto wino_layer = [&](int l) { return wino && (l > 0 || latent == hid); };
+        const bool hoist = !wino && precision == VAD_PREC_FP32 && ZX[0] && vad_convlstm_hoist_ok();
         bool hoist_upper = hoist;
         auto lstm_step = [&](int l, int ti, hipStream_t st) -> int {
             const float* xin_l = (l == 0) ? E : HS[l - 1];
@@ -401,6 +407,10 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
             const long long clip_in = (l == 0) ? (long long)cs * fs_lat : (long long)t * fs_hid;   // layer 0 reads the shared features
             const long long clip_zx = (l == 0) ? (long long)cs * fs_zx : (long long)t * fs_zx;
             VadProfScope ps(4, st);
+            if (wino_layer(l))
+                return vad_convlstm_step_wino(xin_l + (size_t)ti * fs_in, clip_in, ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
+                                              ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l), HS[l] + (size_t)ti * fs_hid, (long long)t * fs_hid, CS[l], ZW,
+                                              nc, h16, w16, hid, hid, st);
             return vad_convlstm_step_zx(xin_l + (size_t)ti * fs_in, clip_in, (hoist && (l == 0 || hoist_upper)) ? ZX[l] + (size_t)ti * fs_zx : nullptr, clip_zx,
                                         ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
                                         ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l),
@@ -422,7 +432,7 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         const long long lstm_groups = vid_lstm_groups(nc, h16, w16, hid);
         const int wf = g_vad_lstm_wavefront.load(std::memory_order_relaxed);
         if (hoist) TRY(lstm_xhalf(0, -1, s));
-        if (layers > 1 && ((lstm_groups < 256 && wf) || wf == 2)) {
+        if (layers > 1 && !wino && ((lstm_groups < 256 && wf) || wf == 2)) {   // (Winograd steps share ONE z buffer: layers strictly in order)
             // per-step x halves of the layers above 0 (a helper-stream launch and two event hops per step) pay while a step is a
             // long serial K loop; with the gate-split kernel (one window: ~11 us per step) they cost more than they save - measured
             // 0.78 -> 0.70 ms for one 16-frame window, 1.05 -> 0.97 for two clips - so those steps run their whole K loop

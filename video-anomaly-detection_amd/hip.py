@@ -126,6 +126,7 @@ SIGNATURES = {
     "vad_pack_conv3x3_wino_floats": (_sz, [_i, _i]),
     "vad_pack_conv3x3_wino": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "vad_conv3x3_wino": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_convlstm_step_wino": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vad_conv1x1": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "vad_convlstm_step": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vad_score_partials": (_i, [_i, _i, _i]),
