@@ -44,11 +44,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
     constexpr int CK = 32, LW = 18, LH = 10, PS = CK + 4, NPIX = LW * LH;
     constexpr int TOT = NPIX * (CK / 4), NPF = (TOT + 255) / 256;
     constexpr int XF = 4 * 2 * NT * 64 * 16;                        // exchange floats
-    constexpr int SMEM = (NPIX * PS > XF) ? NPIX * PS : XF;
+    // TWO input tiles (chunk c is read from tile c & 1 while chunk c + 1 is written to the other): one barrier per chunk instead
+    // of two.  The exchange records alias both.
+    constexpr int TILE_F = NPIX * PS;
+    constexpr int SMEM = (2 * TILE_F > XF) ? 2 * TILE_F : XF;
     constexpr int NS = 16;                                          // (k-group, fc) steps per 32-channel chunk
     constexpr int PB = 1, NB = 2;                                   // B ring: PB steps ahead, NB register sets (NS % NB == 0)
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    float* tile = smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -137,31 +139,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
     // on the pipe the MFMAs use).
     f32x16 acc[4][NT];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#define COMPUTE_V(buf, kg)                                                                               \
+    // A operands of one 8-channel group: the two patch rows this wave's frequency row needs are REQUESTED one group ahead (8
+    // ds_read_b128 into `raw`, issued in front of the previous group's 16*NT MFMAs, so their latency passes under ~2,000 cycles of
+    // matrix work) and TRANSFORMED between two groups' MFMAs (32 VALU instructions: the row combination d[ia] + sgn d[ib], then the
+    // column transform; fp32 VALU work does not overlap with fp32 MFMAs anyway).
+#define LOAD_RAW(kg)                                                                                     \
+    {                                                                                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                               \
+            raw[0][j_] = *(const f32x4*)&tile_[rowa + j_ * PS + (kg) * 8];                               \
+            raw[1][j_] = *(const f32x4*)&tile_[rowb + j_ * PS + (kg) * 8];                               \
+        }                                                                                                \
+    }
+#define TRANSFORM_V()                                                                                    \
     {                                                                                                    \
         f32x4 t_[4];                                                                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                               \
-            const f32x4 da_ = *(const f32x4*)&tile[rowa + j_ * PS + (kg) * 8];                           \
-            const f32x4 db_ = *(const f32x4*)&tile[rowb + j_ * PS + (kg) * 8];                           \
-            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[j_][e_] = __builtin_fmaf(sgn, db_[e_], da_[e_]); \
-        }                                                                                                \
-        v[buf][0] = t_[0] - t_[2];                                                                       \
-        v[buf][1] = t_[1] + t_[2];                                                                       \
-        v[buf][2] = t_[2] - t_[1];                                                                       \
-        v[buf][3] = t_[1] - t_[3];                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) t_[j_][e_] = __builtin_fmaf(sgn, raw[1][j_][e_], raw[0][j_][e_]); \
+        v[0] = t_[0] - t_[2];                                                                            \
+        v[1] = t_[1] + t_[2];                                                                            \
+        v[2] = t_[2] - t_[1];                                                                            \
+        v[3] = t_[1] - t_[3];                                                                            \
     }
 #define CHUNK(FIRST, ch, n_, nn_, has_next_)                                                             \
     {                                                                                                    \
-        __syncthreads();                       /* every wave is done reading the previous stage (tile or exchange records) */ \
+        /* the tile this chunk is written to was last read two chunks ago (a barrier lies between), or held exchange records \
+           whose readers have passed the barrier that ends the epilogue */                               \
+        float* tile_ = smem + (((ch) & 1) ? TILE_F : 0);                                                 \
         _Pragma("unroll") for (int i = 0; i < NPF; ++i)                                                  \
-            if (pix0 + 32 * i < NPIX) *(f32x4*)&tile[(pix0 + 32 * i) * PS + c4 * 4] = pf[i];             \
+            if (pix0 + 32 * i < NPIX) *(f32x4*)&tile_[(pix0 + 32 * i) * PS + c4 * 4] = pf[i];            \
         __syncthreads();                                                                                 \
+        f32x4 raw[2][4], v[4];                 /* v[fc][channel j of this lane's quad] */                \
+        LOAD_RAW(0);                                                                                     \
         if ((ch) + 1 < nch) { ISSUE(n_, (ch) + 1); }                                                     \
         else if (has_next_) { ISSUE(nn_, 0); }                                                           \
-        f32x4 v[2][4];                         /* V[fc][channel j of this lane's quad] of one 8-channel group */ \
-        COMPUTE_V(0, 0);                                                                                 \
+        TRANSFORM_V();                                                                                   \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) {                                               \
-            const int cur = kg & 1;                                                                      \
+            if (kg + 1 < 4) { LOAD_RAW(kg + 1); }                                                        \
             _Pragma("unroll") for (int fc = 0; fc < 4; ++fc) {                                           \
                 const int s_ = kg * 4 + fc, bcur = s_ % NB, bnxt = (s_ + PB) % NB;                       \
                 if (s_ + PB < NS) { LOAD_B(bnxt, ch, s_ + PB); }                                         \
@@ -169,10 +182,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
                     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
-                        acc[fc][nt] = MFMA32W(v[cur][fc][j], b[bcur][nt][j], ((FIRST) && kg == 0 && j == 0) ? zero16 : acc[fc][nt]); \
+                        acc[fc][nt] = MFMA32W(v[fc][j], b[bcur][nt][j], ((FIRST) && kg == 0 && j == 0) ? zero16 : acc[fc][nt]); \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
-                if (fc == 1 && kg + 1 < 4) { COMPUTE_V(cur ^ 1, kg + 1); }   /* next group's A values under this group's MFMAs */ \
             }                                                                                            \
+            if (kg + 1 < 4) { TRANSFORM_V(); }                                                           \
         }                                                                                                \
     }
 
@@ -239,11 +252,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
         }
         if (!has_next) break;
         n = nn;
+        __syncthreads();                           // every wave has read its records: the next tile may overwrite them
     }
 #undef ISSUE
 #undef LOAD_B
 #undef CHUNK
-#undef COMPUTE_V
+#undef LOAD_RAW
+#undef TRANSFORM_V
 }
 
 // ------------------------------------------------------------------------------------------------ host side
