@@ -836,6 +836,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     // B fragments + bias: ONE register set, (re)loaded only when the channel tile changes - once per work-group for every
     // reference layer.  (Without restrict the compiler cannot hoist loads out of the tile loop past the stores.)
     float b[14], bv = 0.f;
+    f32x16 bias16;              // bv in every register: the C operand of a tile's first k-step
     int have = -1;
     // BatchNorm statistics of the training forward, taken from the accumulators instead of a second pass over the 8.4 MB per
     // frame this kernel has just written: two levels (per tile, then per work-group) so that a lane never adds more than 64 +
@@ -877,6 +878,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
 #pragma unroll
                 for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
                 bv = p.bias[co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bias16[r] = bv;
                 have = nt;
                 // retire these loads HERE, inside the branch: left pending, hipcc guards the first MFMA below with a
                 // vmcnt(0) that runs on every tile - and, vmcnt being in order, drains the next tile's prefetch issued just
@@ -885,11 +888,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                 for (int s = 0; s < 14; ++s) asm volatile("" ::"v"(b[s]));
                 asm volatile("" ::"v"(bv));
             }
+            // (the accumulators are never initialised: the FIRST k-step takes the bias splat `bias16` as its C operand - the same
+            // arithmetic as starting from the bias, without 64 v_mov per tile on the pipe the MFMAs use)
             f32x16 acc[MTW];
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][r] = bv;
             // A operands through a two-deep register pipeline (4 LDS values per k-step), fenced per step: left alone the
             // compiler hoists all 56 reads of a tile into registers and spills
             const int abase = (2 * wave * MTW + prow) * RS + pcol;
@@ -904,41 +905,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) acc[mt] = MFMA32(av[s & 1][mt], b[s], acc[mt]);
+                for (int mt = 0; mt < MTW; ++mt) acc[mt] = MFMA32(av[s & 1][mt], b[s], s == 0 ? bias16 : acc[mt]);
             }
             float ts = 0.f, tq = 0.f;        // this tile's share of the statistics
+            // The epilogue in TWO copies behind ONE scalar branch: `full` is wave-uniform, but written as `if (!full) vo = ...` per
+            // store hipcc if-converted it - 2 v_cmp + 2 v_cndmask in front of every one of the 64 stores of a tile, ~8 of the
+            // kernel's ~13 VALU instructions per MFMA, on the pipe the exact-fp32 MFMAs use (profiles/r04_pmc_insts_winograd_image.txt).
+            auto epilogue = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
+                for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (POOL) {
-                        // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one activation
-                        // per window instead of four; vad_vmax = one v_max_f32 (fmaxf adds a canonicalising max per operand)
-                        const float m = vad_act(vad_vmax(vad_vmax(acc[mt][4 * q], acc[mt][4 * q + 1]), vad_vmax(acc[mt][4 * q + 2], acc[mt][4 * q + 3])), ACT);
-                        // lane part (column half, channel) + scalar part (row, column pair); a window outside the pooled image
-                        // (partial tiles only) gets the out-of-range offset and the store is dropped
-                        unsigned vo = lanepart;
-                        if (!full) vo = ((oy0 + mt) < oh && (ox0 + 2 * q + lh) < ow) ? lanepart : VAD_OOB;
-                        vad_bstore1(m, rout, vo, ubase + (unsigned)mt * orow + (unsigned)(2 * q) * ocol);
-                    } else {
-                        // un-pooled (training forward): the window's four pixels (dy = pos >> 1, dx = pos & 1) at column 4q + 2 lh + dx
-#pragma unroll
-                        for (int pos = 0; pos < 4; ++pos) {
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (POOL) {
+                            // MaxPool2d(act(.)) == act(MaxPool2d(.)) bit for bit (ReLU / LeakyReLU are non-decreasing): one activation
+                            // per window instead of four; vad_vmax = one v_max_f32 (fmaxf adds a canonicalising max per operand)
+                            const float m = vad_act(vad_vmax(vad_vmax(acc[mt][4 * q], acc[mt][4 * q + 1]), vad_vmax(acc[mt][4 * q + 2], acc[mt][4 * q + 3])), ACT);
+                            // lane part (column half, channel) + scalar part (row, column pair); a window outside the pooled image
+                            // (partial tiles only) gets the out-of-range offset and the store is dropped
                             unsigned vo = lanepart;
-                            if (!full) vo = ((oy0 + 2 * mt + (pos >> 1)) < oh && (ox0 + 4 * q + 2 * lh + (pos & 1)) < ow) ? lanepart : VAD_OOB;
-                            if constexpr (OUT16) vad_bstore_h(vad_f_bf16(acc[mt][4 * q + pos]), rout, vo,
-                                                              ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
-                            else vad_bstore1(vad_act(acc[mt][4 * q + pos], ACT), rout, vo,
-                                             ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
-                            if (p.stats) {   // (uniform)
-                                const float d = (full || vo != VAD_OOB) ? acc[mt][4 * q + pos] - bv : 0.f;
-                                ts += d;
-                                tq = fmaf(d, d, tq);
+                            if constexpr (!FULL) vo = ((oy0 + mt) < oh && (ox0 + 2 * q + lh) < ow) ? lanepart : VAD_OOB;
+                            vad_bstore1(m, rout, vo, ubase + (unsigned)mt * orow + (unsigned)(2 * q) * ocol);
+                        } else {
+                            // un-pooled (training forward): the window's four pixels (dy = pos >> 1, dx = pos & 1) at column 4q + 2 lh + dx
+#pragma unroll
+                            for (int pos = 0; pos < 4; ++pos) {
+                                unsigned vo = lanepart;
+                                if constexpr (!FULL) vo = ((oy0 + 2 * mt + (pos >> 1)) < oh && (ox0 + 4 * q + 2 * lh + (pos & 1)) < ow) ? lanepart : VAD_OOB;
+                                if constexpr (OUT16) vad_bstore_h(vad_f_bf16(acc[mt][4 * q + pos]), rout, vo,
+                                                                  ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
+                                else vad_bstore1(vad_act(acc[mt][4 * q + pos], ACT), rout, vo,
+                                                 ubase + (unsigned)(2 * mt + (pos >> 1)) * orow + (unsigned)(4 * q + (pos & 1)) * ocol);
                             }
                         }
                     }
                 }
-            }
+                // the statistics of the training forward (un-activated launches only) in a pass of their own behind ONE uniform
+                // branch per tile - tested per element the branch sat in front of every store; same terms, same order
+                if constexpr (!POOL && ACT == VAD_ACT_NONE) {
+                    if (p.stats) {
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int pos = 0; pos < 4; ++pos) {
+                                    const bool in = FULL || ((oy0 + 2 * mt + (pos >> 1)) < oh && (ox0 + 4 * q + 2 * lh + (pos & 1)) < ow);
+                                    const float d = in ? acc[mt][4 * q + pos] - bv : 0.f;
+                                    ts += d;
+                                    tq = fmaf(d, d, tq);
+                                }
+                    }
+                }
+            };
+            if (full) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
             st_s += ts;
             st_q += tq;
         }

@@ -512,13 +512,17 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
                 } else {
                 constexpr int TPW = (NT0 + 3) / 4;
                 f32x16 c0[TPW];
+                // bias0 in every register: the C operand of each chain's first k-step.  Built per tile (16 v_mov instead of the 48 that
+                // initialising three accumulators took; kept across tiles it cost the 16 registers that three work-groups per CU do
+                // not leave: 8 bytes of scratch inside the frame loop)
+                f32x16 bias16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bias16[r] = bias0;
                 int abase0[TPW];
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
                     const int q = (wave + 4 * u) * 32 + li, qc = q < NPIX ? q : NPIX - 1;
                     abase0[u] = (qc / LW) * XS + (qc % LW);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) c0[u][r] = bias0;
                 }
                 // the 14 k-steps in two halves: gather 7 x TPW A values, then their MFMAs (all 42 values at once cost 21 more
                 // live registers than three work-groups per CU leave, and hipcc spilled loop-carried offsets instead)
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256, (FUSE_C3 && !PREC) ? 3 : 2) void conv3x3_mfma_
 #pragma unroll
                     for (int s0 = 0; s0 < 7; ++s0)
 #pragma unroll
-                        for (int u = 0; u < TPW; ++u) c0[u] = MFMA32(av[u][s0], b0w[h0 + s0], c0[u]);
+                        for (int u = 0; u < TPW; ++u) c0[u] = MFMA32(av[u][s0], b0w[h0 + s0], (h0 + s0 == 0) ? bias16 : c0[u]);   // first k-step: C = the bias splat (no accumulator initialisation)
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
