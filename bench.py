@@ -467,7 +467,7 @@ TRAIN_GROUP_GFLOP = {"first layer fwd": 0.11325, "conv3x3 fwd": 1.50995, "ConvLS
                      "conv3x3 dgrad": 1.50995, "ConvLSTM conv dgrad": 1.20796, "convT / proj dgrad (1x1)": 0.16777,
                      "weight gradients": 1.50995 + 1.20796 + 0.16777 + 0.01258, "first layer wgrad": 0.11325}
 TRAIN_GROUP_MB_FP32 = {"BatchNorm fwd": 18.9 + 7.5, "BatchNorm bwd": (18.9 + 7.5) + (18.9 + 7.5 + 18.9)}
-TRAIN_PEAK_TFLOPS = {"fp32": 157.3, "split": 2500.0 / 3, "bf16": 2500.0}
+TRAIN_PEAK_TFLOPS = {"fp32": 157.3, "split": 2500.0 / 3, "bf16": 2500.0, "winograd": 157.3}
 
 
 def training_groups(vad, frames, hw, precision):
@@ -509,7 +509,7 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
     m = m.to(dev)
     x = vad.scoring.synth_frames_device(0xC0FFEE + 4, 0, clips * t, hw, hw, 3, dev).view(clips, t, 3, hw, hw)
     out = {"unit": "frames/s trained", "clips": clips, "t": t, "dtype": "f32"}
-    for precision in ("fp32", "split", "bf16"):  # all start from the same weights: a fresh trainer re-reads the module
+    for precision in ("fp32", "split", "bf16", "winograd"):  # all start from the same weights: a fresh trainer re-reads the module
         state = {k: v.detach().clone() for k, v in m.state_dict().items()}
         tr = vad.VideoTrainer(m, precision=precision)
         first = None
@@ -550,6 +550,12 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
         elif precision == "split":
             out["split_precision"] = dict(res, arithmetic="3x3 / transposed convolutions (forward + data gradients) on split-fp16 operands, "
                                                           "everything else fp32")
+        elif precision == "winograd":
+            # (the group rates are ALGORITHMIC, direct-convolution FLOPs: the Winograd groups execute 16/36 of them, so their
+            # `tflops` may exceed the 157.3 peak and `roofline.frac` is not an executed-FLOP fraction in this mode)
+            res["roofline"]["flops"] = "algorithmic (direct-convolution) FLOPs; the 3x3 forward / data-gradient groups execute 16/36 of them"
+            out["winograd_precision"] = dict(res, arithmetic="fp32 everywhere; the 3x3 convolutions behind the first layer (forward + data gradients, ConvLSTM gate "
+                                                             "convolutions included) as Winograd F(2x2,3x3) on the exact-fp32 MFMA; weight gradients direct")
         else:
             out["bf16_precision"] = dict(res, arithmetic="BASELINE configs[4] dtype: activation and activation-gradient tensors bf16 in HBM, every convolution / "
                                                          "weight-gradient GEMM behind the first layer on bf16 MFMA operands with fp32 accumulation; arithmetic inside "

@@ -68,6 +68,7 @@ def test_conv3x3(cin, cout, h, w, act, pool):
     (32, 32, 16, 16, 1, True, 2), (32, 32, 18, 22, 2, False, 3), (32, 64, 24, 40, 1, False, 2), (64, 64, 16, 32, 1, True, 5),
     (64, 128, 8, 8, 1, False, 2), (128, 128, 12, 20, 2, False, 2), (128, 256, 4, 4, 1, False, 7), (256, 256, 6, 10, 1, True, 2),
     (32, 96, 10, 10, 0, False, 2), (64, 192, 2, 6, 2, False, 2), (64, 64, 128, 128, 1, True, 3), (128, 128, 32, 32, 2, False, 9),
+    (64, 64, 5, 9, 1, False, 3), (128, 256, 3, 3, 0, False, 4), (32, 32, 7, 17, 2, False, 2), (256, 128, 1, 1, 0, False, 3),
 ])
 def test_conv3x3_winograd(cin, cout, h, w, act, pool, n):
     """Winograd F(2x2,3x3) on the exact-fp32 MFMA (opt-in arithmetic): the same layer as `test_conv3x3`, against the same
@@ -179,7 +180,7 @@ def test_convlstm_step_oracle(cx, hid, h, w, zero_state):
 
 
 @pytest.mark.parametrize("n,hid,h,w,zero_state", [(2, 128, 16, 16, False), (2, 128, 16, 16, True), (3, 64, 6, 10, False), (70, 64, 4, 4, False),
-                                                  (1, 64, 2, 2, True)])
+                                                  (1, 64, 2, 2, True), (2, 64, 3, 5, False), (3, 128, 7, 7, False)])
 def test_convlstm_step_winograd(n, hid, h, w, zero_state):
     """ConvLSTMCell step with the gate convolution as ONE two-source Winograd launch (x and h halves of K; the h half skipped at
     t = 0) + the pointwise cell (vad_convlstm_step_wino; VAD_PREC_WINO models): against the oracle at the direct kernels' bound,

@@ -419,6 +419,19 @@ def test_winograd_mode_holds_parity(vad, golden):
         assert rel_err(ov["frame"].cpu().numpy(), v["frame"]) < SCORE_RTOL, name
         assert rel_err(ov["seq"].cpu().numpy(), v["seq"]) < SCORE_RTOL
         assert max_abs(ov["recon"].cpu().numpy(), v["recon"]) < ACT_ATOL
+    # frames whose 16th is odd (48 x 80: 3 x 5 ConvLSTM maps, partial Winograd tiles) against the oracle, and dense windows ==
+    # per-window clips, bit for bit, in this mode
+    mo, sto = _vid_model(vad, 128, 128, 2, 13)
+    mo.precision = "winograd"
+    xo = torch.from_numpy(vad.synth.clips(31, 0, 2, 3, 3, 48, 80)).cuda()
+    with torch.no_grad():
+        oo = mo.score_all(xo)
+        fr = vad.scoring.synth_frames_device(32, 0, 7, 48, 80)
+        dense = mo.score_windows(fr, sequence_length=3, stride=2)
+        each = mo.score_seq_and_frames(torch.stack([fr[k:k + 3] for k in range(0, 5, 2)]))
+    ro = torch_oracle.vid_scores({k: torch.from_numpy(np.asarray(v)) for k, v in sto.items()}, xo.cpu(), 128, 2)
+    assert rel_err(oo["frame"].cpu().numpy(), ro["frame"].numpy()) < SCORE_RTOL and max_abs(oo["recon"].cpu().numpy(), ro["recon"].numpy()) < ACT_ATOL
+    assert torch.equal(dense["frame"], each["frame"]) and torch.equal(dense["seq"], each["seq"])
     # frame-independence holds in this mode too: a frame's score does not depend on its batch or position
     g = golden("img_l256_64.npz")
     m, _ = _img_model(vad, 256, int(g["wseed"]))

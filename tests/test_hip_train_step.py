@@ -174,9 +174,12 @@ def test_train_step_matches_autograd(vad, latent, layers, b, t, hw, wseed):
     assert np.abs(got - want).max() / np.abs(want).max() < 1e-3      # parameters differ by O(1e-6) after the steps
 
 
-def test_train_step_matches_reference_golden(vad, golden):
+@pytest.mark.parametrize("precision", ["fp32", "winograd"])
+def test_train_step_matches_reference_golden(vad, golden, precision):
     """The REFERENCE's VideoAutoencoder.train() + nn.MSELoss + torch.optim.Adam(lr 1e-4, weight_decay 1e-5), three
-    steps on one seeded batch (tests/golden/make_golden.py:train_fixture)."""
+    steps on one seeded batch (tests/golden/make_golden.py:train_fixture).  "winograd": the 3x3 convolutions (forward and data
+    gradients, the ConvLSTM gate convolutions included) as Winograd F(2x2,3x3) on the exact-fp32 MFMA - all-fp32 arithmetic, held
+    to the same bounds as the exact mode."""
     g = golden("train_vid_l32.npz")
     latent, layers, b, t, hw, wseed, xseed, steps = (int(g[k]) for k in ("latent", "layers", "b", "t", "hw", "wseed", "xseed", "steps"))
     x = torch.from_numpy(vad.synth.clips(xseed, 0, b, t, 3, hw, hw)).cuda()
@@ -184,7 +187,7 @@ def test_train_step_matches_reference_golden(vad, golden):
     load_synthetic(vad, m, wseed)
     init = {k: v.detach().clone().numpy() for k, v in m.state_dict().items()}
     m = m.cuda()
-    tr = vad.VideoTrainer(m, lr=LR, weight_decay=WD)
+    tr = vad.VideoTrainer(m, lr=LR, weight_decay=WD, precision=precision)
     loss0, _ = tr.forward_backward(x)
     keys = [str(k) for k in g["param_keys"]]
     got = {k: p.grad.detach().cpu().numpy().reshape(-1) for k, p in m.named_parameters()}
@@ -312,10 +315,12 @@ def _conditioned_float64(vad, latent, layers, wseed, x, decisions):
                                                         (32, 2, 2, 2, (48, 80), 45), (64, 2, 1, 3, (64, 32), 46),
                                                         ((32, 64), 2, 2, 3, 32, 48), ((64, 32), 1, 1, 3, 48, 49),
                                                         (32, 1, 1, 1, 16, 50), (32, 2, 1, 2, (16, 32), 51), (64, 2, 3, 1, 32, 52)])
-@pytest.mark.parametrize("precision", ["fp32", "split"])
+@pytest.mark.parametrize("precision", ["fp32", "split", "winograd"])
 def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, layers, b, t, hw, wseed, precision):
     """precision "split": the 3x3 / transposed convolutions (forward and data gradients) on split-fp16 operands (22-bit
-    products); same bounds - the mode is meant to be indistinguishable from fp32 at this level."""
+    products); same bounds - the mode is meant to be indistinguishable from fp32 at this level.  "winograd": the same
+    convolutions as Winograd F(2x2,3x3) in fp32 (odd map sizes included: frames of 48 / 80 / 112 give 3 / 5 / 7-pixel ConvLSTM
+    maps, whose last 2x2 tiles are partial)."""
     h, w = hw if isinstance(hw, tuple) else (hw, hw)          # non-square cases: H and W are carried separately everywhere
     x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, h, w))
     m = _make(vad, latent, layers)
@@ -348,7 +353,7 @@ def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, la
     print(f"[{precision},{latent},{layers},{b}x{t},{hw}] worst gradient deviation {worst:.2e}; differing decisions {[(s, n_, f'{mg:.1e}') for s, n_, mg, _ in report if n_]}")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "split", "bf16", "bf16_operands"])
+@pytest.mark.parametrize("precision", ["fp32", "split", "winograd", "bf16", "bf16_operands"])
 def test_loss_curve_follows_cpu_autograd_over_many_steps(vad, precision):
     """SURVEY.md section 8 row f-1 gate: the loss trajectory of the native step against the fp32 CPU restatement
     (train_video.py:44-65 semantics) over 25 Adam steps on one batch.  Individual parameters may wander by a few lr (see

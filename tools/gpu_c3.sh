@@ -16,7 +16,7 @@ v = d["video"]
 print("video direct", v["value"], v["ms_per_step"], {k: round(x["ms"] / x["launches"], 4) for k, x in v["layers"].items()})
 print("video winograd", v["winograd_precision"]["value"], v["winograd_precision"]["ms_per_step"], {k: x["ms"] for k, x in v["winograd_precision"]["layers"].items()})
 t = d["training_step"]
-for k in ("", "split_precision", "bf16_precision"):
+for k in ("", "split_precision", "bf16_precision", "winograd_precision"):
     r = t[k] if k else t
     print("train", k or "fp32", r["value"], r["ms_per_step"], {g: x["ms"] for g, x in r["roofline"]["groups"].items()})
 PY

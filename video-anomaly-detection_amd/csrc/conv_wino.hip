@@ -309,7 +309,7 @@ extern "C" int vad_conv3x3_wino(const float* in, long long in_fs, const float* w
     VAD_REQUIRE(in && w && bias && out, "conv3x3_wino: null pointer");
     VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "conv3x3_wino: bad shape n=%d h=%d w=%d", n, h, wd);
     VAD_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin > 0 && cout > 0, "conv3x3_wino: cin=%d cout=%d must be positive multiples of 32", cin, cout);
-    VAD_REQUIRE(h % 2 == 0 && wd % 2 == 0, "conv3x3_wino: 2x2 output tiles need even H, W (got %dx%d)", h, wd);
+    VAD_REQUIRE(!pool || (h % 2 == 0 && wd % 2 == 0), "conv3x3_wino: pooling needs even H, W (got %dx%d)", h, wd);   // (odd sizes: the last 2x2 tiles are partial)
     VAD_REQUIRE(act >= 0 && act <= 2, "conv3x3_wino: bad act %d", act);
     const long long chmax = cin > cout ? cin : cout;
     VAD_REQUIRE((long long)h * wd * chmax * 4 < (1ll << 31) && 16ll * cin * cout * 4 < (1ll << 31),
@@ -368,7 +368,7 @@ extern "C" int vad_convlstm_step_wino(const float* x, long long x_fs, const floa
                                       int n, int h, int wd, int cin_x, int hid, void* stream) {
     VAD_REQUIRE(x && w && bias && h_out && c_out && z_ws, "convlstm_step_wino: null pointer");
     VAD_REQUIRE((h_prev == nullptr) == (c_prev == nullptr), "convlstm_step_wino: h_prev and c_prev must both be given or both NULL");
-    VAD_REQUIRE(n > 0 && h > 0 && wd > 0 && h % 2 == 0 && wd % 2 == 0, "convlstm_step_wino: bad shape %d x %dx%d (even H, W)", n, h, wd);
+    VAD_REQUIRE(n > 0 && h > 0 && wd > 0, "convlstm_step_wino: bad shape %d x %dx%d", n, h, wd);
     VAD_REQUIRE(cin_x > 0 && hid > 0 && hid % 16 == 0 && cin_x % 32 == 0 && cin_x == hid,
                 "convlstm_step_wino: cin_x=%d and hid=%d must be equal multiples of 32 (one set of staging offsets serves both sources)", cin_x, hid);
     const int cin = cin_x + hid, cout = 4 * hid;

@@ -1328,6 +1328,38 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* w, int c
     }
 }
 
+// Winograd F(2x2,3x3) forms of a Conv2d weight for the training step's VAD_PREC_WINO mode (csrc/conv_wino.hip): U = G g G^T per
+// (output, input) channel pair in double, rounded once - the forward form [16][cin/8][cout][8] and the data-gradient form (taps
+// rotated by 180 degrees, channel roles swapped) [16][cout/8][cin][8].  One thread per channel pair.
+__global__ __launch_bounds__(256) void pack_conv3x3_wino_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad) {
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const long long total = (long long)cout * cin;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int ci = (int)(idx % cin), co = (int)(idx / cin);
+        double g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = (double)w[idx * 9 + a * 3 + b];
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+            for (int fc = 0; fc < 4; ++fc) {
+                double u = 0.0, ur = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        u += G[fr][a] * g[a][b] * G[fc][b];
+                        ur += G[fr][a] * g[2 - a][2 - b] * G[fc][b];
+                    }
+                const int f = fr * 4 + fc;
+                if (fwd) fwd[(((size_t)f * (cin / 8) + ci / 8) * cout + co) * 8 + (ci & 7)] = (float)u;
+                if (dgrad) dgrad[(((size_t)f * (cout / 8) + co / 8) * cin + ci) * 8 + (co & 7)] = (float)ur;
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_convt2x2_kernel(const float* w, int cin, int cout, float* fwd, float* dgrad, int split, int dgrad16) {
     const long long total = (long long)cin * cout * 4;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -1881,7 +1913,12 @@ extern "C" int vad_adam_step(float* p, const float* g, float* m, float* v, long 
 
 extern "C" int vad_train_pack_conv3x3(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream) {
     VAD_REQUIRE(w_oihw && (fwd || dgrad) && cout > 0 && cin > 0 && cin % 8 == 0 && (!dgrad || cout % 8 == 0), "train_pack_conv3x3: bad arguments");
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "train_pack_conv3x3: precision=%d must be 0 (fp32), 1 (split fp16), 2 or 3 (bf16)", precision);
+    if (precision == VAD_PREC_WINO) {     // Winograd forms (16 "taps": vad_pack_conv3x3_wino_floats of room each)
+        hipLaunchKernelGGL(pack_conv3x3_wino_kernel, dim3(grid_for((long long)cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad);
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "train_pack_conv3x3: precision=%d must be 0 (fp32), 1 (split fp16), 2 or 3 (bf16) or 4 (Winograd)", precision);
     const int split = precision == VAD_PREC_BF16S ? 2 : precision;   // the packed layout follows the arithmetic mode, like the host packers (2 = bf16 in the hi slots)
     VAD_REQUIRE(!split || (cin % 16 == 0 && (!dgrad || cout % 16 == 0)), "train_pack_conv3x3: split precision needs channel counts in multiples of 16");
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for(9ll * cout * cin)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, fwd, dgrad, split);

@@ -98,8 +98,9 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     auto chan = [&](long long npix, int c) { const size_t v = vad_chan_ws_floats(npix, c); if (v > max_chan) max_chan = v; };
     for (int k = 0; k < 4; ++k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
-        p.pk_e[k] = take(k == 0 ? vad_pack_conv3x3_c3_floats(co) : vad_pack_conv3x3_floats(co, ci));
-        p.pk_e_dg[k] = k == 0 ? 0 : take(vad_pack_conv3x3_floats(ci, co));
+        // (3x3 operand slots hold either form of a layer: direct, 9 taps, or Winograd, 16 - VAD_PREC_WINO)
+        p.pk_e[k] = take(k == 0 ? vad_pack_conv3x3_c3_floats(co) : vad_pack_conv3x3_wino_floats(co, ci));
+        p.pk_e_dg[k] = k == 0 ? 0 : take(vad_pack_conv3x3_wino_floats(ci, co));
         const size_t ysz = N * hk * wk * co;
         p.y[k] = take(ysz);
         if (ysz > max_act) max_act = ysz;
@@ -111,8 +112,8 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     }
     for (int l = 0; l < NL; ++l) {
         const int cin = p.lstm_cin(l) + Hd;
-        p.pk_l[l] = take(vad_pack_conv3x3_floats(4 * Hd, cin));
-        p.pk_l_dg[l] = take(vad_pack_conv3x3_floats(cin, 4 * Hd));
+        p.pk_l[l] = take(vad_pack_conv3x3_wino_floats(4 * Hd, cin));
+        p.pk_l_dg[l] = take(vad_pack_conv3x3_wino_floats(cin, 4 * Hd));
         p.cat[l] = take(N * p.hw * cin);
         p.z[l] = take(N * p.hw * 4 * Hd);
         p.c[l] = take(N * p.hw * Hd);
@@ -230,7 +231,18 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
                                      const float* params, float* grads, float* running, void* workspace, size_t workspace_bytes,
                                      int precision, float* loss, float* recon, void* stream) {
     VAD_REQUIRE(x && params && grads && workspace && loss, "vid_train_fwd_bwd: null pointer");
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "vid_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16), 2 (bf16 operands) or 3 (bf16 tensors)", precision);
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_WINO, "vid_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16), 2 (bf16 operands), 3 (bf16 tensors) or 4 (Winograd)", precision);
+    // VAD_PREC_WINO: the 3x3 convolutions behind the first layer - forward and data gradients, the ConvLSTM gate convolutions
+    // included - in Winograd F(2x2,3x3) form on the exact-fp32 matrix pipe (csrc/conv_wino.hip); everything else is the
+    // VAD_PREC_FP32 arithmetic (`precision` below).  All-fp32, another rounding order than mode 0.
+    const bool wino = precision == VAD_PREC_WINO;
+    const int pack_prec = precision;
+    if (wino) precision = VAD_PREC_FP32;
+    // a 3x3 convolution [n][hh][ww][ci] -> [n][hh][ww][co] without activation, in the step's mode
+    auto conv3 = [&](const float* in, const float* wpk, const float* bias, float* out, int n, int hh, int ww, int ci, int co, float* stats, int* srows) -> int {
+        if (wino) { if (srows) *srows = 0; return vad_conv3x3_wino(in, 0, wpk, bias, out, 0, n, hh, ww, ci, co, VAD_ACT_NONE, 0, stream); }
+        return vad_conv3x3_stats(in, 0, wpk, bias, out, 0, n, hh, ww, ci, co, VAD_ACT_NONE, 0, precision, stats, srows, stream);
+    };
     // Arithmetic mode (argument `precision`): 0 = exact fp32 everywhere (the parity path); 1 = the 3x3 and transposed
     // convolutions (forward and data gradients) take split-fp16 operands (22-bit products, fp32 accumulate), everything
     // else - first layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam - stays fp32; 2 = bf16 operands
@@ -267,9 +279,9 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     { PS(TS_PACK);
     TRY(vad_train_pack_conv3x3_c3(P + p.e_w[0], 32, ws + p.pk_e[0], s));
     for (int k = 1; k < 4; ++k)
-        TRY(vad_train_pack_conv3x3(P + p.e_w[k], p.encC[k + 1], p.encC[k], ws + p.pk_e[k], ws + p.pk_e_dg[k], precision, s));
+        TRY(vad_train_pack_conv3x3(P + p.e_w[k], p.encC[k + 1], p.encC[k], ws + p.pk_e[k], ws + p.pk_e_dg[k], pack_prec, s));
     for (int l = 0; l < NL; ++l)
-        TRY(vad_train_pack_conv3x3(P + p.l_w[l], 4 * Hd, p.lstm_cin(l) + Hd, ws + p.pk_l[l], ws + p.pk_l_dg[l], precision, s));
+        TRY(vad_train_pack_conv3x3(P + p.l_w[l], 4 * Hd, p.lstm_cin(l) + Hd, ws + p.pk_l[l], ws + p.pk_l_dg[l], pack_prec, s));
     for (int j = 0; j < 3; ++j)
         TRY(vad_train_pack_convt2x2(P + p.d_w[j], p.decC[j], p.decC[j + 1], ws + p.pk_d[j], ws + p.pk_d_dg[j], precision, s));
     if (p.proj) TRY(vad_train_pack_conv1x1_p(P + p.pj_w, L, Hd, ws + p.pk_pj, ws + p.pk_pj_dg, precision, s));
@@ -282,7 +294,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         float* y = A(p.y[k]);
         int sblocks = 0;      // > 0: the convolution wrote the BatchNorm partial sums itself (first layer: no second pass over y)
         if (k == 0) { PS(TS_C3_FWD); TRY(vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, io, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s)); }
-        else { PS(TS_CONV_FWD); TRY(vad_conv3x3_stats(A(p.a[k - 1]), 0, ws + p.pk_e[k], P + p.e_b[k], y, 0, N, hk, wk, ci, co, VAD_ACT_NONE, 0, precision, ws + p.chan_ws, &sblocks, s)); }
+        else { PS(TS_CONV_FWD); TRY(conv3(A(p.a[k - 1]), ws + p.pk_e[k], P + p.e_b[k], y, N, hk, wk, ci, co, ws + p.chan_ws, &sblocks)); }
         float* rs = running ? running + p.e_rs[k] : nullptr;
         if (sblocks > 0) { PS(TS_STATS_MISC); TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[k], s)); }
         else {
@@ -304,7 +316,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         for (int tt = 0; tt < T; ++tt) {
             float* zt = A(p.z[l], (size_t)tt * B * hw * 4 * Hd);
             float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
-            { PS(TS_LSTM_CONV_FWD); TRY(vad_conv3x3(A(p.cat[l], tt * slab), 0, ws + p.pk_l[l], P + p.l_b[l], zt, 0, B, p.h16, p.w16, cin, 4 * Hd, VAD_ACT_NONE, 0, precision, s)); }
+            { PS(TS_LSTM_CONV_FWD); TRY(conv3(A(p.cat[l], tt * slab), ws + p.pk_l[l], P + p.l_b[l], zt, B, p.h16, p.w16, cin, 4 * Hd, nullptr, nullptr)); }
             float* h1 = tt + 1 < T ? A(p.cat[l], (tt + 1) * slab + cx) : nullptr;
             float* h2; long long h2_fs; int h2_ps;
             if (l + 1 < NL) { h2 = A(p.cat[l + 1], (size_t)tt * B * hw * 2 * Hd); h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
@@ -384,7 +396,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
             TRY(vad_lstm_gates_bwd_t(A(p.z[l], (size_t)tt * B * hw * 4 * Hd), io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
                                      dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s)); }
             PS(TS_LSTM_CONV_DGRAD);
-            TRY(vad_conv3x3(dzt, 0, ws + p.pk_l_dg[l], zeros, A(p.dcat[l], tt * slab), 0, B, p.h16, p.w16, 4 * Hd, cin, VAD_ACT_NONE, 0, precision, s));
+            TRY(conv3(dzt, ws + p.pk_l_dg[l], zeros, A(p.dcat[l], tt * slab), B, p.h16, p.w16, 4 * Hd, cin, nullptr, nullptr));
         }
         // weight / bias gradients of the cell's convolution over all steps at once (frames = T*B)
         { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.cat[l]), A(p.dzl[l]), G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s)); }
@@ -409,7 +421,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         } else {
             { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.a[k - 1]), g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s)); }
             PS(TS_CONV_DGRAD);
-            TRY(vad_conv3x3(g2, 0, ws + p.pk_e_dg[k], zeros, g0, 0, N, hk, wk, co, ci, VAD_ACT_NONE, 0, precision, s));
+            TRY(conv3(g2, ws + p.pk_e_dg[k], zeros, g0, N, hk, wk, co, ci, nullptr, nullptr));
         }
     }
     return VAD_OK;
