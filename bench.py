@@ -336,6 +336,8 @@ def main():
     # :344 one 16-frame window), eager launches, per-layer events off.  Never part of `value`.
     if rank == 0 and world == 1 and default_line and not args.no_small:
         out["reference_call_sizes"] = reference_call_sizes(vad, lib, model, dev, hw, seed)
+        if "winograd_precision" in out:       # the same calls in the opt-in Winograd mode (never part of `value`)
+            out["winograd_precision"]["reference_call_sizes"] = reference_call_sizes(vad, lib, model, dev, hw, seed, precision="winograd")
     # Secondary measurement (row f-1): the native training step of the ConvLSTM video autoencoder (train_video.py:44-65),
     # exact fp32, 32 clips x 10 frames at the bench resolution.  Never part of `value` / `roofline`.
     if rank == 0 and world == 1 and not args.no_train and args.workload == "image" and args.precision == "fp32":
@@ -662,7 +664,7 @@ def cpu_baseline(vad, state, kind, clip_len, gpu_scores, seed, hw):
             "gpu_vs_cpu_max_rel_score_err": rel}
 
 
-def reference_call_sizes(vad, lib, img_model, dev, hw, seed, steps=100, warmup=10):
+def reference_call_sizes(vad, lib, img_model, dev, hw, seed, steps=100, warmup=10, precision="fp32"):
     """Latency / throughput of the batch sizes the reference's own scripts use: inputs resident in HBM,
     `steps` calls back to back after `warmup`, one synchronise at the end."""
     def timed(fn):
@@ -678,6 +680,8 @@ def reference_call_sizes(vad, lib, img_model, dev, hw, seed, steps=100, warmup=1
 
     lib.vad_prof_enable(0)
     out = {}
+    was = img_model.precision
+    img_model.precision = precision
     frames = vad.scoring.synth_frames_device(seed + 5, 0, 16, hw, hw, device=dev)
     for b, site in ((1, "main.py:274"), (16, "evaluate.py:240")):
         x = frames[:b].contiguous()
@@ -687,6 +691,8 @@ def reference_call_sizes(vad, lib, img_model, dev, hw, seed, steps=100, warmup=1
     shapes = {k: tuple(v.shape) for k, v in vm.state_dict().items()}
     vm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vad.synth.synthetic_state(shapes, 8).items()}, strict=True)
     vm = vm.to(dev).eval()
+    vm.precision = precision
+    img_model.precision = was
     clips = vad.scoring.synth_frames_device(seed + 6, 0, 4 * 16, hw, hw, device=dev).view(4, 16, 3, hw, hw)
     for b, site in ((4, "evaluate_video.py:416"), (1, "evaluate_video.py:344 (one window)")):
         x = clips[:b].contiguous()

@@ -25,14 +25,14 @@ def _free_port():
 # world 4 = the largest rehearsal a GPU box allows from inside the test session (at most 6 processes may hold the card: the
 # session itself + 4 ranks); image: 8 frames per rank per step and a ragged 1,030-frame stream (blocks of 258, the last 256),
 # video: ONE clip per rank.  The 8-rank form of the same host logic runs on CPU ranks in tests/test_sharding.py.
-@pytest.mark.parametrize("world,workload,extra", [(2, "image", ["--batch", "24"]),
-                                                  (2, "video", ["--batch", "3", "--clip-len", "4", "--size", "64"]),
-                                                  (4, "image", ["--batch", "8", "--size", "64", "--stream-frames", "1030"]),
-                                                  (4, "video", ["--batch", "1", "--clip-len", "10", "--size", "64"])])
+@pytest.mark.parametrize("world,workload,extra", [(2, "image", ["--batch", "24", "--size", "64"]),       # with the split / winograd objects
+                                                  (2, "video", ["--batch", "3", "--clip-len", "4", "--size", "64", "--no-split"]),
+                                                  (4, "image", ["--batch", "8", "--size", "64", "--stream-frames", "1030", "--no-split"]),
+                                                  (4, "video", ["--batch", "1", "--clip-len", "10", "--size", "64", "--no-split"])])
 def test_multi_rank_bench_line_verifies_itself(world, workload, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--share-gpu", "--workload", workload, "--no-split", "--no-train", *extra]
+           "--backend", "gloo", "--share-gpu", "--workload", workload, "--no-train", *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -47,6 +47,10 @@ def test_multi_rank_bench_line_verifies_itself(world, workload, extra):
     assert [i // per for i in mg["parity"]["checked_items"]] == list(range(world))
     assert mg["parity"]["within_1e-4"] and mg["parity"]["max_rel_score_err_vs_cpu"] < 1e-5
     assert "cpu_baseline" not in d                                 # the CPU baseline is an N = 1 measurement
+    if "--no-split" not in extra:                                  # the opt-in modes ride in the N > 1 line too, never as `value`
+        assert d["dtype"] == "f32"
+        for mode in ("split_precision", "winograd_precision"):
+            assert d[mode]["value"] > 0 and d[mode]["max_rel_score_diff_vs_exact_fp32"] < 1e-5, mode
     if "--stream-frames" in extra:                                 # configs[3] on `world` ranks with a ragged tail
         st = d["stream"]
         assert st["frames"] == 1030 and st["frames_per_rank"] == 258 and st["scaling"] == "strong" and st["value"] > 0

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_insts_$tag
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM \
-  --kernel-trace --output-format csv -d $R/gpurun_out/pmc_insts_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-layer-events --no-split --no-train --no-video --stream-frames 0 "$@" > /dev/null 2>&1
+  --kernel-trace --output-format csv -d $R/gpurun_out/pmc_insts_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-layer-events --no-split --no-train --no-video --no-small --stream-frames 0 "$@" > /dev/null 2>&1
 cd $R
 python3 - <<PY
 import csv, glob
