@@ -296,7 +296,7 @@ VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_re
     z.zx0 = small ? up256(sizeof(float) * nf * p16 * 4 * hid) : 0;
     z.zxl = small ? up256(sizeof(float) * n * p16 * 4 * hid) : 0;
     z.zw = up256(sizeof(float) * (size_t)chunk * p16 * 4 * hid);   // VAD_PREC_WINO: one step's gate pre-activations (vad_convlstm_step_wino)
-    z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst) + z.proj + z.parts + z.zx0 + (size_t)(layers - 1) * z.zxl + z.zw;   // h sequence + cell state per layer
+    z.total = 2 * z.act + z.enc + (size_t)layers * (z.hseq + z.cst + z.zw) + z.proj + z.parts + z.zx0 + (size_t)(layers - 1) * z.zxl;   // h sequence + cell state (+ z) per layer
     return z;
 }
 
@@ -370,7 +370,8 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         ZX[0] = (float*)base; base += Z.zx0;
         for (int l = 1; l < layers; ++l) { ZX[l] = (float*)base; base += Z.zxl; }
     }
-    float* ZW = (float*)base; base += Z.zw;
+    float* ZW[8];                                   // per layer: the layers of a small launch group run concurrently (wavefront)
+    for (int l = 0; l < layers; ++l) { ZW[l] = (float*)base; base += Z.zw; }
     const int nparts = vad_score_partials(1, h, w);
     const int h16 = h / 16, w16 = w / 16;
     const long long fs_lat = (long long)h16 * w16 * latent, fs_hid = (long long)h16 * w16 * hid;
@@ -409,7 +410,7 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
             VadProfScope ps(4, st);
             if (wino_layer(l))
                 return vad_convlstm_step_wino(xin_l + (size_t)ti * fs_in, clip_in, ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
-                                              ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l), HS[l] + (size_t)ti * fs_hid, (long long)t * fs_hid, CS[l], ZW,
+                                              ti ? CS[l] : nullptr, W_(4 + l), B_(4 + l), HS[l] + (size_t)ti * fs_hid, (long long)t * fs_hid, CS[l], ZW[l],
                                               nc, h16, w16, hid, hid, st);
             return vad_convlstm_step_zx(xin_l + (size_t)ti * fs_in, clip_in, (hoist && (l == 0 || hoist_upper)) ? ZX[l] + (size_t)ti * fs_zx : nullptr, clip_zx,
                                         ti ? HS[l] + (size_t)(ti - 1) * fs_hid : nullptr, (long long)t * fs_hid,
@@ -432,7 +433,7 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         const long long lstm_groups = vid_lstm_groups(nc, h16, w16, hid);
         const int wf = g_vad_lstm_wavefront.load(std::memory_order_relaxed);
         if (hoist) TRY(lstm_xhalf(0, -1, s));
-        if (layers > 1 && !wino && ((lstm_groups < 256 && wf) || wf == 2)) {   // (Winograd steps share ONE z buffer: layers strictly in order)
+        if (layers > 1 && ((lstm_groups < 256 && wf) || wf == 2)) {   // (Winograd steps share ONE z buffer: layers strictly in order)
             // per-step x halves of the layers above 0 (a helper-stream launch and two event hops per step) pay while a step is a
             // long serial K loop; with the gate-split kernel (one window: ~11 us per step) they cost more than they save - measured
             // 0.78 -> 0.70 ms for one 16-frame window, 1.05 -> 0.97 for two clips - so those steps run their whole K loop
