@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--clips", type=int, default=8); ap.add_argument("--t", type=int, default=10); ap.add_argument("--hw", type=int, default=256)
 ap.add_argument("--latent", type=int, default=128); ap.add_argument("--layers", type=int, default=2)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
-ap.add_argument("--precision", choices=["fp32", "split", "bf16", "bf16_operands"], default="fp32",
+ap.add_argument("--precision", choices=["fp32", "split", "bf16", "bf16_operands", "winograd"], default="fp32",
                 help="split / bf16_operands: 3x3 / transposed convs on split-fp16 / bf16 operands; bf16: activation and gradient tensors bf16 in HBM too")
 a = ap.parse_args()
 torch.cuda.set_device(0)
@@ -31,7 +31,7 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 losses.append(float(loss))
 frames = a.clips * a.t
 fwd_flop_per_frame = 3011510272.0 * (a.hw / 256.0) ** 2 if (a.latent, a.layers, a.t) == (128, 2, 10) else None
-print(json.dumps({"metric": "training frames/s (native step, %s)" % {"fp32": "exact fp32", "split": "split-fp16 convolutions, rest fp32", "bf16": "bf16 tensors + bf16 MFMA operands, fp32 arithmetic / statistics / master weights", "bf16_operands": "bf16 convolution operands from fp32 tensors, rest fp32"}[a.precision], "value": round(frames / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+print(json.dumps({"metric": "training frames/s (native step, %s)" % {"fp32": "exact fp32", "split": "split-fp16 convolutions, rest fp32", "bf16": "bf16 tensors + bf16 MFMA operands, fp32 arithmetic / statistics / master weights", "bf16_operands": "bf16 convolution operands from fp32 tensors, rest fp32", "winograd": "fp32 everywhere, 3x3 forward / data-gradient convolutions as Winograd F(2x2,3x3)"}[a.precision], "value": round(frames / dt, 1), "ms_per_step": round(dt * 1e3, 3),
                   "clips": a.clips, "t": a.t, "hw": a.hw, "latent": a.latent, "layers": a.layers, "steps": a.steps,
                   "workspace_GiB": round(tr._ws.numel() / 2**30, 2), "losses_first_last": [losses[0], losses[-1]],
                   "algorithmic_tflops": round(3 * fwd_flop_per_frame * frames / dt / 1e12, 2) if fwd_flop_per_frame else None}))
