@@ -485,3 +485,33 @@ def test_optimizer_state_moves_between_native_trainer_and_torch_adam(vad, tmp_pa
     for k, v in ref2.state_dict().items():
         if not k.endswith("num_batches_tracked") and k not in zero_true and "running_" not in k:
             assert float((m2.state_dict()[k].cpu() - v).abs().mean()) < 0.02 * LR, k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "winograd"])
+def test_convlstm_layer_wavefront_changes_no_bit(vad, precision):
+    """The ConvLSTM layers of a small batch run as a wavefront on helper streams (step (l, t) beside (l-1, t+1); backward:
+    (l, t) beside (l+1, t-1)) instead of layers-outer (models/video_autoencoder.py:153-160): same launches, same operands, another
+    order in time - loss, every gradient, the running statistics and the reconstruction must be bit-identical to the sequential
+    order (vad_debug_set_lstm_wavefront(0)), step after step."""
+    l = vad.hip.lib()
+    x = torch.from_numpy(vad.synth.clips(77, 0, 3, 4, 3, 48, 32)).cuda()
+    outs = []
+    for mode in (1, 0, 2):
+        m = _make(vad, 64, 3)
+        load_synthetic(vad, m, 61)
+        tr = vad.VideoTrainer(m.cuda(), lr=LR, weight_decay=WD, precision=precision)
+        try:
+            l.vad_debug_set_lstm_wavefront(mode)
+            losses, recon = [], None
+            for _ in range(3):
+                loss, recon = tr.forward_backward(x, recon=True)
+                tr.optimizer_step()
+                losses.append(loss.clone())
+        finally:
+            l.vad_debug_set_lstm_wavefront(1)
+        torch.cuda.synchronize()
+        outs.append((torch.stack(losses), tr.grad.clone(), tr.flat.clone(), tr.running.clone(), recon.clone()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    assert bool(torch.isfinite(outs[0][0]).all())

@@ -42,7 +42,7 @@ struct Plan {
     // workspace offsets (floats)
     size_t pk_e[4], pk_e_dg[4], pk_l[8], pk_l_dg[8], pk_d[3], pk_d_dg[3];
     size_t y[4], a[3], st_e[4], cat[8], z[8], c[8], hseq, pseq, pk_pj, pk_pj_dg, u[3], r[3], st_d[3], dpre;
-    size_t g[3], dcat[8], dzl[8], dc, ksums, zeros, chan_ws, wgrad_ws, to3_ws;
+    size_t g[3], dcat[8], dzl[8], dc[8], ksums, zeros, chan_ws, wgrad_ws, to3_ws;
     size_t ws_floats;
     int lstm_cin(int l) const { return l == 0 ? L : Hd; }
 };
@@ -123,7 +123,7 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
         const size_t wg = vad_conv_wgrad_ws_floats(p.N, p.h16, 9, cin, 4 * Hd);
         if (wg > max_wgrad) max_wgrad = wg;
     }
-    p.dc = take((size_t)B * p.hw * Hd);
+    for (int l = 0; l < NL; ++l) p.dc[l] = take((size_t)B * p.hw * Hd);   // per layer: the layers of a small batch run as a wavefront
     p.hseq = take(N * p.hw * Hd);
     p.pseq = p.pk_pj = p.pk_pj_dg = 0;
     if (p.proj) {
@@ -170,6 +170,35 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
 
 }  // namespace
 
+// Helper streams of the ConvLSTM layer wavefront (small batches: a step's launch fills a fraction of the chip, so layer l's step t
+// runs beside layer l-1's step t+1 - forward - and layer l's step t beside layer l+1's step t-1 - backward; the reference's loops
+// are layers-outer, models/video_autoencoder.py:153-160, the data dependences allow the diagonal order).  Created once per thread
+// and device; fork / join through events on the caller's stream, so the step stays asynchronous.
+namespace {
+struct TrainStreams {
+    int dev = -1, n = 0;
+    hipStream_t st[7] = {};
+    hipEvent_t done[8] = {};
+    hipEvent_t fork = nullptr;
+};
+thread_local TrainStreams t_ts;
+int train_streams(int layers, TrainStreams** out) {
+    int dev = 0;
+    VAD_HIP_TRY(hipGetDevice(&dev));
+    TrainStreams& S = t_ts;
+    if (S.dev != dev) {
+        S = TrainStreams{};
+        S.dev = dev;
+        VAD_HIP_TRY(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+        for (int l = 0; l < 8; ++l) VAD_HIP_TRY(hipEventCreateWithFlags(&S.done[l], hipEventDisableTiming));
+    }
+    while (S.n < layers - 1) { VAD_HIP_TRY(hipStreamCreateWithFlags(&S.st[S.n], hipStreamNonBlocking)); ++S.n; }
+    *out = &S;
+    return VAD_OK;
+}
+}  // namespace
+extern "C" int vad_lstm_wavefront_mode(void);   // vad_api.hip: vad_debug_set_lstm_wavefront (0 = never, 1 = small launch groups, 2 = always)
+
 // Debug: return from vad_vid_train_fwd_bwd right after the backward of decoder stage `j` (2, 1, 0), 10 + l after ConvLSTM
 // layer l, leaving the gradient scratch (g0 = gradient of that stage's input, g2 = gradient of its conv output)
 // in the workspace for inspection (tools/diag_stream.py).  -1 = run the whole step (default).
@@ -180,6 +209,7 @@ extern "C" int vad_debug_set_train_stop(int stage) { g_vad_train_stop = stage; r
 enum { TS_C3_FWD = 0, TS_CONV_FWD, TS_BN_FWD, TS_LSTM_CONV_FWD, TS_LSTM_GATES_FWD, TS_CONVT_FWD, TS_LOSS, TS_WGRAD, TS_BN_BWD,
        TS_CONVT_DGRAD, TS_LSTM_GATES_BWD, TS_LSTM_CONV_DGRAD, TS_CONV_DGRAD, TS_C3_WGRAD, TS_PACK, TS_STATS_MISC };
 #define PS(slot) VadProfScope ps_(slot, s)
+#define PSS(slot, st_) VadProfScope ps_(slot, st_)
 
 #define TRY(expr)                    \
     do {                             \
@@ -239,9 +269,10 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     const int pack_prec = precision;
     if (wino) precision = VAD_PREC_FP32;
     // a 3x3 convolution [n][hh][ww][ci] -> [n][hh][ww][co] without activation, in the step's mode
-    auto conv3 = [&](const float* in, const float* wpk, const float* bias, float* out, int n, int hh, int ww, int ci, int co, float* stats, int* srows) -> int {
-        if (wino) { if (srows) *srows = 0; return vad_conv3x3_wino(in, 0, wpk, bias, out, 0, n, hh, ww, ci, co, VAD_ACT_NONE, 0, stream); }
-        return vad_conv3x3_stats(in, 0, wpk, bias, out, 0, n, hh, ww, ci, co, VAD_ACT_NONE, 0, precision, stats, srows, stream);
+    auto conv3 = [&](const float* in, const float* wpk, const float* bias, float* out, int n, int hh, int ww, int ci, int co, float* stats, int* srows,
+                     hipStream_t st) -> int {
+        if (wino) { if (srows) *srows = 0; return vad_conv3x3_wino(in, 0, wpk, bias, out, 0, n, hh, ww, ci, co, VAD_ACT_NONE, 0, st); }
+        return vad_conv3x3_stats(in, 0, wpk, bias, out, 0, n, hh, ww, ci, co, VAD_ACT_NONE, 0, precision, stats, srows, st);
     };
     // Arithmetic mode (argument `precision`): 0 = exact fp32 everywhere (the parity path); 1 = the 3x3 and transposed
     // convolutions (forward and data gradients) take split-fp16 operands (22-bit products, fp32 accumulate), everything
@@ -294,7 +325,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         float* y = A(p.y[k]);
         int sblocks = 0;      // > 0: the convolution wrote the BatchNorm partial sums itself (first layer: no second pass over y)
         if (k == 0) { PS(TS_C3_FWD); TRY(vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, io, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s)); }
-        else { PS(TS_CONV_FWD); TRY(conv3(A(p.a[k - 1]), ws + p.pk_e[k], P + p.e_b[k], y, N, hk, wk, ci, co, ws + p.chan_ws, &sblocks)); }
+        else { PS(TS_CONV_FWD); TRY(conv3(A(p.a[k - 1]), ws + p.pk_e[k], P + p.e_b[k], y, N, hk, wk, ci, co, ws + p.chan_ws, &sblocks, s)); }
         float* rs = running ? running + p.e_rs[k] : nullptr;
         if (sblocks > 0) { PS(TS_STATS_MISC); TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[k], s)); }
         else {
@@ -307,23 +338,45 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         else   // latent features go straight into layer 0's operand buffers: frame b*T+t -> slot t*B+b, x-part
             TRY(vad_bn_act_pool_fwd_t(y, io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.cat[0]), 0, L + Hd, T, B, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
     }
-    // ConvLSTM (models/video_autoencoder.py:153-163): layer by layer, step by step; h(-1) = c(-1) = 0
-    for (int l = 0; l < NL; ++l) {
+    // ConvLSTM (models/video_autoencoder.py:153-163); h(-1) = c(-1) = 0.  Step (l, t) needs (l, t-1) and (l-1, t) only.
+    // A step's launch covers B*h16*w16 pixels: at 32 clips of 16x16 that is 256 (forward) or 128 (data gradient) work-groups on
+    // 512 resident slots, so with more than one layer the layers run as a WAVEFRONT on helper streams (layer l on stream l-1,
+    // step t of layer l behind step t of layer l-1) and two launches share the chip; large batches keep the layers-outer order.
+    const int wf_mode = vad_lstm_wavefront_mode();
+    const bool wavefront = NL > 1 && g_vad_train_stop < 10 && (wf_mode == 2 || (wf_mode == 1 && (long long)B * hw <= 12288));
+    TrainStreams* TS = nullptr;
+    if (wavefront) TRY(train_streams(NL, &TS));
+    for (int l = 0; l < NL; ++l) {    // h-part of every layer's t = 0 operand is the zero initial state (the x-part is written by the producer)
+        const int cx = p.lstm_cin(l), cin = cx + Hd;
+        VAD_HIP_TRY(hipMemset2DAsync(A(p.cat[l], cx), (size_t)cin * es, 0, (size_t)Hd * es, (size_t)B * hw, s));
+    }
+    auto lstm_fwd_step = [&](int l, int tt, hipStream_t st) -> int {
         const int cx = p.lstm_cin(l), cin = cx + Hd;
         const size_t slab = (size_t)B * hw * cin;
-        // h-part of the t = 0 operand is the zero initial state (the x-part was / will be written by the producer)
-        VAD_HIP_TRY(hipMemset2DAsync(A(p.cat[l], cx), (size_t)cin * es, 0, (size_t)Hd * es, (size_t)B * hw, s));
-        for (int tt = 0; tt < T; ++tt) {
-            float* zt = A(p.z[l], (size_t)tt * B * hw * 4 * Hd);
-            float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
-            { PS(TS_LSTM_CONV_FWD); TRY(conv3(A(p.cat[l], tt * slab), ws + p.pk_l[l], P + p.l_b[l], zt, B, p.h16, p.w16, cin, 4 * Hd, nullptr, nullptr)); }
-            float* h1 = tt + 1 < T ? A(p.cat[l], (tt + 1) * slab + cx) : nullptr;
-            float* h2; long long h2_fs; int h2_ps;
-            if (l + 1 < NL) { h2 = A(p.cat[l + 1], (size_t)tt * B * hw * 2 * Hd); h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
-            else { h2 = A(p.hseq, (size_t)tt * hw * Hd); h2_ps = Hd; h2_fs = (long long)T * hw * Hd; }
-            PS(TS_LSTM_GATES_FWD);
-            TRY(vad_lstm_gates_fwd_t(zt, io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, h1, (long long)hw * cin, cin, h2, h2_fs, h2_ps, B, hw, Hd, s));
-        }
+        float* zt = A(p.z[l], (size_t)tt * B * hw * 4 * Hd);
+        float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
+        { PSS(TS_LSTM_CONV_FWD, st); TRY(conv3(A(p.cat[l], tt * slab), ws + p.pk_l[l], P + p.l_b[l], zt, B, p.h16, p.w16, cin, 4 * Hd, nullptr, nullptr, st)); }
+        float* h1 = tt + 1 < T ? A(p.cat[l], (tt + 1) * slab + cx) : nullptr;
+        float* h2; long long h2_fs; int h2_ps;
+        if (l + 1 < NL) { h2 = A(p.cat[l + 1], (size_t)tt * B * hw * 2 * Hd); h2_ps = 2 * Hd; h2_fs = (long long)hw * h2_ps; }
+        else { h2 = A(p.hseq, (size_t)tt * hw * Hd); h2_ps = Hd; h2_fs = (long long)T * hw * Hd; }
+        PSS(TS_LSTM_GATES_FWD, st);
+        return vad_lstm_gates_fwd_t(zt, io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, h1, (long long)hw * cin, cin, h2, h2_fs, h2_ps, B, hw, Hd, st);
+    };
+    if (wavefront) {
+        VAD_HIP_TRY(hipEventRecord(TS->fork, s));                                   // the latent features and the zeroed states are ready
+        for (int l = 1; l < NL; ++l) VAD_HIP_TRY(hipStreamWaitEvent(TS->st[l - 1], TS->fork, 0));
+        for (int tt = 0; tt < T; ++tt)
+            for (int l = 0; l < NL; ++l) {
+                hipStream_t st = l ? TS->st[l - 1] : s;
+                if (l) VAD_HIP_TRY(hipStreamWaitEvent(st, TS->done[l - 1], 0));       // (l-1, tt) finished
+                TRY(lstm_fwd_step(l, tt, st));
+                if (l + 1 < NL || tt + 1 == T) VAD_HIP_TRY(hipEventRecord(TS->done[l], st));
+            }
+        for (int l = 1; l < NL; ++l) VAD_HIP_TRY(hipStreamWaitEvent(s, TS->done[l], 0));   // join
+    } else {
+        for (int l = 0; l < NL; ++l)
+            for (int tt = 0; tt < T; ++tt) TRY(lstm_fwd_step(l, tt, s));
     }
     // proj (models/video_autoencoder.py:311-312, 346-349): Conv2d k1 hidden -> latent when the two differ, else Identity
     const float* dec_in = A(p.hseq);
@@ -380,28 +433,49 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         { PS(TS_CONVT_DGRAD); TRY(vad_conv1x1_p(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, precision, s)); }
         dhseq = g2;
     }
-    // dhseq = d hseq [b*T+t][hw][Hd].  BPTT, top layer first.
-    for (int l = NL - 1; l >= 0; --l) {
+    // dhseq = d hseq [b*T+t][hw][Hd].  BPTT: step (l, t) needs (l, t+1) and (l+1, t) only - the same wavefront, top layer on the
+    // caller's stream.
+    auto lstm_bwd_step = [&](int l, int tt, hipStream_t st) -> int {
         const int cx = p.lstm_cin(l), cin = cx + Hd;
         const size_t slab = (size_t)B * hw * cin;
-        float* dc = ws + p.dc;
-        for (int tt = T - 1; tt >= 0; --tt) {
-            const float* dh1; long long dh1_fs; int dh1_ps;
-            if (l == NL - 1) { dh1 = at(dhseq, (size_t)tt * hw * Hd); dh1_ps = Hd; dh1_fs = (long long)T * hw * Hd; }
-            else { dh1 = A(p.dcat[l + 1], (size_t)tt * B * hw * 2 * Hd); dh1_ps = 2 * Hd; dh1_fs = (long long)hw * dh1_ps; }
-            const float* dh2 = tt + 1 < T ? A(p.dcat[l], (tt + 1) * slab + cx) : nullptr;
-            float* dzt = A(p.dzl[l], (size_t)tt * B * hw * 4 * Hd);
-            const float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
-            { PS(TS_LSTM_GATES_BWD);
-            TRY(vad_lstm_gates_bwd_t(A(p.z[l], (size_t)tt * B * hw * 4 * Hd), io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
-                                     dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, s)); }
-            PS(TS_LSTM_CONV_DGRAD);
-            TRY(conv3(dzt, ws + p.pk_l_dg[l], zeros, A(p.dcat[l], tt * slab), B, p.h16, p.w16, 4 * Hd, cin, nullptr, nullptr));
-        }
-        // weight / bias gradients of the cell's convolution over all steps at once (frames = T*B)
+        float* dc = ws + p.dc[l];
+        const float* dh1; long long dh1_fs; int dh1_ps;
+        if (l == NL - 1) { dh1 = at(dhseq, (size_t)tt * hw * Hd); dh1_ps = Hd; dh1_fs = (long long)T * hw * Hd; }
+        else { dh1 = A(p.dcat[l + 1], (size_t)tt * B * hw * 2 * Hd); dh1_ps = 2 * Hd; dh1_fs = (long long)hw * dh1_ps; }
+        const float* dh2 = tt + 1 < T ? A(p.dcat[l], (tt + 1) * slab + cx) : nullptr;
+        float* dzt = A(p.dzl[l], (size_t)tt * B * hw * 4 * Hd);
+        const float* ct = ws + p.c[l] + (size_t)tt * B * hw * Hd;
+        { PSS(TS_LSTM_GATES_BWD, st);
+        TRY(vad_lstm_gates_bwd_t(A(p.z[l], (size_t)tt * B * hw * 4 * Hd), io, tt ? ct - (size_t)B * hw * Hd : nullptr, ct, dh1, dh1_fs, dh1_ps,
+                                 dh2, (long long)hw * cin, cin, tt + 1 < T ? dc : nullptr, dzt, dc, B, hw, Hd, st)); }
+        PSS(TS_LSTM_CONV_DGRAD, st);
+        return conv3(dzt, ws + p.pk_l_dg[l], zeros, A(p.dcat[l], tt * slab), B, p.h16, p.w16, 4 * Hd, cin, nullptr, nullptr, st);
+    };
+    // weight / bias gradients of a cell's convolution over all its steps at once (frames = T*B)
+    auto lstm_wgrad = [&](int l) -> int {
+        const int cin = p.lstm_cin(l) + Hd;
         { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.cat[l]), A(p.dzl[l]), G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s)); }
-        { PS(TS_STATS_MISC); TRY(vad_chan_sum_t(A(p.dzl[l]), io, (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s)); }
-        if (g_vad_train_stop == 10 + l) return VAD_OK;
+        PS(TS_STATS_MISC);
+        return vad_chan_sum_t(A(p.dzl[l]), io, (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s);
+    };
+    if (wavefront) {
+        VAD_HIP_TRY(hipEventRecord(TS->fork, s));                                   // d hseq is ready
+        for (int l = 0; l + 1 < NL; ++l) VAD_HIP_TRY(hipStreamWaitEvent(TS->st[l], TS->fork, 0));
+        for (int tt = T - 1; tt >= 0; --tt)
+            for (int l = NL - 1; l >= 0; --l) {
+                hipStream_t st = (l == NL - 1) ? s : TS->st[l];
+                if (l + 1 < NL) VAD_HIP_TRY(hipStreamWaitEvent(st, TS->done[l + 1], 0));   // (l+1, tt) finished
+                TRY(lstm_bwd_step(l, tt, st));
+                if (l > 0 || tt == 0) VAD_HIP_TRY(hipEventRecord(TS->done[l], st));
+            }
+        for (int l = 0; l + 1 < NL; ++l) VAD_HIP_TRY(hipStreamWaitEvent(s, TS->done[l], 0));   // join
+        for (int l = NL - 1; l >= 0; --l) TRY(lstm_wgrad(l));                       // (shared scratch: on the caller's stream, in order)
+    } else {
+        for (int l = NL - 1; l >= 0; --l) {
+            for (int tt = T - 1; tt >= 0; --tt) TRY(lstm_bwd_step(l, tt, s));
+            TRY(lstm_wgrad(l));
+            if (g_vad_train_stop == 10 + l) return VAD_OK;
+        }
     }
     // encoder, last stage first; the x-part of layer 0's operand gradient is d(latent features)
     for (int k = 3; k >= 0; --k) {
@@ -421,7 +495,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         } else {
             { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.a[k - 1]), g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s)); }
             PS(TS_CONV_DGRAD);
-            TRY(conv3(g2, ws + p.pk_e_dg[k], zeros, g0, N, hk, wk, co, ci, nullptr, nullptr));
+            TRY(conv3(g2, ws + p.pk_e_dg[k], zeros, g0, N, hk, wk, co, ci, nullptr, nullptr, s));
         }
     }
     return VAD_OK;

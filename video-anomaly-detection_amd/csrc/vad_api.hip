@@ -337,6 +337,7 @@ static int side_streams(int layers, VadSideStreams** out) {
 
 static std::atomic<int> g_vad_lstm_wavefront{1};   // debug: 0 = always the sequential layers-outer order, 2 = wavefront at any size
 extern "C" int vad_debug_set_lstm_wavefront(int on) { g_vad_lstm_wavefront = on; return VAD_OK; }
+extern "C" int vad_lstm_wavefront_mode(void) { return g_vad_lstm_wavefront.load(std::memory_order_relaxed); }   // the training step shares the switch
 
 // clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
 int vid_run(const void* xv, int x_format, int precision, long long nclips, int t, int cs, int h, int w, int latent_real, int hid_real, int layers,
