@@ -487,17 +487,20 @@ def test_optimizer_state_moves_between_native_trainer_and_torch_adam(vad, tmp_pa
             assert float((m2.state_dict()[k].cpu() - v).abs().mean()) < 0.02 * LR, k
 
 
+@pytest.mark.parametrize("latent,hid", [(64, 64), (32, 64)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "winograd"])
-def test_convlstm_layer_wavefront_changes_no_bit(vad, precision):
+def test_convlstm_layer_wavefront_changes_no_bit(vad, precision, latent, hid):
     """The ConvLSTM layers of a small batch run as a wavefront on helper streams (step (l, t) beside (l-1, t+1); backward:
     (l, t) beside (l+1, t-1)) instead of layers-outer (models/video_autoencoder.py:153-160): same launches, same operands, another
     order in time - loss, every gradient, the running statistics and the reconstruction must be bit-identical to the sequential
-    order (vad_debug_set_lstm_wavefront(0)), step after step."""
+    order (vad_debug_set_lstm_wavefront(0)), step after step.  The same switch moves the weight-gradient GEMMs of the backward
+    pass onto a helper stream beside the BatchNorm / data-gradient chain (two alternating buffers for the gradient of a conv
+    output): covered by the same comparison, with and without `proj` (latent != hidden)."""
     l = vad.hip.lib()
     x = torch.from_numpy(vad.synth.clips(77, 0, 3, 4, 3, 48, 32)).cuda()
     outs = []
     for mode in (1, 0, 2):
-        m = _make(vad, 64, 3)
+        m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid, lstm_num_layers=3)
         load_synthetic(vad, m, 61)
         tr = vad.VideoTrainer(m.cuda(), lr=LR, weight_decay=WD, precision=precision)
         try:

@@ -154,7 +154,8 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
     p.dpre = take(N * (size_t)(H / 2) * (W / 2) * 32);
     p.g[0] = take(max_act);
     p.g[2] = take(max_act);
-    p.g[1] = p.g[2];      // (was the materialised routed gradient; kept in the debug layout as an alias)
+    p.g[1] = take(max_act);   // second buffer for the gradient of a conv output: while the weight gradient of layer k reads one on the
+                              // helper stream, the BatchNorm backward of layer k-1 writes the other
     p.ksums = take(2 * 1024);
     p.zeros = take(1024);
     // the first layer writes its BatchNorm partial sums itself: one [2][32] row per work-group, at most one per 32x16 tile
@@ -180,6 +181,8 @@ struct TrainStreams {
     hipStream_t st[7] = {};
     hipEvent_t done[8] = {};
     hipEvent_t fork = nullptr;
+    hipStream_t wg = nullptr;          // the weight-gradient GEMMs of the backward pass (beside the BatchNorm / data-gradient chain)
+    hipEvent_t wg_in = nullptr, wg_read[2] = {};
 };
 thread_local TrainStreams t_ts;
 int train_streams(int layers, TrainStreams** out) {
@@ -191,6 +194,9 @@ int train_streams(int layers, TrainStreams** out) {
         S.dev = dev;
         VAD_HIP_TRY(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
         for (int l = 0; l < 8; ++l) VAD_HIP_TRY(hipEventCreateWithFlags(&S.done[l], hipEventDisableTiming));
+        VAD_HIP_TRY(hipStreamCreateWithFlags(&S.wg, hipStreamNonBlocking));
+        VAD_HIP_TRY(hipEventCreateWithFlags(&S.wg_in, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) VAD_HIP_TRY(hipEventCreateWithFlags(&S.wg_read[i], hipEventDisableTiming));
     }
     while (S.n < layers - 1) { VAD_HIP_TRY(hipStreamCreateWithFlags(&S.st[S.n], hipStreamNonBlocking)); ++S.n; }
     *out = &S;
@@ -344,8 +350,13 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     // step t of layer l behind step t of layer l-1) and two launches share the chip; large batches keep the layers-outer order.
     const int wf_mode = vad_lstm_wavefront_mode();
     const bool wavefront = NL > 1 && g_vad_train_stop < 10 && (wf_mode == 2 || (wf_mode == 1 && (long long)B * hw <= 12288));
+    // The weight-gradient GEMMs run on a helper stream BESIDE the chain BatchNorm backward -> data gradient -> BatchNorm backward
+    // of the next layer: they are matrix- / latency-bound, the chain is HBM-bound, and nothing downstream needs them before the
+    // optimiser.  The gradient of a conv output alternates between two buffers so that the next layer's BatchNorm backward does
+    // not overwrite what a weight gradient is still reading.  Same launches, same operands: bit-identical to the serial order.
+    const bool overlap = wf_mode != 0 && g_vad_train_stop < 0;
     TrainStreams* TS = nullptr;
-    if (wavefront) TRY(train_streams(NL, &TS));
+    if (wavefront || overlap) TRY(train_streams(NL, &TS));
     for (int l = 0; l < NL; ++l) {    // h-part of every layer's t = 0 operand is the zero initial state (the x-part is written by the producer)
         const int cx = p.lstm_cin(l), cin = cx + Hd;
         VAD_HIP_TRY(hipMemset2DAsync(A(p.cat[l], cx), (size_t)cin * es, 0, (size_t)Hd * es, (size_t)B * hw, s));
@@ -409,15 +420,38 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     if (g_vad_train_stop == 20) return VAD_OK;      // debug: g0 = gradient of the last decoder activation, dpre intact
 
     // ================================================================================== backward
-    { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.r[2]), A(p.dpre), G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, precision, s)); }
+    float* dyb[2] = {g2, overlap ? A(p.g[1]) : g2};
+    bool dy_pending[2] = {false, false};
+    int dy_turn = 0, dy_cur = 0;
+    hipStream_t wgs = overlap ? TS->wg : s;
+    // the buffer the next BatchNorm backward writes: behind the weight gradient that last read it
+    auto acquire_dy = [&]() -> float* {
+        dy_cur = dy_turn; dy_turn ^= 1;
+        if (dy_pending[dy_cur]) { (void)hipStreamWaitEvent(s, TS->wg_read[dy_cur], 0); dy_pending[dy_cur] = false; }
+        return dyb[dy_cur];
+    };
+    // the helper stream picks up behind everything the caller's stream has launched so far
+    auto wg_begin = [&]() -> int {
+        if (overlap) { VAD_HIP_TRY(hipEventRecord(TS->wg_in, s)); VAD_HIP_TRY(hipStreamWaitEvent(wgs, TS->wg_in, 0)); }
+        return VAD_OK;
+    };
+    auto wg_end_reads_dy = [&]() -> int {
+        if (overlap) { VAD_HIP_TRY(hipEventRecord(TS->wg_read[dy_cur], wgs)); dy_pending[dy_cur] = true; }
+        return VAD_OK;
+    };
+    TRY(wg_begin());
+    { PSS(TS_WGRAD, wgs); TRY(vad_conv_wgrad(A(p.r[2]), A(p.dpre), G + p.t_w, ws + p.wgrad_ws, N, H / 2, W / 2, 32, 32, 1, 3, precision, wgs)); }
     for (int j = 2; j >= 0; --j) {
         const int ci = p.decC[j], co = p.decC[j + 1], hj = p.h16 << j, wj = p.w16 << j;
         const float* in = j == 0 ? dec_in : A(p.r[j - 1]);
         // g0 = d r_j (dense, 2hj x 2wj) -> g2 = d u_j in the space-to-depth view [N][hj][wj][4*co]
+        g2 = acquire_dy();
         { PS(TS_BN_BWD);
         TRY(vad_bn_act_pool_bwd_t(A(p.u[j]), io, ws + p.st_d[j], P + p.d_g[j], P + p.d_be[j], g0, 0, 0, 0, 0, g2, 1, G + p.d_g[j], G + p.d_be[j],
                                   ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s)); }
-        { PS(TS_WGRAD); TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, precision, s)); }
+        TRY(wg_begin());
+        { PSS(TS_WGRAD, wgs); TRY(vad_conv_wgrad(in, g2, G + p.d_w[j], ws + p.wgrad_ws, N, hj, wj, ci, 4 * co, 1, 1, precision, wgs)); }
+        TRY(wg_end_reads_dy());
         // bias of a conv that feeds a batch-statistics BatchNorm: sum(dy) = gamma*invstd*(sum(dz) - M*k1 - k2*sum(xhat)) = 0
         // exactly (the batch mean removes any constant).  Autograd returns ~1e-9 rounding noise there, which Adam turns
         // into a +-lr random walk; an exact zero costs no pass over the tensor and leaves the bias where it is.
@@ -428,8 +462,12 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     // g0 = gradient of the decoder input [b*T+t][hw][L]; through proj when present
     const float* dhseq = g0;
     if (p.proj) {
-        { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.hseq), g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, precision, s)); }
+        // (the split-K scratch belongs to the helper stream; this one reads g0, which the chain reuses: it is waited for at once)
+        TRY(wg_begin());
+        { PSS(TS_WGRAD, wgs); TRY(vad_conv_wgrad(A(p.hseq), g0, G + p.pj_w, ws + p.wgrad_ws, N, p.h16, p.w16, Hd, L, 1, 4, precision, wgs)); }
+        if (overlap) { VAD_HIP_TRY(hipEventRecord(TS->wg_in, wgs)); VAD_HIP_TRY(hipStreamWaitEvent(s, TS->wg_in, 0)); }
         { PS(TS_STATS_MISC); TRY(vad_chan_sum_t(g0, io, (long long)N * hw, L, G + p.pj_b, ws + p.chan_ws, s)); }
+        g2 = acquire_dy();
         { PS(TS_CONVT_DGRAD); TRY(vad_conv1x1_p(g0, ws + p.pk_pj_dg, zeros, g2, (long long)N * hw, L, Hd, precision, s)); }
         dhseq = g2;
     }
@@ -454,7 +492,8 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     // weight / bias gradients of a cell's convolution over all its steps at once (frames = T*B)
     auto lstm_wgrad = [&](int l) -> int {
         const int cin = p.lstm_cin(l) + Hd;
-        { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.cat[l]), A(p.dzl[l]), G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, s)); }
+        TRY(wg_begin());           // (reads cat[l] / dzl[l] only: nothing later overwrites them)
+        { PSS(TS_WGRAD, wgs); TRY(vad_conv_wgrad(A(p.cat[l]), A(p.dzl[l]), G + p.l_w[l], ws + p.wgrad_ws, N, p.h16, p.w16, cin, 4 * Hd, 9, 0, precision, wgs)); }
         PS(TS_STATS_MISC);
         return vad_chan_sum_t(A(p.dzl[l]), io, (long long)N * hw, 4 * Hd, G + p.l_b[l], ws + p.chan_ws, s);
     };
@@ -480,6 +519,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     // encoder, last stage first; the x-part of layer 0's operand gradient is d(latent features)
     for (int k = 3; k >= 0; --k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
+        g2 = acquire_dy();
         { PS(TS_BN_BWD);
         if (k == 3)
             TRY(vad_bn_act_pool_bwd_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.dcat[0]), 0, L + Hd, T, B, g2, 0,
@@ -489,14 +529,20 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
                                       G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         }
         VAD_HIP_TRY(hipMemsetAsync(G + p.e_b[k], 0, (size_t)co * sizeof(float), s));      // structurally zero, see the decoder loop
+        TRY(wg_begin());
         if (k == 0) {
-            PS(TS_C3_WGRAD);
-            TRY(vad_conv_c3_wgrad_t(x, g2, io, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, s));
+            PSS(TS_C3_WGRAD, wgs);
+            TRY(vad_conv_c3_wgrad_t(x, g2, io, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, wgs));
         } else {
-            { PS(TS_WGRAD); TRY(vad_conv_wgrad(A(p.a[k - 1]), g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, s)); }
+            { PSS(TS_WGRAD, wgs); TRY(vad_conv_wgrad(A(p.a[k - 1]), g2, G + p.e_w[k], ws + p.wgrad_ws, N, hk, wk, ci, co, 9, 0, precision, wgs)); }
+            TRY(wg_end_reads_dy());
             PS(TS_CONV_DGRAD);
             TRY(conv3(g2, ws + p.pk_e_dg[k], zeros, g0, N, hk, wk, co, ci, nullptr, nullptr, s));
         }
+    }
+    if (overlap) {             // join: the optimiser reads every gradient
+        VAD_HIP_TRY(hipEventRecord(TS->wg_in, wgs));
+        VAD_HIP_TRY(hipStreamWaitEvent(s, TS->wg_in, 0));
     }
     return VAD_OK;
 }
