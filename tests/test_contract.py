@@ -269,6 +269,48 @@ def test_bn_folding_and_packing_layout(vad):
     assert np.array_equal(ot.reshape(4, 8, 32, 8), wt.reshape(8, 8, 32, 4).transpose(3, 0, 2, 1))
 
 
+def test_winograd_packing_is_the_same_convolution(vad):
+    """vad_pack_conv3x3_wino (no GPU needed): the packed U = G g G^T, laid out [16][cin/8][cout][8] with BatchNorm folded, is the
+    filter transform of Winograd F(2x2,3x3).  Pinned two ways: against numpy's G g G^T, and end to end - a numpy restatement of
+    the kernel's arithmetic (input transform B^T d B, 16 element-wise products summed over channels, output transform A^T m A)
+    on the packed operands reproduces the C oracle's direct convolution + folded BatchNorm on ragged sizes."""
+    from oracle import c_oracle
+    lib = vad.hip.lib()
+    rng = np.random.default_rng(5)
+    cout, cin, n, h, w_ = 32, 16, 2, 6, 10
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    bn = [rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32),
+          rng.standard_normal(cout).astype(np.float32), rng.uniform(0.2, 2.0, cout).astype(np.float32)]
+    out = np.empty(lib.vad_pack_conv3x3_wino_floats(cout, cin), np.float32)
+    bo = np.empty(cout, np.float32)
+    ptrs = (C.c_void_p * 4)(*[a.ctypes.data for a in bn])
+    vad.hip.check(lib.vad_pack_conv3x3_wino(wt.ctypes.data, b.ctypes.data, ptrs, cout, cin, out.ctypes.data, bo.ctypes.data))
+    assert out.size == 16 * cin * cout
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    s = bn[0].astype(np.float64) / np.sqrt(bn[3].astype(np.float64) + 1e-5)
+    U = np.einsum("ra,oiab,cb->rcoi", G, wt.astype(np.float64) * s[:, None, None, None], G)          # [fr][fc][co][ci]
+    got = out.reshape(16, cin // 8, cout, 8).transpose(0, 2, 1, 3).reshape(4, 4, cout, cin)
+    assert np.allclose(got, U, rtol=0, atol=1e-7) and np.array_equal(bo, ((b.astype(np.float64) - bn[2]) * s + bn[1]).astype(np.float32))
+    x = rng.standard_normal((n, cin, h, w_)).astype(np.float32)
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    xp = np.zeros((n, cin, h + 2 + 1, w_ + 2 + 1))                    # zero padding (+1: partial last tiles on odd sizes)
+    xp[:, :, 1:h + 1, 1:w_ + 1] = x
+    y = np.zeros((n, cout, h + 1, w_ + 1))
+    for ty in range(0, h, 2):
+        for tx in range(0, w_, 2):
+            d = xp[:, :, ty:ty + 4, tx:tx + 4]
+            V = np.einsum("ri,ncij,sj->nrsc", BT, d, BT)
+            M = np.einsum("nrsc,rsoc->nrso", V, got.astype(np.float64))
+            y[:, :, ty:ty + 2, tx:tx + 2] = np.einsum("ir,nrso,js->noij", AT, M, AT)
+    y = y[:, :, :h, :w_] + bo[None, :, None, None]
+    ref = c_oracle.batchnorm_eval(c_oracle.conv2d(x, wt, b, 3), *bn)
+    assert np.abs(y - ref).max() < 2e-5
+    assert lib.vad_pack_conv3x3(wt.ctypes.data, b.ctypes.data, None, cout, cin, 4, out.ctypes.data, bo.ctypes.data) == -1   # the direct packer refuses the mode
+    assert b"vad_pack_conv3x3_wino" in lib.vad_last_error()
+
+
 def test_model_pack_consumes_state_dict_in_order(vad):
     lib = vad.hip.lib()
     m = vad.ConvAutoencoder(latent_dim=64)
@@ -283,6 +325,9 @@ def test_model_pack_consumes_state_dict_in_order(vad):
     split = np.empty_like(blob)
     vad.hip.check(lib.vad_img_pack(vad.hip.pointer_array(params), 92, 3, 64, 1, split.ctypes.data))
     assert lib.vad_blob_precision(split.ctypes.data) == 1 and not np.array_equal(split[4:], blob[4:])
+    wino = np.empty_like(blob)                    # VAD_PREC_WINO: same layout (a 3x3 slot holds either form), its own tag
+    vad.hip.check(lib.vad_img_pack(vad.hip.pointer_array(params), 92, 3, 64, 4, wino.ctypes.data))
+    assert lib.vad_blob_precision(wino.ctypes.data) == 4 and np.isfinite(wino).all() and not np.array_equal(wino[4:], blob[4:])
     assert lib.vad_blob_precision(blob[8:].ctypes.data) == -1 and b"not a packed model blob" in lib.vad_last_error()
     assert lib.vad_img_pack(vad.hip.pointer_array(params), 92, 3, 64, 7, blob.ctypes.data) == -1 and b"precision" in lib.vad_last_error()
     assert not hasattr(lib, "vad_set_precision")
