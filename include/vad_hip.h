@@ -267,7 +267,7 @@ int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, const float* bi
 int vad_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* Device-side operand packing of the CURRENT parameters (no BatchNorm folding in train mode; the layout follows
- * `precision` like the host packers):
+ * `precision` like the host packers; VAD_PREC_WINO: both operands in Winograd form, vad_pack_conv3x3_wino_floats of room each):
  * fwd = the forward kernels' order (vad_pack_conv3x3 / vad_pack_convt2x2 / vad_pack_conv3x3_c3 layouts);
  * dgrad = the data-gradient operand: for conv3x3 a conv3x3 weight with cin/cout swapped and taps rotated (run it
  * through vad_conv3x3), for convT a 1x1 weight with K = 4*cout (run vad_conv1x1 on the space-to-depth gradient). */
@@ -324,7 +324,12 @@ int vad_conv3x3_c3_bf16(const float* x_nchw, const float* w_packed, const float*
  * is given), nn.MSELoss, and the full backward.  precision VAD_PREC_FP32: exact fp32; VAD_PREC_SPLIT / VAD_PREC_BF16: the 3x3
  * and transposed convolutions (forward + data gradients) use split-fp16 / bf16 operands with fp32 accumulation (bf16: the
  * weight gradients too), the rest (first and last layer, 1x1 data gradients, BatchNorm, gates, loss, Adam, master weights;
- * in split mode also the weight gradients) stays fp32.  params / grads: flat fp32 device buffers of vad_vid_train_nparams
+ * in split mode also the weight gradients) stays fp32.  VAD_PREC_BF16S: VAD_PREC_BF16 with every activation / gradient tensor
+ * of the workspace stored as bf16.  VAD_PREC_WINO: fp32 everywhere, the 3x3 convolutions behind the first layer (forward + data
+ * gradients, ConvLSTM gate convolutions included) as Winograd F(2x2,3x3) (csrc/conv_wino.hip).  With more than one ConvLSTM layer
+ * and a small batch the layers run as a wavefront on library-owned helper streams, and the weight-gradient GEMMs run on a helper
+ * stream beside the BatchNorm / data-gradient chain; both fork from and join `stream` (vad_debug_set_lstm_wavefront(0): serial
+ * order, bit-identical).  params / grads: flat fp32 device buffers of vad_vid_train_nparams
  * floats, torch layouts in named_parameters() order (see csrc/train_step.hip); running: vad_vid_train_nstats floats,
  * {running_mean, running_var} per BatchNorm in module order.  x [B,T,3,H,W]; loss: device float[1];
  * recon (nullable) [B,T,3,H,W].  Every gradient is overwritten (no accumulation), so there is no zero_grad.
