@@ -1,6 +1,6 @@
 """Seeded random sweep of the scoring entry points against the CPU oracle: frame sizes (multiples of 16, non-square),
 batch sizes that do not divide the chunk, chunk sizes, latent / hidden sizes, number of ConvLSTM layers, clip lengths,
-both arithmetic modes and uint8 ingest.  Every case is an exact statement of the drop-in contract: scores within 1e-5
+the three arithmetic modes (exact fp32, split-fp16, Winograd) and uint8 ingest.  Every case is an exact statement of the drop-in contract: scores within 1e-5
 relative of the reference arithmetic, identical under re-chunking."""
 import os
 
@@ -26,7 +26,7 @@ def test_image_random_configuration(vad, seed):
     h, w = (int(16 * rng.integers(1, 9)) for _ in range(2))
     b = int(rng.integers(1, 12))
     chunk = int(rng.integers(1, 9))
-    precision = "split" if seed % 3 == 2 else "fp32"
+    precision = ("fp32", "winograd", "split")[seed % 3]
     m = vad.ConvAutoencoder(in_channels=3, latent_dim=latent)
     st = load_synthetic(vad, m, 300 + seed)
     m = m.cuda().eval()
@@ -55,7 +55,8 @@ def test_video_random_configuration(vad, seed):
     layers = int(rng.integers(1, 4))
     h, w = (int(16 * rng.integers(1, 6)) for _ in range(2))
     b, t = int(rng.integers(1, 5)), int(rng.integers(1, 7))
-    precision = "split" if (seed % 3 == 2 and hid == latent) else "fp32"     # split ConvLSTM step: x and h halves of equal width
+    # split ConvLSTM step: x and h halves of equal width; winograd: any widths (layer 0 stays direct when they pad differently)
+    precision = "split" if (seed % 3 == 2 and hid == latent) else ("winograd" if seed % 3 == 1 else "fp32")
     m = vad.VideoAutoencoder(in_channels=3, latent_dim=latent, lstm_hidden_dim=hid, lstm_num_layers=layers)
     st = load_synthetic(vad, m, 700 + seed)
     m = m.cuda().eval()
