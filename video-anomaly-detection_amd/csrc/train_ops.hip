@@ -1694,7 +1694,10 @@ extern "C" int vad_debug_set_wgrad_pairs(int on) { g_wgrad_x2 = on; return VAD_O
 // steps (32 clips / 128 images): a 2048-wave target is within noise of 4096 (35.8 vs 35.6-36.0 ms, 38.5 vs 39.0 ms), 1024
 // is 13 % slower; the partial buffers are small either way.
 static int wgrad_splits(long long tiles, int total_rows) {
-    long long s = (4096 + tiles - 1) / tiles;
+    // ~2048 wave items per launch = ONE round of the resident slots (2 work-groups of 4 waves on 256 CUs).  4096 (rounds 1-3)
+    // balanced the tail better but doubled the partials the reduction reads (~150 MB per launch): measured per 32-clip step
+    // 4096 / 3072 / 2048 / 1536 / 1024 items: bf16 10.54 / 10.53 / 10.46 / 10.62 / 10.84 ms, fp32 31.5 / 32.1 / 31.0 / 32.7 / 34.8.
+    long long s = (2048 + tiles - 1) / tiles;
     if (s > total_rows) s = total_rows;
     if (s > 2048) s = 2048;
     if (s < 1) s = 1;
