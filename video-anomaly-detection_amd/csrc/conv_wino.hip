@@ -321,7 +321,10 @@ extern "C" int vad_conv3x3_wino(const float* in, long long in_fs, const float* w
     p.out_fs = out_fs ? out_fs : (long long)ho * wo * cout;
     p.n = n; p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout;
     p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 7) / 8;
-    const bool two = cout % 64 == 0;
+    // Two N-tiles per wave (64 channels per work-group) halve the input transform per MFMA; when that grid would leave CUs idle
+    // (the reference's own call sizes) one N-tile per wave gives twice the work-groups and half the serial K loop per wave.  The
+    // accumulation order of an output does not depend on NT: the same bits either way.
+    const bool two = cout % 64 == 0 && (long long)n * p.tiles_x * p.tiles_y * (cout / 64) >= wino_num_cus();
     p.cblocks = cout / (two ? 64 : 32);
     VAD_REQUIRE((long long)p.tiles_x * p.tiles_y * p.cblocks < (1ll << 24), "conv3x3_wino: %d x %d x %d work-group positions out of range", p.tiles_x, p.tiles_y, p.cblocks);
     return two ? launch_wino_nt<2>(p, act, pool, (hipStream_t)stream) : launch_wino_nt<1>(p, act, pool, (hipStream_t)stream);
@@ -378,8 +381,11 @@ extern "C" int vad_convlstm_step_wino(const float* x, long long x_fs, const floa
     p.in2 = h_prev; p.in2_fs = h_prev_fs ? h_prev_fs : (long long)h * wd * hid;
     p.w = w; p.bias = bias; p.out = z_ws; p.out_fs = (long long)h * wd * cout;
     p.n = n; p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout;
-    p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 7) / 8; p.cblocks = cout / 64;
-    TRYW(launch_wino_nt<2>(p, VAD_ACT_NONE, 0, (hipStream_t)stream));
+    p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 7) / 8;
+    const bool two = (long long)n * p.tiles_x * p.tiles_y * (cout / 64) >= wino_num_cus();     // see vad_conv3x3_wino
+    p.cblocks = cout / (two ? 64 : 32);
+    if (two) TRYW(launch_wino_nt<2>(p, VAD_ACT_NONE, 0, (hipStream_t)stream));
+    else TRYW(launch_wino_nt<1>(p, VAD_ACT_NONE, 0, (hipStream_t)stream));
     CellP c{};
     c.z = z_ws; c.c_prev = c_prev; c.c_out = c_out; c.h_out = h_out;
     c.h_fs = h_out_fs ? h_out_fs : (long long)h * wd * hid;
