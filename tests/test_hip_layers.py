@@ -180,7 +180,8 @@ def test_convlstm_step_oracle(cx, hid, h, w, zero_state):
 
 
 @pytest.mark.parametrize("n,hid,h,w,zero_state", [(2, 128, 16, 16, False), (2, 128, 16, 16, True), (3, 64, 6, 10, False), (70, 64, 4, 4, False),
-                                                  (1, 64, 2, 2, True), (2, 64, 3, 5, False), (3, 128, 7, 7, False)])
+                                                  (1, 64, 2, 2, True), (2, 64, 3, 5, False), (3, 128, 7, 7, False),
+                                                  (40, 128, 16, 16, False), (300, 64, 4, 4, True), (70, 64, 5, 7, False)])   # the fused-cell form (grids that fill the chip)
 def test_convlstm_step_winograd(n, hid, h, w, zero_state):
     """ConvLSTMCell step with the gate convolution as ONE two-source Winograd launch (x and h halves of K; the h half skipped at
     t = 0) + the pointwise cell (vad_convlstm_step_wino; VAD_PREC_WINO models): against the oracle at the direct kernels' bound,

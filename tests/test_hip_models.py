@@ -432,6 +432,17 @@ def test_winograd_mode_holds_parity(vad, golden):
     ro = torch_oracle.vid_scores({k: torch.from_numpy(np.asarray(v)) for k, v in sto.items()}, xo.cpu(), 128, 2)
     assert rel_err(oo["frame"].cpu().numpy(), ro["frame"].numpy()) < SCORE_RTOL and max_abs(oo["recon"].cpu().numpy(), ro["recon"].numpy()) < ACT_ATOL
     assert torch.equal(dense["frame"], each["frame"]) and torch.equal(dense["seq"], each["seq"])
+    # clip-independence across the two ConvLSTM forms of this mode: 40 clips in one launch group fill the chip (the cell fused
+    # into the gate convolution's epilogue), a clip alone does not (one N-tile per wave + the pointwise cell launch): same bits
+    xc = vad.scoring.synth_frames_device(33, 0, 40 * 3, 64, 64).view(40, 3, 3, 64, 64)
+    mo.chunk = 64
+    with torch.no_grad():
+        big = mo.score_seq_and_frames(xc)
+        alone = [mo.score_seq_and_frames(xc[i:i + 1]) for i in (0, 21, 39)]
+    for i, a in zip((0, 21, 39), alone):
+        assert torch.equal(a["frame"], big["frame"][i:i + 1]) and torch.equal(a["seq"], big["seq"][i:i + 1]), i
+    rc = torch_oracle.vid_scores({k: torch.from_numpy(np.asarray(v)) for k, v in sto.items()}, xc[[0, 39]].cpu(), 128, 2)
+    assert rel_err(big["frame"][[0, 39]].cpu().numpy(), rc["frame"].numpy()) < SCORE_RTOL
     # frame-independence holds in this mode too: a frame's score does not depend on its batch or position
     g = golden("img_l256_64.npz")
     m, _ = _img_model(vad, 256, int(g["wseed"]))

@@ -37,10 +37,17 @@ struct ConvWP {
     float* out;       long long out_fs;    // NHWC [n][h or h/2][w or w/2][cout]
     int n, h, w_, cin, cout;
     int tiles_x, tiles_y, cblocks;
+    // POOL == 2 (ConvLSTM cell fused into the epilogue): cout = 4 * hid gate pre-activations, `out` = h' [n][h][w][hid];
+    const float* c_prev; float* c_out; int hid;   // c_prev NULL = zero initial state; dense [n][h][w][hid]
 };
 
+// POOL: 0 = plain, 1 = MaxPool2d(2,2) fused (a tile's 2x2 outputs are one window), 2 = ConvLSTM cell fused (NT == 2): a work-group
+// owns 16 hidden channels - N-tile 0 = their i | f gates (lanes 0-15 | 16-31), N-tile 1 = g | o - so that after the row half of the
+// output transform the lane pair (li, li ^ 16) holds all four gates of a hidden channel; the pair swaps half of its values
+// (ds_swizzle, xor 16) and each lane finishes the cells of one column parity: models/video_autoencoder.py:73-83, vad_lstm_cell.
 template <int NT, int POOL, int ACT>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
+    static_assert(POOL != 2 || NT == 2, "fused ConvLSTM cell: two N-tiles (i|f and g|o) per wave");
     constexpr int CK = 32, LW = 18, LH = 10, PS = CK + 4, NPIX = LW * LH;
     constexpr int TOT = NPIX * (CK / 4), NPF = (TOT + 255) / 256;
     constexpr int XF = 4 * 2 * NT * 64 * 16;                        // exchange floats
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
     float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = (cb * NT + nt) * 32 + li;
+        const int co = (POOL == 2) ? (2 * nt + (li >> 4)) * p.hid + cb * 16 + (li & 15) : (cb * NT + nt) * 32 + li;
         wl[nt] = (unsigned)(wave * 4) * ftap + (unsigned)co * 32u + 16u * lh;
         bv[nt] = p.bias[co];
     }
@@ -116,12 +123,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
     }
 
     // ---- epilogue geometry: wave w finishes tile row w; lane = (channel li, column half lh), kk = tile column 4 lh + kk
-    const int ech = p.cout;
-    const int ow = POOL ? (W >> 1) : W, oh = POOL ? (H >> 1) : H;
-    const int ey0 = POOL ? (y0 >> 1) + wave : y0 + 2 * wave;
-    const int ex0 = POOL ? (x0 >> 1) + 4 * lh : x0 + 8 * lh;
+    const int ech = (POOL == 2) ? p.hid : p.cout;
+    const int ow = (POOL == 1) ? (W >> 1) : W, oh = (POOL == 1) ? (H >> 1) : H;
+    const int ey0 = (POOL == 1) ? (y0 >> 1) + wave : y0 + 2 * wave;
+    const int ex0 = (POOL == 1) ? (x0 >> 1) + 4 * lh : x0 + 8 * lh;
     const unsigned erow = (unsigned)__mul24(ow, ech) * 4u, ecol = (unsigned)ech * 4u;
-    const unsigned eoff = (unsigned)(__mul24(__mul24(ey0, ow) + ex0, ech) + cb * NT * 32 + li) * 4u;
+    const unsigned eoff = (POOL == 2) ? (unsigned)(__mul24(__mul24(ey0, ow) + ex0 + (li >> 4), ech) + cb * 16 + (li & 15)) * 4u   // this lane's column parity
+                                      : (unsigned)(__mul24(__mul24(ey0, ow) + ex0, ech) + cb * NT * 32 + li) * 4u;
     const unsigned out_bytes = (unsigned)__mul24(oh, ow) * (unsigned)ech * 4u;
     const bool full_tile = (y0 + 8 <= H) && (x0 + 16 <= W);
     const int sw = (lane >> 2) & 3;                                 // 16-byte slot swizzle of the exchange records
@@ -220,34 +228,76 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_pkernel(ConvWP p) {
         __syncthreads();
         // ---- row half (over the four waves' frequency rows) for tile row `wave`: Y0 = P0 + P1 + P2, Y1 = P1 - P2 - P3
         const __amdgpu_buffer_rsrc_t ro = vad_rsrc(p.out + (size_t)n * p.out_fs, out_bytes);
+        f32x4 yy[NT][2][2];                        // [nt][dy][dx], components kk = tile column 4 lh + kk
+        float cpv[POOL == 2 ? 8 : 1];              // fused cell: previous cell state of this lane's 8 pixels (dy, kk), requested before the records are read
+        if constexpr (POOL == 2) {
+            const __amdgpu_buffer_rsrc_t rc = vad_rsrc(p.c_prev ? p.c_prev + (size_t)n * (out_bytes / 4) : p.c_out, p.c_prev ? out_bytes : 0u);   // zero-sized -> 0
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x4 y[2][2];                         // [dy][dx], components kk = tile column 4 lh + kk
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + 2 * kk + (li >> 4)) < ow);
+                    cpv[dy * 4 + kk] = vad_bload1(rc, ok ? eoff : VAD_OOB, dy * erow + 2 * kk * ecol);
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x4 pr[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pr[r] = *(const f32x4*)&smem[((((r * 2 + j) * NT + nt) * 64 + lane) * 4 + (wave ^ sw)) * 4];
-                y[0][j] = pr[0] + pr[1] + pr[2];
-                y[1][j] = pr[1] - pr[2] - pr[3];
+                yy[nt][0][j] = pr[0] + pr[1] + pr[2];
+                yy[nt][1][j] = pr[1] - pr[2] - pr[3];
             }
-            if (POOL) {
+        if constexpr (POOL == 2) {
+            // lanes li < 16 hold (i, g), lanes li >= 16 hold (f, o) of hidden channel cb*16 + (li & 15), both column parities dx.  The
+            // low lane keeps dx = 0 and hands over its dx = 1 values, the high lane the other way round: afterwards each lane has all
+            // four gates of ITS parity's 8 pixels.
+            const bool hi = (li >> 4) != 0;
+            const __amdgpu_buffer_rsrc_t rco = vad_rsrc(p.c_out + (size_t)n * (out_bytes / 4), out_bytes);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const bool ok = full_tile || (ey0 < oh && (ex0 + kk) < ow);
-                    const float m = fmaxf(fmaxf(y[0][0][kk], y[0][1][kk]), fmaxf(y[1][0][kk], y[1][1][kk]));
-                    vad_bstore1(vad_act(m + bv[nt], ACT), ro, ok ? eoff : VAD_OOB, kk * ecol + nt * 128u);
+                    float own[2], got[2];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const float keep = hi ? yy[nt][dy][1][kk] : yy[nt][dy][0][kk];
+                        const float give = hi ? yy[nt][dy][0][kk] : yy[nt][dy][1][kk];
+                        own[nt] = keep + bv[nt];
+                        got[nt] = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, give + bv[nt]), 0x401f));   // lane ^ 16
+                    }
+                    // low lane: own = (i, g), got = (f, o); high lane: own = (f, o), got = (i, g)
+                    const float zi = hi ? got[0] : own[0], zf = hi ? own[0] : got[0], zg = hi ? got[1] : own[1], zo = hi ? own[1] : got[1];
+                    float cn, hn;
+                    vad_lstm_cell(zi, zf, zg, zo, cpv[dy * 4 + kk], cn, hn);
+                    const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + 2 * kk + (li >> 4)) < ow);
+                    const unsigned so = dy * erow + 2 * kk * ecol;
+                    vad_bstore1(cn, rco, ok ? eoff : VAD_OOB, so);
+                    vad_bstore1(hn, ro, ok ? eoff : VAD_OOB, so);
                 }
-            } else {
+        } else {
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
+            for (int nt = 0; nt < NT; ++nt) {
+                if (POOL == 1) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const bool ok = full_tile || (ey0 < oh && (ex0 + kk) < ow);
+                        const float m = fmaxf(fmaxf(yy[nt][0][0][kk], yy[nt][0][1][kk]), fmaxf(yy[nt][1][0][kk], yy[nt][1][1][kk]));
+                        vad_bstore1(vad_act(m + bv[nt], ACT), ro, ok ? eoff : VAD_OOB, kk * ecol + nt * 128u);
+                    }
+                } else {
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + 2 * kk + dx) < ow);
-                            vad_bstore1(vad_act(y[dy][dx][kk] + bv[nt], ACT), ro, ok ? eoff : VAD_OOB, dy * erow + (2 * kk + dx) * ecol + nt * 128u);
-                        }
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const bool ok = full_tile || ((ey0 + dy) < oh && (ex0 + 2 * kk + dx) < ow);
+                                vad_bstore1(vad_act(yy[nt][dy][dx][kk] + bv[nt], ACT), ro, ok ? eoff : VAD_OOB, dy * erow + (2 * kk + dx) * ecol + nt * 128u);
+                            }
+                }
             }
         }
         if (!has_next) break;
@@ -383,9 +433,20 @@ extern "C" int vad_convlstm_step_wino(const float* x, long long x_fs, const floa
     p.n = n; p.h = h; p.w_ = wd; p.cin = cin; p.cout = cout;
     p.tiles_x = (wd + 15) / 16; p.tiles_y = (h + 7) / 8;
     const bool two = (long long)n * p.tiles_x * p.tiles_y * (cout / 64) >= wino_num_cus();     // see vad_conv3x3_wino
-    p.cblocks = cout / (two ? 64 : 32);
-    if (two) TRYW(launch_wino_nt<2>(p, VAD_ACT_NONE, 0, (hipStream_t)stream));
-    else TRYW(launch_wino_nt<1>(p, VAD_ACT_NONE, 0, (hipStream_t)stream));
+    if (two) {
+        // large launch groups: the cell in the convolution's epilogue - z never exists (2 x 2 KB per pixel and step of HBM traffic
+        // and one launch less per step).  Same values as the two-launch form below: the same accumulation order, the same
+        // bias add, the same vad_lstm_cell.
+        p.cblocks = hid / 16; p.hid = hid;
+        p.out = h_out; p.out_fs = h_out_fs ? h_out_fs : (long long)h * wd * hid;
+        p.c_prev = c_prev; p.c_out = c_out;
+        VAD_REQUIRE((long long)p.tiles_x * p.tiles_y * p.cblocks < (1ll << 24), "convlstm_step_wino: grid out of range");
+        launch_wino<2, 2, VAD_ACT_NONE>(p, (hipStream_t)stream);
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
+    p.cblocks = cout / 32;
+    TRYW(launch_wino_nt<1>(p, VAD_ACT_NONE, 0, (hipStream_t)stream));
     CellP c{};
     c.z = z_ws; c.c_prev = c_prev; c.c_out = c_out; c.h_out = h_out;
     c.h_fs = h_out_fs ? h_out_fs : (long long)h * wd * hid;
