@@ -79,7 +79,7 @@ def driver(pack_path: str, oracle_path: str) -> None:
     gold = REPO / "tests" / "golden"
     L = C.CDLL(pack_path)
     for f in ("vad_img_packed_floats", "vad_vid_packed_floats", "vad_pack_conv3x3_floats", "vad_pack_convt2x2_floats",
-              "vad_pack_conv1x1_floats", "vad_pack_conv3x3_to3_floats", "vad_pack_conv3x3_c3_floats"):
+              "vad_pack_conv1x1_floats", "vad_pack_conv3x3_to3_floats", "vad_pack_conv3x3_c3_floats", "vad_pack_conv3x3_wino_floats"):
         getattr(L, f).restype = C.c_size_t
     L.vad_last_error.restype = C.c_char_p
     checked = 0
@@ -88,7 +88,7 @@ def driver(pack_path: str, oracle_path: str) -> None:
         g = np.load(gold / name)
         params = _float_params(_golden_state(synth, g))
         latent = int(g["latent_dim"])
-        for prec in (0, 1):
+        for prec in (0, 1, 4):                 # exact fp32, split fp16, Winograd (VAD_PREC_WINO)
             blob = np.full(L.vad_img_packed_floats(3, latent), np.nan, np.float32)
             assert L.vad_img_pack(_ptrs(params), len(params), 3, latent, prec, _vp(blob)) == 0, L.vad_last_error()
             assert np.isfinite(blob[4:]).all() if prec == 0 else True
@@ -100,7 +100,7 @@ def driver(pack_path: str, oracle_path: str) -> None:
         g = np.load(gold / name)
         params = _float_params(_golden_state(synth, g))
         lat, hid, layers = int(g["latent_dim"]), int(g["hid"]), int(g["layers"])
-        for prec in (0, 1):
+        for prec in (0, 1, 4):
             n = L.vad_vid_packed_floats(lat, hid, layers)
             assert n > 0, name
             blob = np.full(n, np.nan, np.float32)
@@ -118,6 +118,9 @@ def driver(pack_path: str, oracle_path: str) -> None:
         bo = np.empty(cout, np.float32)
         for prec in ((0, 1) if cin % 16 == 0 else (0,)):
             assert L.vad_pack_conv3x3(_vp(w), _vp(b), _ptrs(bn), cout, cin, prec, _vp(out), _vp(bo)) == 0
+        ow = np.empty(L.vad_pack_conv3x3_wino_floats(cout, cin), np.float32)
+        assert L.vad_pack_conv3x3_wino(_vp(w), _vp(b), _ptrs(bn), cout, cin, _vp(ow), _vp(bo)) == 0 and np.isfinite(ow).all()
+        assert L.vad_pack_conv3x3(_vp(w), _vp(b), _ptrs(bn), cout, cin, 4, _vp(out), _vp(bo)) < 0      # the direct packer refuses the mode
         wt = rng.standard_normal((cin, cout, 2, 2)).astype(np.float32)
         ot = np.empty(L.vad_pack_convt2x2_floats(cin, cout), np.float32)
         assert L.vad_pack_convt2x2(_vp(wt), _vp(b), None, cin, cout, 0, _vp(ot), _vp(bo)) == 0
