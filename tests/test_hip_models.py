@@ -515,7 +515,6 @@ def test_winograd_mode_through_capture_windows_and_threads(vad):
     assert not errs and not any(th.is_alive() for th in ths), errs
     for i in range(3):
         assert torch.equal(res[i], single[i]), i
-    assert not torch.equal(single[0], single[2]) or True      # (modes may coincide on tiny inputs; equality is not required either way)
 
 
 def test_two_threads_with_different_precision_do_not_interfere(vad):
