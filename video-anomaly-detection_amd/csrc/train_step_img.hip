@@ -63,10 +63,11 @@ bool make_plan(ImgPlan& p, int N, int H, int W, int L) {
     const size_t n = (size_t)N;
     for (int i = 0; i < 4; ++i) {
         const int ci = c[i], co = c[i + 1], hi = H >> i, wi = W >> i;
-        p.pk_ea[i] = take(i == 0 ? vad_pack_conv3x3_c3_floats(co) : vad_pack_conv3x3_floats(co, ci));
-        p.pk_ea_dg[i] = i == 0 ? 0 : take(vad_pack_conv3x3_floats(ci, co));
-        p.pk_eb[i] = take(vad_pack_conv3x3_floats(co, co));
-        p.pk_eb_dg[i] = take(vad_pack_conv3x3_floats(co, co));
+        // (3x3 operand slots hold either form of a layer: direct, 9 taps, or Winograd, 16 - VAD_PREC_WINO)
+        p.pk_ea[i] = take(i == 0 ? vad_pack_conv3x3_c3_floats(co) : vad_pack_conv3x3_wino_floats(co, ci));
+        p.pk_ea_dg[i] = i == 0 ? 0 : take(vad_pack_conv3x3_wino_floats(ci, co));
+        p.pk_eb[i] = take(vad_pack_conv3x3_wino_floats(co, co));
+        p.pk_eb_dg[i] = take(vad_pack_conv3x3_wino_floats(co, co));
         const size_t sz = n * hi * wi * co;
         if (sz > max_act) max_act = sz;
         p.ya[i] = take(sz); p.a[i] = take(sz); p.yb[i] = take(sz); p.p[i] = take(sz / 4);
@@ -85,8 +86,8 @@ bool make_plan(ImgPlan& p, int N, int H, int W, int L) {
         chan((long long)n * 4 * hj * wj, co);
         wg(vad_conv_wgrad_ws_floats(N, hj, 1, ci, 4 * co));
         if (j < 3) {
-            p.pk_dc[j] = take(vad_pack_conv3x3_floats(co, co));
-            p.pk_dc_dg[j] = take(vad_pack_conv3x3_floats(co, co));
+            p.pk_dc[j] = take(vad_pack_conv3x3_wino_floats(co, co));
+            p.pk_dc_dg[j] = take(vad_pack_conv3x3_wino_floats(co, co));
             p.yc[j] = take(sz); p.rc[j] = take(sz); p.st_dc[j] = take(2 * (size_t)co);
             wg(vad_conv_wgrad_ws_floats(N, 2 * hj, 9, co, co));
         }
@@ -145,7 +146,12 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
     VAD_REQUIRE(x && params && grads && workspace && loss, "img_train_fwd_bwd: null pointer");
     // precision VAD_PREC_SPLIT: the 3x3 / transposed convolutions (forward + data gradients) on split-fp16 operands, as in
     // the video step; first layer, last layer, weight gradients, BatchNorm, criterion and Adam stay fp32
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16, "img_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16) or 2 (bf16)", precision);
+    // VAD_PREC_WINO: fp32 everywhere, the 3x3 convolutions behind the first layer (forward + data gradients) as Winograd F(2x2,3x3)
+    VAD_REQUIRE((precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16) || precision == VAD_PREC_WINO,
+                "img_train_fwd_bwd: precision=%d must be 0 (fp32), 1 (split fp16), 2 (bf16 operands) or 4 (Winograd)", precision);
+    const bool wino = precision == VAD_PREC_WINO;
+    const int pack_prec = precision;
+    if (wino) precision = VAD_PREC_FP32;
     VAD_REQUIRE(loss_kind >= 0 && loss_kind <= 2, "img_train_fwd_bwd: loss_kind must be 0 (mse), 1 (ssim) or 2 (combined)");
     ImgPlan p;
     VAD_REQUIRE(make_plan(p, n, h, w, latent), "img_train_fwd_bwd: unsupported configuration (N=%d %dx%d latent=%d): H, W multiples "
@@ -167,15 +173,21 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
         return vad_bn_stats(y, npix, c, eps, mom, ws + st, r, r ? r + c : nullptr, ws + p.chan_ws, s);
     };
 
+    // a 3x3 convolution [n][hh][ww][ci] -> [n][hh][ww][co] without activation, in the step's mode
+    auto conv3 = [&](const float* in, const float* wpk, const float* bias, float* out, int hh, int ww, int ci, int co) -> int {
+        if (wino) return vad_conv3x3_wino(in, 0, wpk, bias, out, 0, N, hh, ww, ci, co, VAD_ACT_NONE, 0, s);
+        return vad_conv3x3(in, 0, wpk, bias, out, 0, N, hh, ww, ci, co, VAD_ACT_NONE, 0, precision, s);
+    };
+
     // ---- operand packing of the current parameters
     TRY(vad_train_pack_conv3x3_c3(P + p.ea_w[0], 32, ws + p.pk_ea[0], s));
     for (int i = 0; i < 4; ++i) {
-        if (i > 0) TRY(vad_train_pack_conv3x3(P + p.ea_w[i], p.c[i + 1], p.c[i], ws + p.pk_ea[i], ws + p.pk_ea_dg[i], precision, s));
-        TRY(vad_train_pack_conv3x3(P + p.eb_w[i], p.c[i + 1], p.c[i + 1], ws + p.pk_eb[i], ws + p.pk_eb_dg[i], precision, s));
+        if (i > 0) TRY(vad_train_pack_conv3x3(P + p.ea_w[i], p.c[i + 1], p.c[i], ws + p.pk_ea[i], ws + p.pk_ea_dg[i], pack_prec, s));
+        TRY(vad_train_pack_conv3x3(P + p.eb_w[i], p.c[i + 1], p.c[i + 1], ws + p.pk_eb[i], ws + p.pk_eb_dg[i], pack_prec, s));
     }
     for (int j = 0; j < 4; ++j) {
         TRY(vad_train_pack_convt2x2(P + p.dt_w[j], p.d[j], p.d[j + 1], ws + p.pk_dt[j], ws + p.pk_dt_dg[j], precision, s));
-        if (j < 3) TRY(vad_train_pack_conv3x3(P + p.dc_w[j], p.d[j + 1], p.d[j + 1], ws + p.pk_dc[j], ws + p.pk_dc_dg[j], precision, s));
+        if (j < 3) TRY(vad_train_pack_conv3x3(P + p.dc_w[j], p.d[j + 1], p.d[j + 1], ws + p.pk_dc[j], ws + p.pk_dc_dg[j], pack_prec, s));
     }
     TRY(vad_train_pack_conv3x3_to3(P + p.last_w, 32, ws + p.pk_last, ws + p.pk_last_dg, s));
 
@@ -185,10 +197,10 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
         const int ci = p.c[i], co = p.c[i + 1], hi = H >> i, wi = W >> i;
         const long long npix = (long long)N * hi * wi;
         if (i == 0) TRY(vad_conv3x3_c3(x, ws + p.pk_ea[0], P + p.ea_b[0], ws + p.ya[0], N, hi, wi, co, VAD_ACT_NONE, 0, s));
-        else TRY(vad_conv3x3(ws + p.p[i - 1], 0, ws + p.pk_ea[i], P + p.ea_b[i], ws + p.ya[i], 0, N, hi, wi, ci, co, VAD_ACT_NONE, 0, precision, s));
+        else TRY(conv3(ws + p.p[i - 1], ws + p.pk_ea[i], P + p.ea_b[i], ws + p.ya[i], hi, wi, ci, co));
         TRY(bn_stats(ws + p.ya[i], npix, co, p.st_ea[i], p.rs_ea[i]));
         TRY(vad_bn_act_pool_fwd(ws + p.ya[i], ws + p.st_ea[i], P + p.ea_g[i], P + p.ea_be[i], ws + p.a[i], 0, 0, 0, 0, N, hi, wi, co, VAD_ACT_LEAKY, 0, s));
-        TRY(vad_conv3x3(ws + p.a[i], 0, ws + p.pk_eb[i], P + p.eb_b[i], ws + p.yb[i], 0, N, hi, wi, co, co, VAD_ACT_NONE, 0, precision, s));
+        TRY(conv3(ws + p.a[i], ws + p.pk_eb[i], P + p.eb_b[i], ws + p.yb[i], hi, wi, co, co));
         TRY(bn_stats(ws + p.yb[i], npix, co, p.st_eb[i], p.rs_eb[i]));
         TRY(vad_bn_act_pool_fwd(ws + p.yb[i], ws + p.st_eb[i], P + p.eb_g[i], P + p.eb_be[i], ws + p.p[i], 0, 0, 0, 0, N, hi, wi, co, VAD_ACT_LEAKY, 1, s));
     }
@@ -201,7 +213,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
         TRY(bn_stats(ws + p.ut[j], npix, co, p.st_dt[j], p.rs_dt[j]));
         TRY(vad_bn_act_pool_fwd(ws + p.ut[j], ws + p.st_dt[j], P + p.dt_g[j], P + p.dt_be[j], ws + p.rt[j], 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
         if (j < 3) {
-            TRY(vad_conv3x3(ws + p.rt[j], 0, ws + p.pk_dc[j], P + p.dc_b[j], ws + p.yc[j], 0, N, 2 * hj, 2 * wj, co, co, VAD_ACT_NONE, 0, precision, s));
+            TRY(conv3(ws + p.rt[j], ws + p.pk_dc[j], P + p.dc_b[j], ws + p.yc[j], 2 * hj, 2 * wj, co, co));
             TRY(bn_stats(ws + p.yc[j], npix, co, p.st_dc[j], p.rs_dc[j]));
             TRY(vad_bn_act_pool_fwd(ws + p.yc[j], ws + p.st_dc[j], P + p.dc_g[j], P + p.dc_be[j], ws + p.rc[j], 0, 0, 0, 0, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
         }
@@ -233,7 +245,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
                                     ws + p.ksums, ws + p.chan_ws, N, 2 * hj, 2 * wj, co, VAD_ACT_RELU, 0, s));
             TRY(vad_conv_wgrad(ws + p.rt[j], g2, G + p.dc_w[j], ws + p.wgrad_ws, N, 2 * hj, 2 * wj, co, co, 9, 0, precision, s));
             VAD_HIP_TRY(hipMemsetAsync(G + p.dc_b[j], 0, (size_t)co * sizeof(float), s));       // structurally zero (train_step.hip)
-            TRY(vad_conv3x3(g2, 0, ws + p.pk_dc_dg[j], zeros, g0, 0, N, 2 * hj, 2 * wj, co, co, VAD_ACT_NONE, 0, precision, s));
+            TRY(conv3(g2, ws + p.pk_dc_dg[j], zeros, g0, 2 * hj, 2 * wj, co, co));
         }
         // convT-BN-ReLU: g0 = d rt_j -> g2 = d ut_j (space-to-depth) -> weight gradient, g0 = d (input of the convT)
         const float* in = j == 0 ? ws + p.p[3] : ws + p.rc[j - 1];
@@ -249,7 +261,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
                                 ws + p.ksums, ws + p.chan_ws, N, hi, wi, co, VAD_ACT_LEAKY, 1, s));
         TRY(vad_conv_wgrad(ws + p.a[i], g2, G + p.eb_w[i], ws + p.wgrad_ws, N, hi, wi, co, co, 9, 0, precision, s));
         VAD_HIP_TRY(hipMemsetAsync(G + p.eb_b[i], 0, (size_t)co * sizeof(float), s));
-        TRY(vad_conv3x3(g2, 0, ws + p.pk_eb_dg[i], zeros, g0, 0, N, hi, wi, co, co, VAD_ACT_NONE, 0, precision, s));          // g0 = d a_i
+        TRY(conv3(g2, ws + p.pk_eb_dg[i], zeros, g0, hi, wi, co, co));          // g0 = d a_i
         TRY(vad_bn_act_pool_bwd(ws + p.ya[i], ws + p.st_ea[i], P + p.ea_g[i], P + p.ea_be[i], g0, 0, 0, 0, 0, g2, 0, G + p.ea_g[i], G + p.ea_be[i],
                                 ws + p.ksums, ws + p.chan_ws, N, hi, wi, co, VAD_ACT_LEAKY, 0, s));
         VAD_HIP_TRY(hipMemsetAsync(G + p.ea_b[i], 0, (size_t)co * sizeof(float), s));
@@ -257,7 +269,7 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
             TRY(vad_conv_c3_wgrad(x, g2, G + p.ea_w[0], ws + p.wgrad_ws, N, hi, wi, co, s));
         } else {
             TRY(vad_conv_wgrad(ws + p.p[i - 1], g2, G + p.ea_w[i], ws + p.wgrad_ws, N, hi, wi, ci, co, 9, 0, precision, s));
-            TRY(vad_conv3x3(g2, 0, ws + p.pk_ea_dg[i], zeros, g0, 0, N, hi, wi, co, ci, VAD_ACT_NONE, 0, precision, s));      // g0 = d p_{i-1}
+            TRY(conv3(g2, ws + p.pk_ea_dg[i], zeros, g0, hi, wi, co, ci));      // g0 = d p_{i-1}
         }
     }
     return VAD_OK;

@@ -33,8 +33,8 @@ PRECISIONS = {"fp32": PREC_FP32, "split": PREC_SPLIT, "bf16": PREC_BF16S, "bf16_
 def training_precision(name: str, trainer: str, tensors: bool) -> str:
     """The ONE place the trainers' `precision=` strings are resolved: returns 'fp32', 'split', 'bf16_operands' or
     'bf16_tensors' ('bf16' -> 'bf16_tensors').  `tensors`: does this trainer have the bf16-tensor form?"""
-    # "winograd" (VideoTrainer): fp32 everywhere, the 3x3 convolutions (forward + data gradients) as Winograd F(2x2,3x3)
-    ok = ("fp32", "split", "bf16_operands") + (("bf16", "bf16_tensors", "winograd") if tensors else ())
+    # "winograd" (both trainers): fp32 everywhere, the 3x3 convolutions (forward + data gradients) as Winograd F(2x2,3x3)
+    ok = ("fp32", "split", "bf16_operands", "winograd") + (("bf16", "bf16_tensors") if tensors else ())
     if name in ("bf16", "bf16_tensors") and not tensors:
         raise VadError(f"{trainer}: precision {name!r} means bf16 TENSORS (activations / gradients bf16 in HBM), which this "
                        f"trainer does not implement; its bf16 form is 'bf16_operands' (fp32 tensors, bf16 MFMA operands)")

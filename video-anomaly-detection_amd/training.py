@@ -258,7 +258,8 @@ class ImageTrainer(_FlatTrainer):
                  process_group=None, loss: str = "mse", ssim_weight: float = 0.5, window_size: int = 11, precision: str = "fp32"):
         from .autoencoder import ConvAutoencoder
         self._check_model(model, ConvAutoencoder, "ImageTrainer")
-        #: "fp32" | "split" | "bf16_operands" (fp32 tensors, bf16 MFMA operands in the convolutions and weight gradients).
+        #: "fp32" | "split" | "winograd" (fp32 everywhere, 3x3 forward / data-gradient convolutions as Winograd F(2x2,3x3)) |
+        #: "bf16_operands" (fp32 tensors, bf16 MFMA operands in the convolutions and weight gradients).
         #: "bf16" / "bf16_tensors" name the bf16-TENSOR mode of `VideoTrainer` and are rejected here by name: the image
         #: step has no such form (round 3 accepted "bf16" here with the operand meaning - the same string, other arithmetic)
         self.precision = hip.training_precision(precision, "ImageTrainer", tensors=False)
