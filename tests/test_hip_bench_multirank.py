@@ -91,3 +91,19 @@ def test_default_bench_line_carries_every_single_gpu_object():
     assert d["training_step"]["bf16_precision"]["value"] > 0 and d["split_precision"]["value"] > 0
     rc = d["reference_call_sizes"]
     assert set(rc) == {"image_batch_1", "image_batch_16", "video_4x16", "video_1x16"} and all(x["ms"] > 0 for x in rc.values())
+
+
+@pytest.mark.parametrize("workload,extra", [("image", ["--batch", "16", "--size", "64"]), ("video", ["--batch", "4", "--clip-len", "5", "--size", "64"])])
+def test_bench_line_with_an_opt_in_mode_as_the_timed_path_says_so(workload, extra):
+    """`bench.py --precision winograd`: the opt-in arithmetic as the timed path must be visible in the line itself - `dtype` names
+    it, no secondary-mode objects ride along, and the CPU baseline's parity figure is that of the mode (still inside 1e-5)."""
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--precision", "winograd",
+           "--workload", workload, "--no-train", "--no-small", *extra]
+    out = subprocess.run(cmd, cwd=REPO, env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert "Winograd" in d["dtype"] and d["value"] > 0 and d["vs_baseline"] is None
+    assert "split_precision" not in d and "winograd_precision" not in d
+    assert d["cpu_baseline"]["gpu_vs_cpu_max_rel_score_err"] < 1e-5
