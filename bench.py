@@ -238,6 +238,10 @@ def main():
         default_shape = hw == 256 and not args.batch and int(model.chunk) == (512 if args.workload == "image" else 64) and (args.workload != "video" or t == 10)
         layers, roofline = layers_and_roofline(hip, lib, args.workload, hw, per_gpu, args.steps, t if args.workload != "image" else 0,
                                                args.stride, default_shape, fps / world, flop_per_frame, bytes_per_frame)
+        if args.precision == "winograd" and args.workload != "dense":
+            # the timed path is the Winograd mode: its roofline counts EXECUTED matrix FLOPs (16/36 of the direct-convolution
+            # FLOPs), or `frac` would exceed 1
+            roofline = winograd_roofline(hip, lib, args.workload, hw, per_gpu, args.steps, t if args.workload != "image" else 0)["roofline"]
 
     out = {
         "metric": "frames/sec/GPU (256x256 autoencoder scoring) + AUROC parity vs reference",

@@ -105,5 +105,6 @@ def test_bench_line_with_an_opt_in_mode_as_the_timed_path_says_so(workload, extr
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert "Winograd" in d["dtype"] and d["value"] > 0 and d["vs_baseline"] is None
+    assert 0 < d["roofline"]["frac"] < 1 and "executed" in d["roofline"]["flops"]       # executed matrix FLOPs, not algorithmic ones
     assert "split_precision" not in d and "winograd_precision" not in d
     assert d["cpu_baseline"]["gpu_vs_cpu_max_rel_score_err"] < 1e-5
