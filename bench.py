@@ -651,7 +651,8 @@ def cpu_baseline(vad, state, kind, clip_len, gpu_scores, seed, hw):
     passes = 2
     with torch.no_grad():
         if kind == "image":
-            n, bs = 64, 16                                   # configs[0]: 64 frames, batches of 16 (evaluate.py:240)
+            n = min(64, int(gpu_scores.shape[0]))            # configs[0]: 64 frames, batches of 16 (evaluate.py:240); fewer when the step has fewer
+            bs = min(16, n)
             xs = torch.from_numpy(vad.synth.frames(seed, 0, n, 3, hw, hw))
             torch_oracle.img_scores(state, xs[:bs])          # warm-up
             t0 = time.perf_counter()
@@ -661,7 +662,7 @@ def cpu_baseline(vad, state, kind, clip_len, gpu_scores, seed, hw):
             got = gpu_scores[:n].cpu()
             frames, sample = n, f"{n} of the step's frames, batches of {bs}, 1 warm-up batch + {passes} timed passes (mean)"
         else:
-            nclips, t = 4, clip_len
+            nclips, t = min(4, int(gpu_scores.shape[0])), clip_len
             xs = torch.from_numpy(vad.synth.clips(seed, 0, nclips, t, 3, hw, hw))
             torch_oracle.vid_scores(state, xs[:1], 128, 2)
             t0 = time.perf_counter()
