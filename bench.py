@@ -535,11 +535,13 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
         vad.hip.check(lib.vad_prof_reset(), "vad_prof_reset")
         vad.hip.check(lib.vad_prof_enable(1), "vad_prof_enable")
         lib.vad_debug_set_lstm_wavefront(0)
-        t1 = time.perf_counter()
-        tr.forward_backward(x)
-        torch.cuda.synchronize(dev)
-        res["ms_per_step_serial_order"] = round((time.perf_counter() - t1) * 1e3, 3)
-        lib.vad_debug_set_lstm_wavefront(1)
+        try:
+            t1 = time.perf_counter()
+            tr.forward_backward(x)
+            torch.cuda.synchronize(dev)
+            res["ms_per_step_serial_order"] = round((time.perf_counter() - t1) * 1e3, 3)
+        finally:
+            lib.vad_debug_set_lstm_wavefront(1)
         groups = training_groups(vad, clips * t, hw, precision)
         vad.hip.check(lib.vad_prof_enable(0), "vad_prof_enable")
         vad.hip.check(lib.vad_prof_reset(), "vad_prof_reset")
