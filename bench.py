@@ -573,7 +573,7 @@ def training_step(vad, dev, hw, clips=32, t=10, steps=3, warmup=1):
                                                              "convolutions included) as Winograd F(2x2,3x3) on the exact-fp32 MFMA; weight gradients direct")
         else:
             out["bf16_precision"] = dict(res, arithmetic="BASELINE configs[4] dtype: activation and activation-gradient tensors bf16 in HBM, every convolution / "
-                                                         "weight-gradient GEMM behind the first layer on bf16 MFMA operands with fp32 accumulation; arithmetic inside "
+                                                         "weight-gradient GEMM behind the first layer and the first layer's forward on bf16 MFMA operands with fp32 accumulation; arithmetic inside "
                                                          "the kernels, BatchNorm statistics, cell states, master weights, parameter gradients, loss, Adam fp32")
         m.load_state_dict(state)
         del tr

@@ -317,6 +317,10 @@ int vad_conv1x1_p(const void* in, const float* w_packed, const float* bias, void
 /* First layer (x NCHW fp32 [N,3,H,W]) -> conv3x3(3->Cout) + bias, un-activated, into a bf16 NHWC tensor. */
 int vad_conv3x3_c3_bf16(const float* x_nchw, const float* w_packed, const float* bias, void* out_bf16, int n, int h, int w,
                         int cout, void* stream);
+/* ... with bf16 MFMA OPERANDS as well (input taps and weights rounded to bf16, nearest even; K = 27 -> 32 = two
+ * v_mfma_f32_32x32x16_bf16 per 32 pixels; fp32 accumulation from the bias): what the VAD_PREC_BF16S training step runs. */
+int vad_conv3x3_c3_bf16op(const float* x_nchw, const float* w_packed, const float* bias, void* out_bf16, int n, int h, int w,
+                          int cout, void* stream);
 
 /* ------------------------------------------------------------------ whole training step (row f-1)
  * Replaces the loop body of train_video.py:50-60 for VideoAutoencoder(in_channels=3, latent_dim, lstm_hidden_dim,

@@ -200,6 +200,20 @@ def test_first_and_last_layer_on_bf16_tensors(vad, n, h, w):
     vad.hip.check(l.vad_conv3x3_c3(x.data_ptr(), wp.data_ptr(), bo.data_ptr(), o32.data_ptr(), n, h, w, 32, 0, 0, H.stream()))
     vad.hip.check(l.vad_conv3x3_c3_bf16(x.data_ptr(), wp.data_ptr(), bo.data_ptr(), o16.data_ptr(), n, h, w, 32, H.stream()))
     assert torch.equal(o16, o32.to(torch.bfloat16))
+    # ... and with bf16 MFMA operands (the form the bf16-tensor step runs since round 4): on bf16-REPRESENTABLE frames and weights
+    # the products are exact in fp32, so the result is the exact-fp32 kernel's up to the summation order of 27 terms - held to
+    # one bf16 ulp with almost every element equal; on arbitrary frames it is the same kernel after rounding both operands
+    xr, wr = x.to(torch.bfloat16).float(), torch.from_numpy(w0).to(torch.bfloat16).float().numpy()
+    wpr, _ = H.pack_conv3x3(wr, np.zeros(32, np.float32))
+    o32r, o16op, o16op_any = _nan32(n, h, w, 32), _nan16(n, h, w, 32), _nan16(n, h, w, 32)
+    vad.hip.check(l.vad_conv3x3_c3(xr.data_ptr(), wpr.data_ptr(), bo.data_ptr(), o32r.data_ptr(), n, h, w, 32, 0, 0, H.stream()))
+    vad.hip.check(l.vad_conv3x3_c3_bf16op(xr.data_ptr(), wpr.data_ptr(), bo.data_ptr(), o16op.data_ptr(), n, h, w, 32, H.stream()))
+    vad.hip.check(l.vad_conv3x3_c3_bf16op(x.data_ptr(), wp.data_ptr(), bo.data_ptr(), o16op_any.data_ptr(), n, h, w, 32, H.stream()))
+    want = o32r.to(torch.bfloat16)
+    same = (o16op == want).float().mean().item()
+    ulp = (o16op.float() - want.float()).abs() / (want.float().abs() * 2.0 ** -7 + 1e-30)
+    assert same > 0.995 and float(ulp.max()) <= 1.0 + 1e-6, (same, float(ulp.max()))
+    assert torch.equal(o16op_any, o16op)                    # rounding the operands first changes nothing: the kernel does exactly that
     # first-layer weight gradient with a bf16 gradient tensor
     g16, g32 = _rep(rng.standard_normal((n, h, w, 32)))
     ws = _ws(l.vad_conv_c3_wgrad_ws_floats(n, h, 32))

@@ -754,9 +754,14 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(ConvC3P p) {
 // the current one is computed (3 planes x 34 x 18 values = 8 per thread).
 // OUT16 (un-pooled, un-activated = the training forward of VAD_PREC_BF16S): the output tensor is bf16 in memory (the
 // arithmetic and the statistics are unchanged).
-template <int POOL, int ACT, int OUT16 = 0>
+// BF16OP (with OUT16; the training forward of VAD_PREC_BF16S since round 4): bf16 MFMA OPERANDS as well - K = 27 padded to 32 is
+// two v_mfma_f32_32x32x16_bf16 per M-tile instead of fourteen exact-fp32 ones (a lane gathers its 2 x 8 taps from the fp32 tile in
+// LDS and rounds them to bf16, nearest even; the weights are rounded once per work-group), fp32 accumulation from the bias; the
+// epilogue and the statistics are the fp32 kernel's.  The layer then runs at the rate of its bf16 stores instead of the fp32 pipe.
+template <int POOL, int ACT, int OUT16 = 0, int BF16OP = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     static_assert(!OUT16 || (!POOL && ACT == VAD_ACT_NONE), "bf16 output: training forward only");
+    static_assert(!BF16OP || OUT16, "bf16 operands: the bf16-tensor training forward");
     constexpr unsigned OS = OUT16 ? 2u : 4u;
     constexpr int MTW = 4, TH = 2 * MTW * 4, LH = TH + 2, RS = 20, NE = 3 * LH * 18, NST = (NE + 255) / 256;
     __shared__ float tile[3 * LH * RS + 1];              // + one dummy slot: staging slots past the tile write there
@@ -764,13 +769,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int prow = (li >> 1) & 1, pcol = 2 * (li >> 2) + (li & 1);
-    int koff[14];
+    int koff[BF16OP ? 16 : 14];
+    if constexpr (BF16OP) {        // MFMA s of an M-tile multiplies k = 16 s + 8 lh + j, j = 0..7 (k >= 27: weight 0, any finite tile value)
 #pragma unroll
-    for (int s = 0; s < 14; ++s) {
-        const int k0 = 2 * s, k1 = 2 * s + 1;
-        const int o0 = ((k0 / 9) * LH + (k0 % 9) / 3) * RS + (k0 % 3);
-        const int o1 = (k1 < 27) ? ((k1 / 9) * LH + (k1 % 9) / 3) * RS + (k1 % 3) : 0;
-        koff[s] = lh ? o1 : o0;
+        for (int i = 0; i < 16; ++i) {
+            const int k0 = 16 * (i >> 3) + (i & 7), k1 = k0 + 8;
+            const int o0 = ((k0 / 9) * LH + (k0 % 9) / 3) * RS + (k0 % 3);
+            const int o1 = (k1 < 27) ? ((k1 / 9) * LH + (k1 % 9) / 3) * RS + (k1 % 3) : 0;
+            koff[i] = lh ? o1 : (k0 < 27 ? o0 : 0);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int o0 = ((k0 / 9) * LH + (k0 % 9) / 3) * RS + (k0 % 3);
+            const int o1 = (k1 < 27) ? ((k1 / 9) * LH + (k1 % 9) / 3) * RS + (k1 % 3) : 0;
+            koff[s] = lh ? o1 : o0;
+        }
     }
     const int ctiles = p.cout / 32;            // output-channel tiles, one after the other (one for every reference layer)
     float pre[NST];
@@ -835,7 +850,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
     };
     // B fragments + bias: ONE register set, (re)loaded only when the channel tile changes - once per work-group for every
     // reference layer.  (Without restrict the compiler cannot hoist loads out of the tile loop past the stores.)
-    float b[14], bv = 0.f;
+    float b[BF16OP ? 1 : 14], bv = 0.f;
+    f16x8 bq[BF16OP ? 2 : 1];   // bf16 operands: the lane's 2 x 8 weights (bit patterns), k = 16 s + 8 lh + j
     f32x16 bias16;              // bv in every register: the C operand of a tile's first k-step
     int have = -1;
     // BatchNorm statistics of the training forward, taken from the accumulators instead of a second pass over the 8.4 MB per
@@ -875,8 +891,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
             const int co = nt * 32 + li;
             const unsigned lanepart = (unsigned)((POOL ? lh : 2 * lh) * p.cout + co) * OS;
             if (have != nt) {
+                if constexpr (BF16OP) {
 #pragma unroll
-                for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        unsigned pk[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int k0 = 16 * s2 + 8 * lh + 2 * j, k1 = k0 + 1;       // (rows 27..31 of the operand are zero)
+                            const float w0 = k0 < 27 ? p.w[(size_t)k0 * p.cout + co] : 0.f, w1 = k1 < 27 ? p.w[(size_t)k1 * p.cout + co] : 0.f;
+                            pk[j] = vad_pack_bf16(w0, w1);
+                        }
+                        bq[s2] = __builtin_bit_cast(f16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 14; ++s) b[s] = p.w[(size_t)(s * 2 + lh) * p.cout + co];
+                }
                 bv = p.bias[co];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bias16[r] = bv;
@@ -884,8 +914,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                 // retire these loads HERE, inside the branch: left pending, hipcc guards the first MFMA below with a
                 // vmcnt(0) that runs on every tile - and, vmcnt being in order, drains the next tile's prefetch issued just
                 // above, tile after tile
+                if constexpr (BF16OP) { asm volatile("" ::"v"(bq[0])); asm volatile("" ::"v"(bq[1])); }
+                else {
 #pragma unroll
-                for (int s = 0; s < 14; ++s) asm volatile("" ::"v"(b[s]));
+                    for (int s = 0; s < 14; ++s) asm volatile("" ::"v"(b[s]));
+                }
                 asm volatile("" ::"v"(bv));
             }
             // (the accumulators are never initialised: the FIRST k-step takes the bias splat `bias16` as its C operand - the same
@@ -894,6 +927,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
             // A operands through a two-deep register pipeline (4 LDS values per k-step), fenced per step: left alone the
             // compiler hoists all 56 reads of a tile into registers and spills
             const int abase = (2 * wave * MTW + prow) * RS + pcol;
+            if constexpr (BF16OP) {
+                // per M-tile: 16 taps from LDS, rounded to bf16 in pairs, two MFMAs; the next M-tile's reads are issued first
+                float g[2][16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) g[0][i] = tile[abase + koff[i]];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    if (mt + 1 < MTW) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) g[(mt + 1) & 1][i] = tile[abase + 2 * (mt + 1) * RS + koff[i]];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float* gm = g[mt & 1];
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, u32x4{vad_pack_bf16(gm[0], gm[1]), vad_pack_bf16(gm[2], gm[3]), vad_pack_bf16(gm[4], gm[5]), vad_pack_bf16(gm[6], gm[7])});
+                    const f16x8 a1 = __builtin_bit_cast(f16x8, u32x4{vad_pack_bf16(gm[8], gm[9]), vad_pack_bf16(gm[10], gm[11]), vad_pack_bf16(gm[12], gm[13]), vad_pack_bf16(gm[14], gm[15])});
+                    acc[mt] = MFMAB16(a0, bq[0], bias16);
+                    acc[mt] = MFMAB16(a1, bq[1], acc[mt]);
+                }
+            } else {
             float av[2][MTW];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) av[0][mt] = tile[abase + 2 * mt * RS + koff[0]];
@@ -906,6 +958,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c3_pkernel(ConvC3P p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) acc[mt] = MFMA32(av[s & 1][mt], b[s], s == 0 ? bias16 : acc[mt]);
+            }
             }
             float ts = 0.f, tq = 0.f;        // this tile's share of the statistics
             // The epilogue in TWO copies behind ONE scalar branch: `full` is wave-uniform, but written as `if (!full) vo = ...` per
@@ -1000,6 +1053,10 @@ int vad_conv3x3_c3_stats(const void* x, int fmt, const float* w, const float* bi
 extern "C" int vad_conv3x3_c3_bf16(const float* x, const float* w, const float* bias, void* out, int n, int h, int wd, int cout, void* stream) {
     return vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, w, bias, out, 1, n, h, wd, cout, VAD_ACT_NONE, 0, nullptr, nullptr, stream);
 }
+// ... with bf16 MFMA operands as well (the form the bf16-tensor training step runs)
+extern "C" int vad_conv3x3_c3_bf16op(const float* x, const float* w, const float* bias, void* out, int n, int h, int wd, int cout, void* stream) {
+    return vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, w, bias, out, 2, n, h, wd, cout, VAD_ACT_NONE, 0, nullptr, nullptr, stream);
+}
 
 // out16 != 0: `out` is a bf16 tensor (VAD_PREC_BF16S; persistent un-pooled un-activated launches only)
 int vad_conv3x3_c3_stats_t(const void* x, int fmt, const float* w, const float* bias, void* outv, int out16,
@@ -1042,6 +1099,14 @@ int vad_conv3x3_c3_stats_t(const void* x, int fmt, const float* w, const float* 
         } else {
             if (act == VAD_ACT_LEAKY) C3P_LAUNCH(0, VAD_ACT_LEAKY)
             else if (act == VAD_ACT_RELU) C3P_LAUNCH(0, VAD_ACT_RELU)
+            else if (out16 == 2) {       // bf16 output AND bf16 MFMA operands (float input only)
+                VAD_REQUIRE(fmt == VAD_X_F32_NCHW, "conv3x3_c3: the bf16-operand form takes float frames");
+                static std::atomic<unsigned> cap_{0};
+                unsigned cap = cap_.load(std::memory_order_relaxed);
+                if (!cap) cap_ = cap = persistent_grid(conv3x3_c3_pkernel<0, VAD_ACT_NONE, 1, 1>, ~0u);
+                hipLaunchKernelGGL((conv3x3_c3_pkernel<0, VAD_ACT_NONE, 1, 1>), dim3(p.nblocks < cap ? p.nblocks : cap), dim3(256), 0, s, p);
+                if (with_stats) *stats_blocks = (int)(p.nblocks < cap ? p.nblocks : cap);
+            }
             else if (out16) {
                 static std::atomic<unsigned> cap_{0};
                 unsigned cap = cap_.load(std::memory_order_relaxed);

@@ -284,8 +284,8 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     // convolutions (forward and data gradients) take split-fp16 operands (22-bit products, fp32 accumulate), everything
     // else - first layer, weight gradients, 1x1 data gradients, BatchNorm, gates, loss, Adam - stays fp32; 2 = bf16 operands
     // in the same places plus the weight gradients; 3 (VAD_PREC_BF16S) = 2 with every activation / activation-gradient
-    // tensor of the workspace stored as bf16 (the buffers keep their fp32-sized slots and use the first half) and the 1x1
-    // data gradients on bf16 operands too.
+    // tensor of the workspace stored as bf16 (the buffers keep their fp32-sized slots and use the first half), the 1x1
+    // data gradients and the first layer's forward on bf16 operands too.
     Plan p;
     VAD_REQUIRE(make_plan(p, b, t, h, w, latent, hid, layers),
                 "vid_train_fwd_bwd: unsupported configuration (B=%d T=%d %dx%d latent=%d hid=%d layers=%d): H, W multiples of 16, "
@@ -330,7 +330,8 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         float* y = A(p.y[k]);
         int sblocks = 0;      // > 0: the convolution wrote the BatchNorm partial sums itself (first layer: no second pass over y)
-        if (k == 0) { PS(TS_C3_FWD); TRY(vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, io, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s)); }
+        // (bf16 tensors: the first layer on bf16 MFMA operands too - out16 = 2 - so that it runs at the rate of its stores)
+        if (k == 0) { PS(TS_C3_FWD); TRY(vad_conv3x3_c3_stats_t(x, VAD_X_F32_NCHW, ws + p.pk_e[0], P + p.e_b[0], y, io ? 2 : 0, N, hk, wk, co, VAD_ACT_NONE, 0, ws + p.chan_ws, &sblocks, s)); }
         else { PS(TS_CONV_FWD); TRY(conv3(A(p.a[k - 1]), ws + p.pk_e[k], P + p.e_b[k], y, N, hk, wk, ci, co, ws + p.chan_ws, &sblocks, s)); }
         float* rs = running ? running + p.e_rs[k] : nullptr;
         if (sblocks > 0) { PS(TS_STATS_MISC); TRY(vad_bn_stats_from_partials(ws + p.chan_ws, sblocks, (long long)N * hk * wk, co, eps, mom, ws + p.st_e[k], rs, rs ? rs + co : nullptr, P + p.e_b[k], s)); }
