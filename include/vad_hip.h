@@ -279,11 +279,11 @@ int vad_train_pack_conv3x3_c3(const float* w_oihw, int cout, float* fwd, void* s
  * the data gradient is a 3->cin first-layer convolution of the pre-activation gradient. */
 int vad_train_pack_conv3x3_to3(const float* w_oihw, int cin, float* fwd, float* dgrad_c3, void* stream);
 /* Backward of Conv2d(32->3,k3,p1)+Tanh: recon = tanh(conv(in)) [n,3,h,w]; the upstream gradient is either drecon [n,3,h,w]
- * or (drecon NULL) that of nn.MSELoss against x.  Outputs: dpre scratch [n,3,h,w], din [n,h,w,32], dw (3,32,3,3), db3 [3]. */
+ * or (drecon NULL) that of nn.MSELoss against x, times grad_mul (a power of two; 1 = none, see vad_convt_to3_mse_t).  Outputs: dpre scratch [n,3,h,w], din [n,h,w,32], dw (3,32,3,3), db3 [3]. */
 size_t vad_conv3x3_to3_bwd_ws_floats(int n, int h, int w, int cin);
 int vad_conv3x3_to3_tanh_bwd(const float* in_nhwc, const float* recon, const float* x, const float* drecon,
                              const float* w_dgrad_c3, float* dpre, float* din, float* dw, float* db3, float* ws,
-                             int n, int h, int w, int cin, void* stream);
+                             int n, int h, int w, int cin, float grad_mul, void* stream);
 /* Conv2d k1 (cout, cin, 1, 1): fwd = vad_pack_conv1x1 layout; dgrad = the transposed 1x1 weight (K = cout, N = cin). */
 int vad_train_pack_conv1x1(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, void* stream);
 
@@ -307,8 +307,14 @@ int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const
                          float* dc_prev, int nb, int hw, int hid, void* stream);
 int vad_conv_c3_wgrad_t(const float* x_nchw, const void* g, int io16, float* dw, float* ws, int n, int h, int w, int cout,
                         void* stream);
+/* grad_mul (a power of two, 1 = none) multiplies every gradient this call emits (din, dpre32, dbias3), not the loss: the
+ * split-fp16 training step runs its whole backward on gradients scaled into the fp16 range and unscales the parameter
+ * gradients at the end (vad_scale_floats) - exact in fp32 either way. */
 int vad_convt_to3_mse_t(const void* in_nhwc, int io16, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
-                        void* din, void* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w, void* stream);
+                        void* din, void* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w, float grad_mul,
+                        void* stream);
+/* p[i] *= mul, i < n. */
+int vad_scale_floats(float* p, long long n, float mul, void* stream);
 /* Conv2d k1 with `precision`: VAD_PREC_BF16S = bf16 tensors and bf16 operands (weights from vad_train_pack_conv1x1_p with the
  * same precision), anything else = vad_conv1x1 / vad_train_pack_conv1x1. */
 int vad_train_pack_conv1x1_p(const float* w_oihw, int cout, int cin, float* fwd, float* dgrad, int precision, void* stream);
@@ -354,6 +360,10 @@ int vad_debug_set_wgrad_pairs(int on);
 /* 1 (default): the BatchNorm forward / backward-apply passes on bf16 tensors take eight channels per thread (16-byte accesses);
  * 0: four, like the fp32 form.  Identical results (every element goes through the same expressions). */
 int vad_debug_set_bn_wide(int on);
+/* debug / A-B: 0 = the split-fp16 training steps run their backward on unscaled gradients (round 3's form: operands below the
+ * fp16 range at large batches); default 1 = scaled by a power of two and unscaled at the end (csrc/train_step.hip). */
+int vad_debug_set_split_grad_scale(int on);
+int vad_split_grad_scale_enabled(void);
 int vad_debug_set_train_stop(int stage);   /* debug: stop vad_vid_train_fwd_bwd after a backward stage (see csrc/train_step.hip) */
 int vad_vid_train_debug_layout(int b, int t, int h, int w, int latent, int hid, int layers, long long* out, int cap);
 int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w, int latent, int hid, int layers,

@@ -233,7 +233,7 @@ def test_first_and_last_layer_on_bf16_tensors(vad, n, h, w):
         din = torch.full((n, h2, w2, 32), float("nan"), dtype=dt, device="cuda")
         dpre = torch.full((n * h2 * w2, 32), float("nan"), dtype=dt, device="cuda")
         vad.hip.check(l.vad_convt_to3_mse_t(r.data_ptr(), io, wt.data_ptr(), bt.data_ptr(), x.data_ptr(), rec.data_ptr(), din.data_ptr(),
-                                            dpre.data_ptr(), loss.data_ptr(), db.data_ptr(), tws.data_ptr(), n, h2, w2, H.stream()))
+                                            dpre.data_ptr(), loss.data_ptr(), db.data_ptr(), tws.data_ptr(), n, h2, w2, 1.0, H.stream()))
         outs[io] = (rec, loss, din, dpre, db)
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
     assert torch.equal(outs[1][2], outs[0][2].to(torch.bfloat16)) and torch.equal(outs[1][3], outs[0][3].to(torch.bfloat16))

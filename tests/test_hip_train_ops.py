@@ -373,7 +373,16 @@ def test_image_last_layer_conv_tanh_backward(vad, n, h, w, given_drecon):
     Rd = H.dev(R)
     vad.hip.check(l.vad_conv3x3_to3_tanh_bwd(ad.data_ptr(), recon.data_ptr(), None if given_drecon else xd.data_ptr(),
                                              Rd.data_ptr() if given_drecon else None, dgr.data_ptr(), dpre.data_ptr(), din.data_ptr(),
-                                             dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, h, w, 32, H.stream()))
+                                             dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, h, w, 32, 1.0, H.stream()))
+    # grad_mul (the split-fp16 step's gradient scale) is an exact power-of-two rescaling of every output
+    din2, dw2, db2, dpre2 = torch.empty_like(din), torch.empty_like(dw), torch.empty_like(db), torch.empty_like(dpre)
+    vad.hip.check(l.vad_conv3x3_to3_tanh_bwd(ad.data_ptr(), recon.data_ptr(), None if given_drecon else xd.data_ptr(),
+                                             Rd.data_ptr() if given_drecon else None, dgr.data_ptr(), dpre2.data_ptr(), din2.data_ptr(),
+                                             dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), n, h, w, 32, 4096.0, H.stream()))
+    assert torch.equal(din2, din * 4096.0) and torch.equal(dw2, dw * 4096.0) and torch.equal(db2, db * 4096.0)
+    assert l.vad_conv3x3_to3_tanh_bwd(ad.data_ptr(), recon.data_ptr(), None if given_drecon else xd.data_ptr(),
+                                      Rd.data_ptr() if given_drecon else None, dgr.data_ptr(), dpre2.data_ptr(), din2.data_ptr(),
+                                      dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), n, h, w, 32, 3.0, H.stream()) != 0     # not a power of two
     _close(H.to_nchw(din), at.grad.numpy(), 1e-4, "d input")
     _close(dw.cpu().numpy(), wtt.grad.numpy(), 1e-4, "dW")
     _close(db.cpu().numpy(), bt.grad.numpy(), 1e-4, "d bias")

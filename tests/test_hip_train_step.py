@@ -310,17 +310,9 @@ def _conditioned_float64(vad, latent, layers, wseed, x, decisions):
     return float(loss.detach()), {k: p.grad.detach().numpy() for k, p in m.named_parameters()}, report
 
 
-@pytest.mark.parametrize("latent,layers,b,t,hw,wseed", [(32, 3, 1, 4, 48, 43), (32, 3, 1, 4, 80, 43), (32, 3, 1, 4, 112, 43),
-                                                        (32, 3, 1, 4, 64, 43), (64, 2, 2, 3, 32, 41), (64, 1, 2, 2, 96, 44),
-                                                        (32, 2, 2, 2, (48, 80), 45), (64, 2, 1, 3, (64, 32), 46),
-                                                        ((32, 64), 2, 2, 3, 32, 48), ((64, 32), 1, 1, 3, 48, 49),
-                                                        (32, 1, 1, 1, 16, 50), (32, 2, 1, 2, (16, 32), 51), (64, 2, 3, 1, 32, 52)])
-@pytest.mark.parametrize("precision", ["fp32", "split", "winograd"])
-def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, layers, b, t, hw, wseed, precision):
-    """precision "split": the 3x3 / transposed convolutions (forward and data gradients) on split-fp16 operands (22-bit
-    products); same bounds - the mode is meant to be indistinguishable from fp32 at this level.  "winograd": the same
-    convolutions as Winograd F(2x2,3x3) in fp32 (odd map sizes included: frames of 48 / 80 / 112 give 3 / 5 / 7-pixel ConvLSTM
-    maps, whose last 2x2 tiles are partial)."""
+def _float64_deviation(vad, latent, layers, b, t, hw, wseed, precision):
+    """One native step against the float64 evaluation conditioned on the step's own decisions: asserts (1) and the loss of (2)
+    below, returns the worst per-tensor gradient deviation (of the tensor's largest entry) and the decision report."""
     h, w = hw if isinstance(hw, tuple) else (hw, hw)          # non-square cases: H and W are carried separately everywhere
     x = torch.from_numpy(vad.synth.clips(wseed + 100, 0, b, t, 3, h, w))
     m = _make(vad, latent, layers)
@@ -338,19 +330,49 @@ def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, la
     # (2) with the decisions fixed, loss and every gradient agree to rounding
     assert abs(loss_gpu - loss64) < 2e-6 * loss64
     zero_true = _bn_fed_biases(m)
-    # fp32: 1e-4 (measured 3e-6 .. 6e-6).  split: products carry 22 bits instead of 24 and the most upstream, heavily
-    # cancelling sums (the first BatchNorm's shift gradient, tensor scale ~1e-4) show it: measured up to 1.7e-4 -> 5e-4.
-    bound = 1e-4 if precision == "fp32" else 5e-4
     worst = 0.0
     for k, r in want.items():
         if k in zero_true:
             continue
-        scale = max(float(np.abs(r).max()), 1e-12)
-        err = float(np.abs(got[k] - r).max()) / scale
-        worst = max(worst, err)
-        assert err < bound, f"grad {k}: {err:.3e} of max |g| {scale:.3e} from the decision-conditioned float64 gradient " \
-                           f"(decisions differing from float64: {[(s, n_) for s, n_, _, _ in report if n_]})"
-    print(f"[{precision},{latent},{layers},{b}x{t},{hw}] worst gradient deviation {worst:.2e}; differing decisions {[(s, n_, f'{mg:.1e}') for s, n_, mg, _ in report if n_]}")
+        worst = max(worst, float(np.abs(got[k] - r).max()) / max(float(np.abs(r).max()), 1e-12))
+    return worst, report
+
+
+@pytest.mark.parametrize("latent,layers,b,t,hw,wseed", [(32, 3, 1, 4, 48, 43), (32, 3, 1, 4, 80, 43), (32, 3, 1, 4, 112, 43),
+                                                        (32, 3, 1, 4, 64, 43), (64, 2, 2, 3, 32, 41), (64, 1, 2, 2, 96, 44),
+                                                        (32, 2, 2, 2, (48, 80), 45), (64, 2, 1, 3, (64, 32), 46),
+                                                        ((32, 64), 2, 2, 3, 32, 48), ((64, 32), 1, 1, 3, 48, 49),
+                                                        (32, 1, 1, 1, 16, 50), (32, 2, 1, 2, (16, 32), 51), (64, 2, 3, 1, 32, 52)])
+@pytest.mark.parametrize("precision", ["fp32", "split", "winograd"])
+def test_train_step_gradients_match_decision_conditioned_float64(vad, latent, layers, b, t, hw, wseed, precision):
+    """precision "split": the 3x3 / transposed convolutions (forward and data gradients) on split-fp16 operands (22-bit
+    products); same bounds - the mode is meant to be indistinguishable from fp32 at this level.  "winograd": the same
+    convolutions as Winograd F(2x2,3x3) in fp32 (odd map sizes included: frames of 48 / 80 / 112 give 3 / 5 / 7-pixel ConvLSTM
+    maps, whose last 2x2 tiles are partial)."""
+    worst, report = _float64_deviation(vad, latent, layers, b, t, hw, wseed, precision)
+    # fp32: 1e-4 (measured 3e-6 .. 6e-6).  split: the same bound since the backward runs on gradients scaled into the fp16
+    # range (round 4; measured 2e-6 .. 6e-6 - round 3's unscaled form reached 1.7e-4 on these cases and needed 5e-4).
+    assert worst < 1e-4, f"worst gradient deviation {worst:.3e} from the decision-conditioned float64 gradient " \
+                         f"(decisions differing from float64: {[(s_, n_) for s_, n_, _, _ in report if n_]})"
+    print(f"[{precision},{latent},{layers},{b}x{t},{hw}] worst gradient deviation {worst:.2e}; differing decisions {[(s_, n_, f'{mg:.1e}') for s_, n_, mg, _ in report if n_]}")
+
+
+def test_split_mode_gradients_hold_at_small_gradient_magnitudes(vad):
+    """The criterion's gradient is 2 (recon - x) / count: 3e-6 at this size (4 x 6 x 96x96), ~1e-8 at BASELINE configs[4] - below the
+    fp16 range, where the (hi, lo) split of a gradient operand keeps 8-10 bits (tools/split_range.py).  The split step therefore
+    runs its backward on gradients times a power of two and scales the parameter gradients back (csrc/train_step.hip): with
+    that, the decision-conditioned float64 gradients hold at the exact mode's bound; round 3's unscaled form (behind
+    vad_debug_set_split_grad_scale(0)) is measured beside it and is the worse one by more than an order of magnitude."""
+    l = vad.hip.lib()
+    case = (64, 2, 4, 6, 96, 71)
+    scaled, _ = _float64_deviation(vad, *case, "split")
+    l.vad_debug_set_split_grad_scale(0)
+    try:
+        unscaled, _ = _float64_deviation(vad, *case, "split")
+    finally:
+        l.vad_debug_set_split_grad_scale(1)
+    print(f"split-fp16 gradients vs decision-conditioned float64 at 2/count = {2.0 / (4 * 6 * 3 * 96 * 96):.1e}: scaled {scaled:.2e}, unscaled {unscaled:.2e}")
+    assert scaled < 1e-4 and unscaled > 10.0 * scaled, (scaled, unscaled)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "split", "winograd", "bf16", "bf16_operands"])

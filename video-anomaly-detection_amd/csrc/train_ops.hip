@@ -1312,6 +1312,11 @@ __device__ __forceinline__ void put_split(float* dst, size_t group16, int k, flo
     o[8 + (k & 7)] = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
+__global__ __launch_bounds__(256) void scale_kernel(float* p, long long n, float mul) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] *= mul;
+}
+
 __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* w, int cout, int cin, float* fwd, float* dgrad, int split) {
     const long long total = (long long)cout * cin * 9;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -1425,14 +1430,14 @@ __global__ __launch_bounds__(256) void pack_conv3x3_to3_train_kernel(const float
 // dpre[n][c][y][x] = g * (1 - recon^2), g = drecon (given) or gscale * (recon - x); per-block partial sums of dpre for the
 // bias gradient: parts[(n*3 + c) * chunks + chunk]
 __global__ __launch_bounds__(256) void tanh_bwd_planes_kernel(const float* recon, const float* x, const float* drecon, float gscale,
-                                                              float* dpre, float* parts, long long plane, int chunks) {
+                                                              float gmul, float* dpre, float* parts, long long plane, int chunks) {
     __shared__ float red[4];
     const long long pl = blockIdx.y, base = pl * plane;
     const long long per = (plane + chunks - 1) / chunks, i0 = (long long)blockIdx.x * per, i1 = (i0 + per < plane) ? i0 + per : plane;
     float s = 0.f;
     for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
         const float r = recon[base + i];
-        const float g = drecon ? drecon[base + i] : gscale * (r - x[base + i]);
+        const float g = drecon ? drecon[base + i] * gmul : gscale * (r - x[base + i]);
         const float d = g * (1.f - r * r);
         dpre[base + i] = d;
         s += d;
@@ -1870,18 +1875,19 @@ extern "C" size_t vad_convt_to3_mse_ws_floats(int n, int h, int w) {
 extern "C" int vad_convt_to3_mse(const float* in_nhwc, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
                                  float* din, float* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w,
                                  void* stream) {
-    return vad_convt_to3_mse_t(in_nhwc, 0, w_iohw, bias3, x_nchw, recon, din, dpre32, loss, dbias3, ws, n, h, w, stream);
+    return vad_convt_to3_mse_t(in_nhwc, 0, w_iohw, bias3, x_nchw, recon, din, dpre32, loss, dbias3, ws, n, h, w, 1.f, stream);
 }
 
 int vad_convt_to3_mse_t(const void* in_nhwc, int io16, const float* w_iohw, const float* bias3, const float* x_nchw, float* recon,
-                        void* din, void* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w, void* stream) {
+                        void* din, void* dpre32, float* loss, float* dbias3, float* ws, int n, int h, int w, float grad_mul, void* stream) {
     VAD_REQUIRE(in_nhwc && w_iohw && bias3 && x_nchw && loss && ws && n > 0 && h > 0 && w > 0, "convt_to3_mse: bad arguments");
+    VAD_REQUIRE(vad_is_pow2f(grad_mul), "convt_to3_mse: grad_mul=%g must be a power of two (an exact rescaling of every gradient)", (double)grad_mul);
     VAD_REQUIRE(!dbias3 || dpre32, "convt_to3_mse: the bias gradient needs the dpre buffer");
     const long long total = (long long)n * h * w;
     const long long nb = (total + 255) / 256;
     VAD_REQUIRE(nb < (1ll << 31), "convt_to3_mse: grid too large");
     const double count = (double)n * 3.0 * (2.0 * h) * (2.0 * w);
-    To3P p{in_nhwc, w_iohw, bias3, x_nchw, recon, din, dpre32, ws, n, h, w, (float)(2.0 / count), total};
+    To3P p{in_nhwc, w_iohw, bias3, x_nchw, recon, din, dpre32, ws, n, h, w, (float)(2.0 / count) * grad_mul, total};
     hipStream_t s = (hipStream_t)stream;
     if (io16) hipLaunchKernelGGL(convt_to3_mse_kernel<vad_bf16>, dim3((unsigned)nb), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(convt_to3_mse_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, p);
@@ -1910,6 +1916,13 @@ extern "C" int vad_adam_step(float* p, const float* g, float* m, float* v, long 
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+extern "C" int vad_scale_floats(float* p, long long n, float mul, void* stream) {
+    VAD_REQUIRE(p && n > 0, "scale_floats: bad arguments");
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, mul);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -1979,8 +1992,9 @@ extern "C" size_t vad_conv3x3_to3_bwd_ws_floats(int n, int h, int w, int cin) {
 
 extern "C" int vad_conv3x3_to3_tanh_bwd(const float* in_nhwc, const float* recon, const float* x, const float* drecon,
                                         const float* w_dgrad_c3, float* dpre, float* din, float* dw, float* db3, float* ws,
-                                        int n, int h, int w, int cin, void* stream) {
+                                        int n, int h, int w, int cin, float grad_mul, void* stream) {
     VAD_REQUIRE(in_nhwc && recon && (x || drecon) && w_dgrad_c3 && dpre && din && dw && db3 && ws, "conv3x3_to3_tanh_bwd: null pointer");
+    VAD_REQUIRE(vad_is_pow2f(grad_mul), "conv3x3_to3_tanh_bwd: grad_mul=%g must be a power of two", (double)grad_mul);
     VAD_REQUIRE(n > 0 && h > 0 && w > 0 && cin == 32, "conv3x3_to3_tanh_bwd: bad shape (the reference's last conv has 32 input channels)");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = to3_chunks(h, w);
@@ -1990,7 +2004,7 @@ extern "C" int vad_conv3x3_to3_tanh_bwd(const float* in_nhwc, const float* recon
     float* wws = tmp + (size_t)cin * 27;
     VAD_HIP_TRY(hipMemsetAsync(zero_bias, 0, 64 * sizeof(float), s));
     const double count = (double)n * 3.0 * h * w;
-    hipLaunchKernelGGL(tanh_bwd_planes_kernel, dim3(chunks, n * 3), dim3(256), 0, s, recon, x, drecon, (float)(2.0 / count), dpre, parts,
+    hipLaunchKernelGGL(tanh_bwd_planes_kernel, dim3(chunks, n * 3), dim3(256), 0, s, recon, x, drecon, (float)(2.0 / count) * grad_mul, grad_mul, dpre, parts,
                        (long long)h * w, chunks);
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(bias3_finalize_kernel, dim3(3), dim3(64), 0, s, (const float*)parts, n, chunks, db3);

@@ -211,6 +211,11 @@ extern "C" int vad_lstm_wavefront_mode(void);   // vad_api.hip: vad_debug_set_ls
 static int g_vad_train_stop = -1;
 extern "C" int vad_debug_set_train_stop(int stage) { g_vad_train_stop = stage; return VAD_OK; }
 
+// A/B switch for the split-fp16 step's gradient scaling (tests/test_hip_train_step.py shows what it buys); default on.
+static int g_vad_split_grad_scale = 1;
+extern "C" int vad_debug_set_split_grad_scale(int on) { g_vad_split_grad_scale = on != 0; return VAD_OK; }
+extern "C" int vad_split_grad_scale_enabled(void) { return g_vad_split_grad_scale; }
+
 // per-group timing (vad_prof_*, model 2 of vad_prof_slot_name): every launch of the step belongs to one of these groups
 enum { TS_C3_FWD = 0, TS_CONV_FWD, TS_BN_FWD, TS_LSTM_CONV_FWD, TS_LSTM_GATES_FWD, TS_CONVT_FWD, TS_LOSS, TS_WGRAD, TS_BN_BWD,
        TS_CONVT_DGRAD, TS_LSTM_GATES_BWD, TS_LSTM_CONV_DGRAD, TS_CONV_DGRAD, TS_C3_WGRAD, TS_PACK, TS_STATS_MISC };
@@ -415,8 +420,19 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     }
     // last layer + loss, forward and backward (models/video_autoencoder.py:259-260, train_video.py:55)
     float *g0 = A(p.g[0]), *g2 = A(p.g[2]);
+    // Split-fp16 mode: the criterion's gradient is 2 (recon - x) / count - ~1e-8 at 32 x 10 x 256x256 -, below the fp16 range the
+    // data-gradient and weight-gradient kernels split their operands into (hi = 0, lo subnormal: 8-10 bits left, measured
+    // with tools/split_range.py).  The backward is linear in that gradient, so it runs on gradients times a power of two that
+    // puts 2 / count at 2^-6 .. 2^-5 (exact in fp32; 2^20 of headroom to the fp16 maximum) and the parameter gradients are
+    // scaled back at the end.  The other modes have the fp32 exponent range in every operand: no scaling.
+    float grad_mul = 1.f;
+    if (precision == VAD_PREC_SPLIT && !wino && g_vad_train_stop < 0 && g_vad_split_grad_scale) {
+        int e = 0;
+        (void)frexp((double)N * 3.0 * H * W, &e);            // count = m 2^e, m in [0.5, 1)
+        grad_mul = (float)ldexp(1.0, e - 7);                  // 2 / count * 2^(e-7) = 2^-6 / m
+    }
     { PS(TS_LOSS);
-    TRY(vad_convt_to3_mse_t(A(p.r[2]), io, P + p.t_w, P + p.t_b, x, recon, g0, A(p.dpre), loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, s)); }
+    TRY(vad_convt_to3_mse_t(A(p.r[2]), io, P + p.t_w, P + p.t_b, x, recon, g0, A(p.dpre), loss, G + p.t_b, ws + p.to3_ws, N, H / 2, W / 2, grad_mul, s)); }
 
     if (g_vad_train_stop == 20) return VAD_OK;      // debug: g0 = gradient of the last decoder activation, dpre intact
 
@@ -545,5 +561,6 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         VAD_HIP_TRY(hipEventRecord(TS->wg_in, wgs));
         VAD_HIP_TRY(hipStreamWaitEvent(s, TS->wg_in, 0));
     }
+    if (grad_mul != 1.f) TRY(vad_scale_floats(G, (long long)vad_vid_train_nparams(latent, hid, layers), 1.f / grad_mul, s));
     return VAD_OK;
 }

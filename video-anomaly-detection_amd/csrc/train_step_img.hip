@@ -236,8 +236,16 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
     }
 
     // ================================================================================== backward
+    // split-fp16 mode: the backward runs on gradients times a power of two (train_step.hip says why), unscaled at the end;
+    // the SSIM / combined criteria's gradient is O(1 / count) like the MSE's
+    float grad_mul = 1.f;
+    if (precision == VAD_PREC_SPLIT && !wino && vad_split_grad_scale_enabled()) {
+        int e = 0;
+        (void)frexp((double)N * 3.0 * H * W, &e);
+        grad_mul = (float)ldexp(1.0, e - 7);
+    }
     TRY(vad_conv3x3_to3_tanh_bwd(ws + p.rt[3], recon, drecon ? nullptr : x, drecon, ws + p.pk_last_dg, ws + p.dpre, g0, G + p.last_w, G + p.last_b,
-                                 ws + p.to3_ws, N, H, W, 32, s));
+                                 ws + p.to3_ws, N, H, W, 32, grad_mul, s));
     for (int j = 3; j >= 0; --j) {
         const int ci = p.d[j], co = p.d[j + 1], hj = (H / 16) << j, wj = (W / 16) << j;
         if (j < 3) {      // conv-BN-ReLU: g0 = d rc_j -> g2 = d yc_j -> weight gradient, g0 = d rt_j
@@ -272,5 +280,6 @@ extern "C" int vad_img_train_fwd_bwd(const float* x, int n, int h, int w, int la
             TRY(conv3(g2, ws + p.pk_ea_dg[i], zeros, g0, hi, wi, co, ci));      // g0 = d p_{i-1}
         }
     }
+    if (grad_mul != 1.f) TRY(vad_scale_floats(G, (long long)p.nparams, 1.f / grad_mul, s));
     return VAD_OK;
 }

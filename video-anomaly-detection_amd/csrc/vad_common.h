@@ -23,6 +23,14 @@ int vad_fail(int code, const char* fmt, ...);
         if (!(cond)) return vad_fail(VAD_ERR_ARG, __VA_ARGS__); \
     } while (0)
 
+// A positive, finite power of two: multiplying by it is exact (up to overflow / underflow), which is what the gradient
+// rescaling of the split-fp16 training mode relies on.
+static inline bool vad_is_pow2f(float v) {
+    unsigned u;
+    __builtin_memcpy(&u, &v, 4);
+    return v > 0.f && (u & 0x007fffffu) == 0u && (u >> 23) != 0u && (u >> 23) != 0xffu;
+}
+
 // Launch check: kernel launches report configuration errors through hipGetLastError.
 #define VAD_LAUNCH_CHECK() VAD_HIP_TRY(hipGetLastError())
 

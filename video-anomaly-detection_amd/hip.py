@@ -161,7 +161,8 @@ SIGNATURES = {
     "vad_lstm_gates_fwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _vp]),
     "vad_lstm_gates_bwd_t": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "vad_conv_c3_wgrad_t": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "vad_convt_to3_mse_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vad_convt_to3_mse_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "vad_scale_floats": (_i, [_vp, _ll, _f, _vp]),
     "vad_train_pack_conv1x1_p": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
     "vad_conv1x1_p": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "vad_conv3x3_c3_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -175,13 +176,15 @@ SIGNATURES = {
     "vad_train_pack_conv1x1": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "vad_train_pack_conv3x3_to3": (_i, [_vp, _i, _vp, _vp, _vp]),
     "vad_conv3x3_to3_bwd_ws_floats": (_sz, [_i, _i, _i, _i]),
-    "vad_conv3x3_to3_tanh_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_conv3x3_to3_tanh_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "vad_vid_train_nparams": (_sz, [_i, _i, _i]),
     "vad_vid_train_nstats": (_sz, [_i, _i, _i]),
     "vad_vid_train_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "vad_debug_set_train_decisions": (_i, [_vp, _sz]),
     "vad_debug_train_decisions_used": (_sz, []),
     "vad_debug_set_train_stop": (_i, [_i]),
+    "vad_debug_set_split_grad_scale": (_i, [_i]),
+    "vad_split_grad_scale_enabled": (_i, []),
     "vad_vid_train_debug_layout": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "vad_vid_train_fwd_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "vad_img_train_nparams": (_sz, [_i]),
