@@ -154,7 +154,7 @@ def test_image_train_step_gradients_match_decision_conditioned_float64(vad, late
         assert ndiff <= max(3, total // 100000), f"{stage}: {ndiff} of {total} branch decisions differ from float64"
         assert margin < 2e-4, f"{stage}: a differing decision has margin {margin:.3e}"
     assert abs(loss_gpu - loss64) < 5e-6 * abs(loss64), (loss_gpu, loss64)
-    bound = 1e-3 if precision == "split" else 2e-4         # split: 22-bit products through 15 BatchNorm backward stages; winograd: fp32, the exact mode's bound
+    bound = 2e-4         # every mode (measured 6e-6 .. 1.3e-5; split: since its backward runs on gradients scaled into the fp16 range - unscaled it needed 1e-3)
     zero_true, worst = _bn_fed_biases(m), 0.0
     assert len(zero_true) == 15
     for k, r in want.items():
