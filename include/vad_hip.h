@@ -246,7 +246,9 @@ int vad_lstm_gates_bwd(const float* gates, const float* c_prev, const float* c, 
  *   taps 1, layout 3: ConvTranspose2d(32->3) from the 32-column dpre of vad_convt_to3_mse, dw (32, 3, 2, 2)
  *   taps 1, layout 4: Conv2d k1 (VideoAutoencoder.proj) weight gradient, dw OIHW (ncols, cin, 1, 1) */
 size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int ncols);
-/* precision VAD_PREC_FP32 / VAD_PREC_SPLIT: exact fp32 (v_mfma_f32_32x32x2_f32, two pixels per instruction);
+/* precision VAD_PREC_FP32: exact fp32 (v_mfma_f32_32x32x2_f32, two pixels per instruction); VAD_PREC_SPLIT (round 4): both
+ * operands split into fp16 (hi, lo) pairs as they are packed, three v_mfma_f32_32x32x16_f16 per 16 pixels (22-bit products, fp32
+ * accumulation; |a|, |g| < 65504 and g should sit in the fp16 range - the step scales its gradients, see vad_convt_to3_mse_t);
  * VAD_PREC_BF16: both operands rounded to bf16, v_mfma_f32_32x32x16_bf16 (16 pixels per instruction), fp32 accumulation and
  * fp32 split-K partials. */
 int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
@@ -357,6 +359,8 @@ size_t vad_debug_train_decisions_used(void);
  * kernel (dword loads, 64 x 64 wave tiles) where cin and ncols are multiples of 64; 2 (default) = its LDS-staged work-group
  * form where ncols is a multiple of 128. */
 int vad_debug_set_wgrad_pairs(int on);
+/* A/B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3); 1 (default) = the split-fp16 kernel. */
+int vad_debug_set_wgrad_split(int on);
 /* 1 (default): the BatchNorm forward / backward-apply passes on bf16 tensors take eight channels per thread (16-byte accesses);
  * 0: four, like the fp32 form.  Identical results (every element goes through the same expressions). */
 int vad_debug_set_bn_wide(int on);

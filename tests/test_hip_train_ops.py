@@ -187,7 +187,7 @@ def test_lstm_gates_forward_backward(vad, nb, hw, hid, first):
 @pytest.mark.parametrize("precision", [0, 1])
 def test_conv3x3_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
     """precision 1: the device packers emit the split-fp16 operand form and the forward / data-gradient convolutions run
-    on it (the weight gradient is fp32 in both modes)."""
+    on it; the weight gradient is checked in all three operand forms (exact, bf16, split-fp16) either way."""
     _check_conv3x3_gradients(vad, n, h, w, cin, cout, precision)
 
 
@@ -209,6 +209,10 @@ def _check_conv3x3_gradients(vad, n, h, w, cin, cout, precision):
     dwb = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
     vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), gd.data_ptr(), dwb.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, 2, H.stream()))
     _close(dwb.cpu().numpy(), wtt.grad.numpy(), 1e-2, "dW (bf16 operands)")
+    # split-fp16 operands (VAD_PREC_SPLIT, round 4): 22-bit products - the exact kernel's result to a few 1e-7 of the largest entry
+    dws = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), gd.data_ptr(), dws.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, 1, H.stream()))
+    _close(dws.cpu().numpy(), dw.cpu().numpy(), 2e-6, "dW (split-fp16 operands) against the exact kernel")
 
     # data gradient = forward kernel on the re-packed weight (device-side packing of the live parameter)
     wd = H.dev(wt)
@@ -231,6 +235,35 @@ def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
     _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision)
 
 
+@pytest.mark.parametrize("n,h,w,cin,ncols,taps", [(2, 24, 40, 64, 64, 9), (3, 12, 33, 32, 64, 9), (2, 16, 16, 128, 256, 9), (5, 7, 20, 64, 128, 9),
+                                                  (2, 9, 64, 32, 128, 9), (2, 24, 40, 64, 256, 1), (3, 12, 33, 32, 128, 1), (4, 16, 16, 128, 128, 1)])
+def test_split_weight_gradient_kernel_forms(vad, n, h, w, cin, ncols, taps):
+    """VAD_PREC_SPLIT weight gradients: the per-lane kernel (vad_debug_set_wgrad_split(1)) and its LDS-staged, transposed form
+    (2, default where ncols % 64 == 0 and cin % 64 == 0 or cin == 32: 16- and 32-pixel groups, ragged widths, pixel halves for
+    32-channel layers) against the exact-fp32 kernel (0) on the same operands: 22-bit products, 2e-6 of the largest entry."""
+    import hip_helpers as H
+    l, rng = vad.hip.lib(), _rng(cin + ncols + w)
+    a = H.dev(rng.standard_normal((n, h, w, cin)).astype(np.float32))
+    g = H.dev((rng.standard_normal((n, h, w, ncols)) * 0.05).astype(np.float32))
+    layout = 0 if taps == 9 else 4
+    shape = (ncols, cin, 3, 3) if taps == 9 else (ncols, cin, 1, 1)
+    ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, taps, cin, ncols))
+    out = {}
+    try:
+        for mode in (0, 1, 2):
+            l.vad_debug_set_wgrad_split(mode)
+            dw = torch.full(shape, float("nan"), device="cuda")
+            vad.hip.check(l.vad_conv_wgrad(a.data_ptr(), g.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, w, cin, ncols, taps, layout, 1, H.stream()))
+            out[mode] = dw.cpu().numpy()
+    finally:
+        l.vad_debug_set_wgrad_split(2)
+    ref = torch.einsum("nhwc,nhwk->kc", a.double()[:, :, :, :], g.double()) if taps == 1 else None
+    if taps == 1:
+        _close(out[0].reshape(ncols, cin), ref.cpu().numpy(), 1e-5, "exact kernel against float64")
+    _close(out[1], out[0], 2e-6, "per-lane split kernel")
+    _close(out[2], out[0], 2e-6, "LDS-staged split kernel")
+
+
 def _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision):
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin * 3 + cout + h)
@@ -249,6 +282,9 @@ def _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision):
     dwb = torch.full((cin, cout, 2, 2), float("nan"), device="cuda")
     vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), g_s2d.data_ptr(), dwb.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, 2, H.stream()))
     _close(dwb.cpu().numpy(), wtt.grad.numpy(), 1e-2, "dW (bf16 operands)")
+    dws = torch.full((cin, cout, 2, 2), float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv_wgrad(ad.data_ptr(), g_s2d.data_ptr(), dws.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, 1, H.stream()))
+    _close(dws.cpu().numpy(), dw.cpu().numpy(), 2e-6, "dW (split-fp16 operands) against the exact kernel")
 
     wd = H.dev(wt)
     fwd = _ws(l.vad_pack_convt2x2_floats(cin, cout))

@@ -774,6 +774,327 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(WgradP p) {
             }
 }
 
+// Split-fp16 form (VAD_PREC_SPLIT, round 4): the same lane / pixel mapping as the bf16 kernel above on fp32 tensors, each operand
+// value split into hi = fp16(v) and lo = fp16((v - hi) 2^11) (vad_split, conv_pkernel.h) as it is packed:
+//   dw += ah gh + (ah gl + al gh) 2^-11      22-bit products, fp32 accumulation, three v_mfma_f32_32x32x16_f16 per 16 pixels
+// with the correction terms in accumulators of their own (they carry the 2^11) that the epilogue folds in.  Twice the
+// accumulators: a 3x3 item is ONE kernel row of a 32 x 32 tile (3 taps: 6 accumulator tiles; 18 loads per 9 MFMAs - the
+// gradient row is re-read per kernel row), a 1x1 item is the bf16 kernel's.  The gradient operand arrives scaled into the fp16
+// range by the step (train_step.hip: grad_mul), the activations are O(1).
+typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void wg_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const wg_f16x2 h = {(_Float16)a, (_Float16)b};
+    const wg_f16x2 l = {(_Float16)((a - (float)h[0]) * 2048.0f), (_Float16)((b - (float)h[1]) * 2048.0f)};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// The same split in five instructions per PAIR: one packed conversion, the two residuals a - hi straight from the packed halves
+// (v_fma_mix_f32: an f16 source widened inside the FMA), and scale + conversion + packing of the lo halves in
+// v_fma_mixlo_f16 / v_fma_mixhi_f16.  Every step is exact or the single rounding of the C form above (a - hi and r * 2048 are
+// exact in fp32): bit-identical to wg_split2, which the per-lane kernel keeps - tests/test_hip_train_ops.py compares the two.
+__device__ __forceinline__ void wg_split2_fast(float a, float b, unsigned& hi, unsigned& lo) {
+    unsigned h, l;
+    float ra, rb;
+    const float k2048 = 2048.0f;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l) : "v"(ra), "s"(k2048));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l) : "v"(rb), "s"(k2048));
+    hi = h;
+    lo = l;
+}
+__device__ __forceinline__ wg_f16x8 wg_hfrag(unsigned a, unsigned b, unsigned c, unsigned d) { return __builtin_bit_cast(wg_f16x8, u32x4{a, b, c, d}); }
+
+template <int TAPS, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(WgradP p) {
+    constexpr int ND = TAPS == 9 ? 3 : 1, HALO = TAPS == 9 ? 1 : 0, NE = 8 + 2 * HALO, NPASS = TAPS == 9 ? 3 : 1;
+    const int lane = threadIdx.x & 63, li = lane & 31, kb = lane >> 5;
+    unsigned item = __builtin_amdgcn_readfirstlane(vad_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));   // see WGRAD_XCD
+    if (item >= p.nitems) return;
+    const int ct = item % p.ci_tiles; item /= p.ci_tiles;
+    const int cgp = item % p.col_groups; item /= p.col_groups;
+    const int pass = item % NPASS;
+    const int split = item / NPASS;
+    const int H = p.h, W = p.w, total_rows = p.n * H;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * 4u;
+    f32x16 acc[ND][NT], cor[ND][NT];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[d][nt][r] = 0.f; cor[d][nt][r] = 0.f; }
+    const unsigned pix_a = (unsigned)p.cin * 4u, pix_g = (unsigned)p.ncols * 4u;
+    const unsigned lane_a = (unsigned)(ct * 32 + li) * 4u, lane_g = (unsigned)(cgp * NT * 32 + li) * 4u;
+    const __amdgpu_buffer_rsrc_t rzero = vad_rsrc(p.a, 0);
+    const int dyk = TAPS == 9 ? pass - 1 : 0;
+    // two-deep software pipeline over (row, 16-pixel group) as in the bf16 kernel: the next group's loads are in flight while
+    // this one is split and multiplied; past the end of the slice - and on rows whose kernel row falls outside the image -
+    // the descriptors are zero-sized (zeros, no branch around a load)
+    const int groups_per_row = (W + 15) / 16;
+    int lrow = r0, lx = 0;
+    __amdgpu_buffer_rsrc_t ra = rzero, rg = rzero;
+    unsigned abase = 0, gbase = 0;
+    auto LOAD = [&](float (&gv)[NT][8], float (&av)[NE]) {
+        if (lx == 0 && lrow >= r1) {
+            rg = rzero; ra = rzero;
+        } else if (lx == 0) {
+            const int n_ = lrow / H, ly = lrow - n_ * H, yy = ly + dyk;
+            const bool rok = yy >= 0 && yy < H;
+            ra = rok ? vad_rsrc((const char*)p.a + (size_t)n_ * H * W * p.cin * 4u, a_bytes) : rzero;
+            rg = rok ? vad_rsrc((const char*)p.g + (size_t)n_ * H * W * p.ncols * 4u, g_bytes) : rzero;
+            abase = rok ? (unsigned)(yy * W) * pix_a : 0u;
+            gbase = rok ? (unsigned)(ly * W) * pix_g : 0u;
+        }
+        const int px0 = lx + 8 * kb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int x = px0 + e;
+            const unsigned off = x < W ? lane_g + (unsigned)x * pix_g : VAD_OOB;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) gv[nt][e] = vad_bload1(rg, off, gbase + (unsigned)nt * 128u);
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int x = px0 + e - HALO;
+            av[e] = vad_bload1(ra, (unsigned)x < (unsigned)W ? lane_a + (unsigned)x * pix_a : VAD_OOB, abase);
+        }
+        lx += 16;
+        if (lx >= W) { lx = 0; ++lrow; }
+    };
+    auto COMPUTE = [&](const float (&gv)[NT][8], const float (&av)[NE]) {
+        wg_f16x8 gh[NT], gl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wg_split2(gv[nt][2 * k], gv[nt][2 * k + 1], h[k], l[k]);
+            gh[nt] = wg_hfrag(h[0], h[1], h[2], h[3]);
+            gl[nt] = wg_hfrag(l[0], l[1], l[2], l[3]);
+        }
+        unsigned eh[NE / 2], el[NE / 2];          // even-aligned pairs (elements 2k, 2k+1) of the 8 (10) pixels, hi and lo
+#pragma unroll
+        for (int k = 0; k < NE / 2; ++k) wg_split2(av[2 * k], av[2 * k + 1], eh[k], el[k]);
+        auto mma = [&](int d, wg_f16x8 fh, wg_f16x8 fl) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[d][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, gh[nt], acc[d][nt], 0, 0, 0);
+                cor[d][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, gl[nt], cor[d][nt], 0, 0, 0);
+                cor[d][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, gh[nt], cor[d][nt], 0, 0, 0);
+            }
+        };
+        if constexpr (TAPS == 9) {
+            unsigned oh[4], ol[4];                // odd-aligned pairs (2k+1, 2k+2): the halves of two neighbouring even pairs
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                oh[k] = __builtin_amdgcn_alignbit(eh[k + 1], eh[k], 16);
+                ol[k] = __builtin_amdgcn_alignbit(el[k + 1], el[k], 16);
+            }
+            mma(0, wg_hfrag(eh[0], eh[1], eh[2], eh[3]), wg_hfrag(el[0], el[1], el[2], el[3]));      // dx = 0: pixels x-1 .. x+6
+            mma(1, wg_hfrag(oh[0], oh[1], oh[2], oh[3]), wg_hfrag(ol[0], ol[1], ol[2], ol[3]));      // dx = 1: pixels x   .. x+7
+            mma(2, wg_hfrag(eh[1], eh[2], eh[3], eh[4]), wg_hfrag(el[1], el[2], el[3], el[4]));      // dx = 2: pixels x+1 .. x+8
+        } else {
+            mma(0, wg_hfrag(eh[0], eh[1], eh[2], eh[3]), wg_hfrag(el[0], el[1], el[2], el[3]));
+        }
+    };
+    const int ngroups = (r1 - r0) * groups_per_row;
+    {
+    float gv0[NT][8], av0[NE], gv1[NT][8], av1[NE];
+    LOAD(gv0, av0);
+    for (int it = 0; it < ngroups; it += 2) {
+        LOAD(gv1, av1);
+        __builtin_amdgcn_sched_barrier(0);
+        COMPUTE(gv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD(gv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        COMPUTE(gv1, av1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int tap = (TAPS == 9 ? 3 * pass : 0) + d;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                p.ws[(((size_t)split * TAPS + tap) * p.cin + ci) * p.ncols + (cgp * NT + nt) * 32 + li] = fmaf(cor[d][nt][r], 1.0f / 2048.0f, acc[d][nt][r]);
+            }
+    }
+}
+
+// The split-fp16 GEMM with its operands staged ONCE per work-group, TRANSPOSED, through LDS.  The kernel above re-reads every
+// operand row per 32 x 32 wave tile from L2 (18 64-lane gathers per 9 MFMAs: 1.4 ms on the 193-GFLOP layers of the 32-clip step,
+// ~6.5 TB/s of L2 -> L1 traffic, 140 TFLOP/s) and splits every value once per wave.  Here (32 WM) x (32 WN) x PS waves share a
+// tile of ONE kernel row: per group of GP pixels a thread fetches two horizontally adjacent pixels x 4 channels (two 16-byte
+// loads), splits them once, and writes the (pixel, pixel + 1) fp16 pairs of each channel as one dword into [channel][pixel]
+// planes (hi and lo; rows of PITCH bytes).  A lane's MFMA fragment - 8 consecutive pixels of ITS channel / column - is then
+// one ds_read_b128 (3x3: + one dword for the 10-pixel window; the dx = 1 window is four v_alignbit of neighbours).  The next
+// group's loads are in flight during the MFMAs (two LDS buffers, one barrier per group).  PS > 1: wave groups take alternate
+// 16-pixel sub-groups of a staged group (a split-K factor inside the work-group, partial slot split * PS + ph) so that a
+// 32-channel layer still has four waves per staged tile.  Same products and the same hi / lo arithmetic as the kernel above.
+template <int TAPS, int WM, int WN, int PS, int GP>
+__global__ __launch_bounds__(64 * WM * WN * PS, 3) void conv_wgrad_split_lds_kernel(WgradP p) {
+    static_assert(GP == 16 || GP == 32, "groups of 16 or 32 pixels");
+    static_assert(GP / 16 >= PS, "pixel split needs a 16-pixel sub-group per wave group");
+    constexpr int ND = TAPS == 9 ? 3 : 1, HALO = TAPS == 9 ? 1 : 0, NPASS = TAPS == 9 ? 3 : 1;
+    constexpr int NTH = 64 * WM * WN * PS;
+    constexpr int CA = 32 * WM, CG = 32 * WN;                        // channels / columns of the work-group tile
+    constexpr int NEA = GP + 2 * HALO;                               // A elements (pixels with halo) per group: even
+    constexpr int PAIRS_A = NEA / 2, PAIRS_G = GP / 2;
+    constexpr int PITCH = GP == 32 ? 80 : 48;                        // bytes per [channel] row: >= 2 NEA, 16-byte multiple, b128 reads of 16 lanes hit 64 distinct banks
+    constexpr int NCA = CA / 4, NCG = CG / 4;                        // 4-channel chunks (one 16-byte load per pixel)
+    constexpr int UA = PAIRS_A * NCA, UG = PAIRS_G * NCG;            // staging units per group
+    constexpr int JA = (UA + NTH - 1) / NTH, JG = (UG + NTH - 1) / NTH;
+    constexpr int PLANE_A = CA * PITCH, PLANE_G = CG * PITCH;
+    constexpr int BUF = 2 * PLANE_A + 2 * PLANE_G;                   // [A hi][A lo][G hi][G lo]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kb = lane >> 5;
+    const int ph = wave / (WM * WN), wt = wave % (WM * WN), wm = wt / WN, wn = wt % WN;
+    unsigned item = vad_xcd_remap(blockIdx.x, gridDim.x);             // see WGRAD_XCD
+    const int ct = item % p.ci_tiles; item /= p.ci_tiles;
+    const int cgp = item % p.col_groups; item /= p.col_groups;
+    const int pass = item % NPASS;
+    const int split = item / NPASS;
+    const int H = p.h, W = p.w, total_rows = p.n * H;
+    const int r0 = split * p.rows_per_split, r1 = (r0 + p.rows_per_split < total_rows) ? r0 + p.rows_per_split : total_rows;
+    const int dy = TAPS == 9 ? pass - 1 : 0;
+    const unsigned a_bytes = (unsigned)(H * W) * (unsigned)p.cin * 4u, g_bytes = (unsigned)(H * W) * (unsigned)p.ncols * 4u;
+    const unsigned pix_a = (unsigned)p.cin * 4u, pix_g = (unsigned)p.ncols * 4u;
+    f32x16 acc[ND], cor[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[d][r] = 0.f; cor[d][r] = 0.f; }
+
+    auto row_ok = [&](int row) { const int ly = row % H + dy; return ly >= 0 && ly < H; };
+    int row = r0, lx = 0;
+    while (row < r1 && !row_ok(row)) ++row;
+    // Per-thread invariants of the staging units (unit u = tid + NTH j: 4-channel chunk c = u % NC, pixel pair pr = u / NC): the
+    // lane part of the load offsets (element index times the pixel pitch; the group's position goes into the scalar offset,
+    // with the descriptor's base one halo pixel BEFORE the frame so that it is never negative), the first element's index for
+    // the range check, and the LDS byte offset of the pair.
+    unsigned voa[JA], vog[JG];
+    int ea[JA], eg[JG], wa[JA], wgo[JG];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int u = tid + NTH * j, c = u % NCA, pr = u / NCA;
+        voa[j] = (unsigned)(2 * pr) * pix_a + (unsigned)c * 16u;
+        ea[j] = u < UA ? 2 * pr - HALO : (1 << 30);                  // (no such unit: never in range)
+        wa[j] = (4 * c) * PITCH + 4 * pr;
+    }
+#pragma unroll
+    for (int j = 0; j < JG; ++j) {
+        const int u = tid + NTH * j, c = u % NCG, pr = u / NCG;
+        vog[j] = (unsigned)(2 * pr) * pix_g + (unsigned)c * 16u;
+        eg[j] = u < UG ? 2 * pr : (1 << 30);
+        wgo[j] = 2 * PLANE_A + (4 * c) * PITCH + 4 * pr;
+    }
+    f32x4 sa[JA][2], sg[JG][2];                      // staging: two adjacent pixels x 4 channels per unit
+    auto fetch = [&](int frow, int flx) {
+        const int n_ = frow / H, ly = frow - n_ * H;
+        const __amdgpu_buffer_rsrc_t ra = vad_rsrc((const char*)p.a + (size_t)n_ * H * W * p.cin * 4u - (size_t)HALO * pix_a, a_bytes + HALO * pix_a);
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const char*)p.g + (size_t)n_ * H * W * p.ncols * 4u, g_bytes);
+        const unsigned abase = (unsigned)((ly + dy) * W + flx) * pix_a + (unsigned)(ct * CA) * 4u;
+        const unsigned gbase = (unsigned)(ly * W + flx) * pix_g + (unsigned)(cgp * CG) * 4u;
+#pragma unroll
+        for (int j = 0; j < JA; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                sa[j][q] = vad_bload4(ra, (unsigned)(ea[j] + q + flx) < (unsigned)W ? voa[j] + (unsigned)q * pix_a : VAD_OOB, abase);
+#pragma unroll
+        for (int j = 0; j < JG; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                sg[j][q] = vad_bload4(rg, (unsigned)(eg[j] + q + flx) < (unsigned)W ? vog[j] + (unsigned)q * pix_g : VAD_OOB, gbase);
+    };
+    auto stash = [&](int b) {
+        unsigned char* base = lds + b * BUF;
+#pragma unroll
+        for (int j = 0; j < JA; ++j)
+            if (ea[j] < (1 << 30)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hi, lo;
+                    wg_split2_fast(sa[j][0][e], sa[j][1][e], hi, lo);
+                    *(unsigned*)(base + wa[j] + e * PITCH) = hi;
+                    *(unsigned*)(base + wa[j] + e * PITCH + PLANE_A) = lo;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < JG; ++j)
+            if (eg[j] < (1 << 30)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hi, lo;
+                    wg_split2_fast(sg[j][0][e], sg[j][1][e], hi, lo);
+                    *(unsigned*)(base + wgo[j] + e * PITCH) = hi;
+                    *(unsigned*)(base + wgo[j] + e * PITCH + PLANE_G) = lo;
+                }
+            }
+    };
+    auto compute = [&](int b) {
+        const unsigned char* Ah = lds + b * BUF + (wm * 32 + li) * PITCH;
+        const unsigned char* Gh = lds + b * BUF + 2 * PLANE_A + (wn * 32 + li) * PITCH;
+#pragma unroll
+        for (int sub0 = 0; sub0 < GP / 16 / PS; ++sub0) {
+            const int sub = PS > 1 ? sub0 * PS + ph : sub0;
+            const int off = 2 * (16 * sub + 8 * kb);                       // byte offset of element px0 (= pixel lx + px0 - HALO)
+            const u32x4 gh4 = *(const u32x4*)(Gh + off), gl4 = *(const u32x4*)(Gh + PLANE_G + off);
+            const wg_f16x8 gh = __builtin_bit_cast(wg_f16x8, gh4), gl = __builtin_bit_cast(wg_f16x8, gl4);
+            const u32x4 ah4 = *(const u32x4*)(Ah + off), al4 = *(const u32x4*)(Ah + PLANE_A + off);
+            wg_f16x8 fh[ND], fl[ND];
+            fh[0] = __builtin_bit_cast(wg_f16x8, ah4); fl[0] = __builtin_bit_cast(wg_f16x8, al4);                   // elements 0..7
+            if constexpr (TAPS == 9) {
+                const unsigned ah5 = *(const unsigned*)(Ah + off + 16), al5 = *(const unsigned*)(Ah + PLANE_A + off + 16);
+                fh[1] = wg_hfrag(__builtin_amdgcn_alignbit(ah4[1], ah4[0], 16), __builtin_amdgcn_alignbit(ah4[2], ah4[1], 16),
+                                 __builtin_amdgcn_alignbit(ah4[3], ah4[2], 16), __builtin_amdgcn_alignbit(ah5, ah4[3], 16));      // 1..8
+                fl[1] = wg_hfrag(__builtin_amdgcn_alignbit(al4[1], al4[0], 16), __builtin_amdgcn_alignbit(al4[2], al4[1], 16),
+                                 __builtin_amdgcn_alignbit(al4[3], al4[2], 16), __builtin_amdgcn_alignbit(al5, al4[3], 16));
+                fh[2] = wg_hfrag(ah4[1], ah4[2], ah4[3], ah5); fl[2] = wg_hfrag(al4[1], al4[2], al4[3], al5);       // 2..9
+            }
+            // (the two correction products of a tap write the same accumulator: issued a tap apart, never back to back)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[d], gh, acc[d], 0, 0, 0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) cor[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[d], gl, cor[d], 0, 0, 0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) cor[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[d], gh, cor[d], 0, 0, 0);
+        }
+    };
+    if (row < r1) {                                   // (uniform over the work-group: every barrier below is reached by all waves)
+        fetch(row, lx);
+        stash(0);
+        __syncthreads();
+        int b = 0;
+        while (true) {
+            int nrow = row, nlx = lx + GP;
+            if (nlx >= W) { nlx = 0; ++nrow; while (nrow < r1 && !row_ok(nrow)) ++nrow; }
+            const bool more = nrow < r1;
+            if (more) fetch(nrow, nlx);               // in flight during this group's MFMAs
+            compute(b);
+            if (!more) break;
+            stash(b ^ 1);                             // the other buffer: its readers passed the last barrier
+            __syncthreads();
+            b ^= 1; row = nrow; lx = nlx;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int tap = (TAPS == 9 ? 3 * pass : 0) + d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ct * CA + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+            p.ws[(((size_t)(split * PS + ph) * TAPS + tap) * p.cin + ci) * p.ncols + cgp * CG + wn * 32 + li] = fmaf(cor[d][r], 1.0f / 2048.0f, acc[d][r]);
+        }
+    }
+}
+
 // bf16 TENSORS, cin and ncols multiples of 64: the same GEMM with DWORD loads.  A dword holds the channel pair (2l, 2l+1) of
 // one pixel, so the 10 (3x3: 8 pixels + halo) dwords a lane loads for a row feed TWO M-tiles - the tile's even channels from
 // the low halves, its odd channels from the high halves (one v_perm per packed pair) - and the 8 dwords of the gradient feed
@@ -1693,7 +2014,9 @@ int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const
 // debug / A-B: 0 = the bf16-tensor mode uses the one-channel-per-lane kernel everywhere, 1 = paired-channel kernel (dword loads
 // per wave) where cin and ncols are multiples of 64, 2 (default) = its LDS-staged work-group form where ncols is a multiple of 128
 static std::atomic<int> g_wgrad_x2{2};
+static std::atomic<int> g_wgrad_split{2};   // debug / A-B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3), 1 = the per-lane split-fp16 kernel, 2 = its LDS-staged form where it applies
 extern "C" int vad_debug_set_wgrad_pairs(int on) { g_wgrad_x2 = on; return VAD_OK; }
+extern "C" int vad_debug_set_wgrad_split(int on) { g_wgrad_split = on; return VAD_OK; }
 
 // split-K factor: enough waves to fill the chip (~4096), never more splits than image rows.  Measured on both training
 // steps (32 clips / 128 images): a 2048-wave target is within noise of 4096 (35.8 vs 35.6-36.0 ms, 38.5 vs 39.0 ms), 1024
@@ -1709,11 +2032,23 @@ static int wgrad_splits(long long tiles, int total_rows) {
     return (int)s;
 }
 
+// work-group items of the LDS-staged split-fp16 kernel: ~two rounds of the 3 x 256 resident work-groups
+static int wgrad_split_lds_splits(long long tiles, int total_rows) {
+    long long s = (1536 + tiles - 1) / tiles;
+    if (s > total_rows) s = total_rows;
+    if (s > 2048) s = 2048;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+// (3x3 layers only: the 1x1 / transposed layers have a third of the MFMAs per staged byte and measured slower than the per-lane
+// kernel - 102 / 206 / 231 us against 78 / 164 / 219 us on the decoder's three)
+static bool wgrad_split_lds_ok(int taps, int w, int cin, int ncols) { return taps == 9 && ncols % 64 == 0 && (cin % 64 == 0 || (cin == 32 && w > 16)); }
+
 extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int ncols) {
     if (n <= 0 || h <= 0 || cin <= 0 || ncols <= 0 || cin % 32 || ncols % 32 || (taps != 9 && taps != 1)) return 0;
     const int nt = (taps == 1 && ncols % 128 == 0) ? 4 : 1;
     const long long tiles = (long long)(cin / 32) * (ncols / (32 * nt));
-    int splits = wgrad_splits(tiles, n * h);
+    int splits = wgrad_splits(tiles, n * h);       // (the split-fp16 kernel has 3x the tiles of a 3x3 layer: never more splits)
     if (cin % 64 == 0 && ncols % 64 == 0) {      // the paired-channel kernel of the bf16-tensor mode: 64 x 64 tiles, one item per kernel row
         const int s2 = wgrad_splits((long long)(cin / 64) * (ncols / 64) * (taps == 9 ? 3 : 1), n * h);
         if (s2 > splits) splits = s2;
@@ -1726,13 +2061,18 @@ extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int 
             if (s3 * ps > splits) splits = (int)(s3 * ps);
         }
     }
+    if (taps == 9 && ncols % 64 == 0 && (cin % 64 == 0 || cin == 32)) {      // the LDS-staged split-fp16 kernel (any map width: upper bound)
+        const int wm = cin % 64 == 0 ? 2 : 1, ps = wm == 1 ? 2 : 1;
+        const int s4 = wgrad_split_lds_splits((long long)(cin / (32 * wm)) * (ncols / 64) * (taps == 9 ? 3 : 1), n * h) * ps;
+        if (s4 > splits) splits = s4;
+    }
     return (size_t)splits * taps * cin * ncols;
 }
 
 extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* ws, int n, int h, int w, int cin, int ncols,
                               int taps, int layout, int precision, void* stream) {
     VAD_REQUIRE(a && g && dw && ws && n > 0 && h > 0 && w > 0, "conv_wgrad: bad arguments");
-    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "conv_wgrad: precision=%d must be 0 (fp32), 1 (split: weight gradients stay fp32), 2 (bf16 operands) or 3 (a and g are bf16 tensors)", precision);
+    VAD_REQUIRE(precision >= VAD_PREC_FP32 && precision <= VAD_PREC_BF16S, "conv_wgrad: precision=%d must be 0 (fp32), 1 (split-fp16 operands), 2 (bf16 operands) or 3 (a and g are bf16 tensors)", precision);
     VAD_REQUIRE(cin % 32 == 0 && ncols % 32 == 0 && cin > 0 && ncols > 0, "conv_wgrad: cin=%d ncols=%d must be multiples of 32", cin, ncols);
     VAD_REQUIRE((taps == 9 && layout == 0) || (taps == 1 && (layout == 1 || layout == 3 || layout == 4)), "conv_wgrad: taps/layout mismatch");
     VAD_REQUIRE(layout != 1 || ncols % 128 == 0, "conv_wgrad: convT gradient needs ncols = 4*cout");
@@ -1777,6 +2117,30 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
         VAD_LAUNCH_CHECK();
         return VAD_OK;
     }
+    if (precision == VAD_PREC_SPLIT && g_wgrad_split.load(std::memory_order_relaxed) >= 2 && wgrad_split_lds_ok(taps, w, cin, ncols)) {
+        const int npass = taps == 9 ? 3 : 1, wm = cin % 64 == 0 ? 2 : 1, ps = wm == 1 ? 2 : 1;
+        p.ci_tiles = cin / (32 * wm); p.col_groups = ncols / 64;
+        const long long tiles4 = (long long)p.ci_tiles * p.col_groups * npass;
+        p.splits = wgrad_split_lds_splits(tiles4, n * h);
+        p.rows_per_split = (n * h + p.splits - 1) / p.splits;
+        p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;
+        const long long items4 = tiles4 * p.splits;
+        VAD_REQUIRE(items4 < (1ll << 31), "conv_wgrad: too many work items");
+        VAD_REQUIRE((size_t)p.splits * ps * taps * cin * ncols <= vad_conv_wgrad_ws_floats(n, h, taps, cin, ncols),
+                    "conv_wgrad: internal error: %d x %d partial slots exceed the size vad_conv_wgrad_ws_floats reports", p.splits, ps);
+        p.nitems = (unsigned)items4;
+        hipStream_t s4 = (hipStream_t)stream;
+        const dim3 g4((unsigned)items4);
+        const bool narrow = w <= 16;
+#define WSL(T_, WM_, PS_, GP_) hipLaunchKernelGGL((conv_wgrad_split_lds_kernel<T_, WM_, 2, PS_, GP_>), g4, dim3(128 * WM_ * PS_), 0, s4, p)
+        if (wm == 1) WSL(9, 1, 2, 32); else if (narrow) WSL(9, 2, 1, 16); else WSL(9, 2, 1, 32);
+#undef WSL
+        VAD_LAUNCH_CHECK();
+        const long long total4 = (long long)taps * cin * ncols;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s4, (const float*)ws, p.splits * ps, taps, cin, ncols, layout, dw);
+        VAD_LAUNCH_CHECK();
+        return VAD_OK;
+    }
     if (precision == VAD_PREC_BF16S && cin % 64 == 0 && ncols % 64 == 0 && g_wgrad_x2.load(std::memory_order_relaxed)) {
         const int npass = taps == 9 ? 3 : 1;
         p.ci_tiles = cin / 64; p.col_groups = ncols / 64;
@@ -1800,7 +2164,9 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     }
     const int nt = (taps == 1 && ncols % 128 == 0) ? 4 : 1;
     p.ci_tiles = cin / 32; p.col_groups = ncols / (32 * nt);
-    const long long tiles = (long long)p.ci_tiles * p.col_groups;
+    const bool split16 = precision == VAD_PREC_SPLIT && g_wgrad_split.load(std::memory_order_relaxed);
+    const int npass = (split16 && taps == 9) ? 3 : 1;          // the split-fp16 kernel's 3x3 items are kernel rows
+    const long long tiles = (long long)p.ci_tiles * p.col_groups * npass;
     p.splits = wgrad_splits(tiles, n * h);
     p.rows_per_split = (n * h + p.splits - 1) / p.splits;
     p.splits = (n * h + p.rows_per_split - 1) / p.rows_per_split;     // no empty splits
@@ -1816,6 +2182,10 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
         if (taps == 9) { WG16(9, 1, 1) } else if (nt == 4) { WG16(1, 4, 1) } else { WG16(1, 1, 1) }
     } else if (precision == VAD_PREC_BF16) {
         if (taps == 9) { WG16(9, 1, 0) } else if (nt == 4) { WG16(1, 4, 0) } else { WG16(1, 1, 0) }
+    } else if (split16) {
+        if (taps == 9) hipLaunchKernelGGL((conv_wgrad_split_kernel<9, 1>), grid, dim3(256), 0, s, p);
+        else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1>), grid, dim3(256), 0, s, p);
     } else if (taps == 9) hipLaunchKernelGGL((conv_wgrad_kernel<9, 1>), grid, dim3(256), 0, s, p);
     else if (nt == 4) hipLaunchKernelGGL((conv_wgrad_kernel<1, 4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, p);
