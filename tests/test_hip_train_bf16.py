@@ -82,7 +82,7 @@ def _batchnorm_passes_on_bf16_tensors(vad, n, h, w, c, act, pool):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 8, 32, 32), (3, 6, 10, 64, 32), (2, 16, 16, 256, 512), (6, 32, 32, 32, 64),
-                                            (2, 3, 3, 64, 128), (4, 7, 7, 128, 64), (2, 20, 36, 64, 128)])
+                                            (2, 3, 3, 64, 128), (4, 7, 7, 128, 64), (2, 20, 36, 64, 128), (5, 9, 70, 128, 64), (7, 5, 16, 32, 128)])
 def test_conv3x3_on_bf16_tensors_equals_the_bf16_operand_kernels(vad, n, h, w, cin, cout):
     """forward + BatchNorm partial sums, data gradient and weight gradient of a 3x3 convolution"""
     import hip_helpers as H
@@ -108,17 +108,20 @@ def test_conv3x3_on_bf16_tensors_equals_the_bf16_operand_kernels(vad, n, h, w, c
     ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, 9, cin, cout))
     w32, w16 = _nan32(cout, cin, 3, 3), _nan32(cout, cin, 3, 3)
     vad.hip.check(l.vad_conv_wgrad(a32.data_ptr(), g32.data_ptr(), w32.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16, H.stream()))
-    l.vad_debug_set_wgrad_pairs(0)
     try:
+        l.vad_debug_set_wgrad_pairs(0)
         vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16S, H.stream()))
+        assert torch.equal(w16, w32)                                             # parameter gradients stay fp32
+        # the other kernel forms, each where it applies (else the call falls through to the next lower one): 1 = paired channels
+        # (dword loads, 64 x 64 wave tiles, one item per kernel row), 2 = its LDS-staged work-group form, 3 (default) = the
+        # row-ring kernel: the same bf16 products, fp32 sums split differently over the image
+        for mode in (1, 2, 3):
+            l.vad_debug_set_wgrad_pairs(mode)
+            w16p = _nan32(cout, cin, 3, 3)
+            vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16p.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16S, H.stream()))
+            assert float((w16p - w32).abs().max()) < 2e-5 * float(w32.abs().max()), mode
     finally:
-        l.vad_debug_set_wgrad_pairs(1)
-    assert torch.equal(w16, w32)                                             # parameter gradients stay fp32
-    # default: the paired-channel kernel where cin and cout are multiples of 64 (dword loads, 64 x 64 tiles, one item per kernel
-    # row): the same bf16 products, fp32 sums split differently over the image rows
-    w16p = _nan32(cout, cin, 3, 3)
-    vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16p.data_ptr(), ws.data_ptr(), n, h, w, cin, cout, 9, 0, BF16S, H.stream()))
-    assert float((w16p - w32).abs().max()) < 2e-5 * float(w32.abs().max())
+        l.vad_debug_set_wgrad_pairs(3)
     # and the bf16-operand kernel itself is held to float64 on these inputs (products exact, fp32 sums)
     ref = torch.nn.functional.conv2d(a32.double().permute(0, 3, 1, 2).cpu(), wt.to(torch.bfloat16).double().cpu(), bias.double().cpu(), padding=1)
     assert float((o32.permute(0, 3, 1, 2).cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
@@ -142,15 +145,17 @@ def test_convt2x2_on_bf16_tensors(vad, n, h, w, cin, cout):
     ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, 1, cin, 4 * cout))
     w32, w16 = _nan32(cin, cout, 2, 2), _nan32(cin, cout, 2, 2)
     vad.hip.check(l.vad_conv_wgrad(a32.data_ptr(), g32.data_ptr(), w32.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16, H.stream()))
-    l.vad_debug_set_wgrad_pairs(0)
     try:
+        l.vad_debug_set_wgrad_pairs(0)
         vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16S, H.stream()))
+        assert torch.equal(w16, w32)
+        for mode in (1, 2, 3):
+            l.vad_debug_set_wgrad_pairs(mode)
+            w16p = _nan32(cin, cout, 2, 2)
+            vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16p.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16S, H.stream()))
+            assert float((w16p - w32).abs().max()) < 2e-5 * float(w32.abs().max()), mode
     finally:
-        l.vad_debug_set_wgrad_pairs(1)
-    assert torch.equal(w16, w32)
-    w16p = _nan32(cin, cout, 2, 2)
-    vad.hip.check(l.vad_conv_wgrad(a16.data_ptr(), g16.data_ptr(), w16p.data_ptr(), ws.data_ptr(), n, h, w, cin, 4 * cout, 1, 1, BF16S, H.stream()))
-    assert float((w16p - w32).abs().max()) < 2e-5 * float(w32.abs().max())
+        l.vad_debug_set_wgrad_pairs(3)
     # 1x1 data gradient (K = 4*cout) on bf16 operands: against float64 on the same bf16 values; products are exact, the sum
     # is fp32, the result is rounded to bf16 (2^-9 relative)
     # (pixel counts that are not a multiple of 16 run as one ragged frame: (2, 5, 3) -> 30 pixels)

@@ -236,11 +236,11 @@ def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
 
 
 @pytest.mark.parametrize("n,h,w,cin,ncols,taps", [(2, 24, 40, 64, 64, 9), (3, 12, 33, 32, 64, 9), (2, 16, 16, 128, 256, 9), (5, 7, 20, 64, 128, 9),
-                                                  (2, 9, 64, 32, 128, 9), (2, 24, 40, 64, 256, 1), (3, 12, 33, 32, 128, 1), (4, 16, 16, 128, 128, 1)])
+                                                  (2, 9, 64, 32, 128, 9), (7, 5, 70, 64, 64, 9), (2, 24, 40, 64, 256, 1), (3, 12, 33, 32, 128, 1), (4, 16, 16, 128, 128, 1)])
 def test_split_weight_gradient_kernel_forms(vad, n, h, w, cin, ncols, taps):
     """VAD_PREC_SPLIT weight gradients: the per-lane kernel (vad_debug_set_wgrad_split(1)) and its LDS-staged, transposed form
-    (2, default where ncols % 64 == 0 and cin % 64 == 0 or cin == 32: 16- and 32-pixel groups, ragged widths, pixel halves for
-    32-channel layers) against the exact-fp32 kernel (0) on the same operands: 22-bit products, 2e-6 of the largest entry."""
+    (2, where ncols % 64 == 0 and cin % 64 == 0 or cin == 32: 16- and 32-pixel groups, ragged widths, pixel halves for
+    32-channel layers) and the row-ring kernel (3, default for those 3x3 layers: every operand row staged once) against the exact-fp32 kernel (0) on the same operands: 22-bit products, 2e-6 of the largest entry."""
     import hip_helpers as H
     l, rng = vad.hip.lib(), _rng(cin + ncols + w)
     a = H.dev(rng.standard_normal((n, h, w, cin)).astype(np.float32))
@@ -250,18 +250,19 @@ def test_split_weight_gradient_kernel_forms(vad, n, h, w, cin, ncols, taps):
     ws = _ws(l.vad_conv_wgrad_ws_floats(n, h, taps, cin, ncols))
     out = {}
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             l.vad_debug_set_wgrad_split(mode)
             dw = torch.full(shape, float("nan"), device="cuda")
             vad.hip.check(l.vad_conv_wgrad(a.data_ptr(), g.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, w, cin, ncols, taps, layout, 1, H.stream()))
             out[mode] = dw.cpu().numpy()
     finally:
-        l.vad_debug_set_wgrad_split(2)
+        l.vad_debug_set_wgrad_split(3)
     ref = torch.einsum("nhwc,nhwk->kc", a.double()[:, :, :, :], g.double()) if taps == 1 else None
     if taps == 1:
         _close(out[0].reshape(ncols, cin), ref.cpu().numpy(), 1e-5, "exact kernel against float64")
     _close(out[1], out[0], 2e-6, "per-lane split kernel")
     _close(out[2], out[0], 2e-6, "LDS-staged split kernel")
+    _close(out[3], out[0], 2e-6, "row-ring split kernel (3x3 layers; else the LDS-staged one again)")
 
 
 def _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision):

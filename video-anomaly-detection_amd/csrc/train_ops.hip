@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "vad_common.h"
 
@@ -1095,6 +1096,225 @@ __global__ __launch_bounds__(64 * WM * WN * PS, 3) void conv_wgrad_split_lds_ker
     }
 }
 
+// ROW-RING form of the 3x3 weight gradient (round 4): every operand row is staged ONCE per work-group.
+// The LDS-staged kernels above and below take one kernel row per work item, so a tile's three kernel rows stage the gradient
+// row three times and the activation rows three times: on bf16 tensors that is 1.5 GB of L2 requests for the 0.5 GB of a
+// 64 -> 128 @ 64x64 layer, 4.2 TB/s for 360 us - the fabric, not the matrix pipe (0.21 of its peak).  Here a work-group owns a
+// (32 WM) x (32 WN) tile of ALL nine taps and walks DOWN a column strip of GP pixels, frame after frame: per output row it
+// stages one new activation row (GP + 2 pixels) into a ring of four and one gradient row into a double buffer, transposed
+// ([channel][pixel], a lane's 8-pixel fragment is one ds_read_b128 as in conv_wgrad_split_lds_kernel), and multiplies the three
+// activation rows in the ring against the gradient row.  Between frames the stream of activation rows carries one zero row (the
+// padding below one frame and above the next), which costs one idle step per frame.
+// FMT 0: bf16 tensors, v_mfma_f32_32x32x16_bf16, a wave holds the nine taps of its 32 x 32 tile (144 accumulator registers).
+// FMT 1: fp32 tensors in split-fp16 arithmetic (hi / lo planes, three MFMAs per product): two accumulator sets per tap, so the
+// three kernel rows of a tile go to three wave groups (96 registers each) that share the staged rows.
+struct WgradRingP {
+    const void* a; const void* g; float* ws;
+    int n, h, w, cin, ncols;
+    int ci_tiles, col_groups, strips, frames_per_split;
+};
+
+template <int FMT, int WM, int WN, int GP>
+__global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void conv_wgrad_ring_kernel(WgradRingP p) {
+    static_assert(GP == 16 || GP == 32, "strips of 16 or 32 pixels");
+    constexpr int ES = FMT ? 4 : 2, CPL = 16 / ES;                   // element bytes, channels per 16-byte load
+    constexpr int NKW = FMT ? 3 : 1, KRW = 3 / NKW;                  // wave groups over kernel rows, kernel rows per wave
+    constexpr int NTH = 64 * WM * WN * NKW;
+    constexpr int CA = 32 * WM, CG = 32 * WN;
+    constexpr int NEA = GP + 2, PAIRS_A = NEA / 2, PAIRS_G = GP / 2;
+    constexpr int PITCH = GP == 32 ? 80 : 48;                        // bytes per [channel] row (16-byte multiple; b128 reads of 16 lanes cover all banks)
+    constexpr int NCA = CA / CPL, NCG = CG / CPL;
+    constexpr int UA = PAIRS_A * NCA, UG = PAIRS_G * NCG;
+    constexpr int JA = (UA + NTH - 1) / NTH, JG = (UG + NTH - 1) / NTH;
+    constexpr int NPL = FMT ? 2 : 1;                                 // planes: hi, lo
+    constexpr int PLANE_A = CA * PITCH, PLANE_G = CG * PITCH;
+    constexpr int SLOT_A = NPL * PLANE_A, BUF_G = NPL * PLANE_G;
+    constexpr int DUMP = 4 * SLOT_A + 2 * BUF_G;                     // where threads without a staging unit store (no branch in the step)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DUMP + (SLOT_A > BUF_G ? SLOT_A : BUF_G)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kb = lane >> 5;
+    const int kw = wave / (WM * WN), wt = wave % (WM * WN), wm = wt / WN, wn = wt % WN;
+    unsigned item = vad_xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = item % p.ci_tiles; item /= p.ci_tiles;
+    const int cgp = item % p.col_groups; item /= p.col_groups;
+    const int strip = item % p.strips;
+    const int fs = item / p.strips;
+    const int H = p.h, W = p.w, lx = strip * GP;
+    const int f0 = fs * p.frames_per_split, f1 = (f0 + p.frames_per_split < p.n) ? f0 + p.frames_per_split : p.n;
+    const int nf = f1 - f0;
+    const unsigned pix_a = (unsigned)p.cin * ES, pix_g = (unsigned)p.ncols * ES;
+    const unsigned a_bytes = (unsigned)(H * W) * pix_a, g_bytes = (unsigned)(H * W) * pix_g;
+    constexpr int NACC = 3 * KRW;
+    f32x16 acc[NACC], cor[FMT ? NACC : 1];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if constexpr (FMT) cor[t][r] = 0.f; }
+
+    // Staging units (unit u = tid + NTH j), invariants as in the kernel above - but PIXEL PAIR fastest (pr = u % PAIRS, channel chunk
+    // c = u / PAIRS): a unit's ds_write_b32 go CPL rows apart, and rows CPL apart share their banks whatever the (16-byte
+    // aligned) pitch - with the chunk fastest the stores of a wave were 8- to 16-way bank conflicts (SQ_LDS_BANK_CONFLICT: more
+    // than half the kernel's cycles), with the pair fastest consecutive lanes hit consecutive banks.  Four chunks stay together
+    // (lanes 4i .. 4i+3 load 64 contiguous bytes of one pixel: full use of the lines they touch) at the price of a 2-way (fp32
+    // tensors: free) or 4-way (bf16 tensors: twice the store cycles) conflict among them.
+    static_assert(NCA % 4 == 0 && NCG % 4 == 0, "chunk quads");
+    unsigned voa[JA], vog[JG];
+    int ea[JA], eg[JG], wa[JA], wgo[JG];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int u = tid + NTH * j, pr = (u / 4) % PAIRS_A, c = (u / (4 * PAIRS_A)) * 4 + (u & 3);
+        voa[j] = (unsigned)(2 * pr) * pix_a + (unsigned)c * 16u;
+        ea[j] = u < UA ? 2 * pr - 1 + lx : (1 << 30);                // pixel of the pair's first element (no such unit: never in range)
+        wa[j] = (CPL * c) * PITCH + 4 * pr;
+    }
+#pragma unroll
+    for (int j = 0; j < JG; ++j) {
+        const int u = tid + NTH * j, pr = (u / 4) % PAIRS_G, c = (u / (4 * PAIRS_G)) * 4 + (u & 3);
+        vog[j] = (unsigned)(2 * pr) * pix_g + (unsigned)c * 16u;
+        eg[j] = u < UG ? 2 * pr + lx : (1 << 30);
+        wgo[j] = 4 * SLOT_A + (CPL * c) * PITCH + 4 * pr;
+    }
+    // The stream of activation rows: position q = f (H + 1) + r is the zero row for r = 0 and row r - 1 of frame f0 + f otherwise
+    // (position nf (H + 1) is the zero row that closes the last frame).  Output rows sit at the positions with r >= 1.
+    int af = 0, ar = 0;            // next activation position to fetch
+    int gf = 0, gr = 1;            // next gradient position to fetch (the centre of a step)
+    u32x4 sa[2][JA][2], sg[2][JG][2];          // two staging sets: a row is fetched two steps before it is written to LDS
+    auto fetchA = [&](auto SET) {
+        constexpr int X = decltype(SET)::value;
+        const bool real = ar >= 1 && af < nf;
+        // (a zero row is a zero-sized descriptor: its base is never dereferenced)
+        const __amdgpu_buffer_rsrc_t ra = vad_rsrc((const char*)p.a + (size_t)(f0 + af) * H * W * pix_a - pix_a, real ? a_bytes + pix_a : 0u);
+        const unsigned abase = (unsigned)((ar - 1) * W + lx) * pix_a + (unsigned)(ct * CA) * ES;
+#pragma unroll
+        for (int j = 0; j < JA; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                sa[X][j][q] = __builtin_bit_cast(u32x4, vad_bload4(ra, (unsigned)(ea[j] + q) < (unsigned)W ? voa[j] + (unsigned)q * pix_a : VAD_OOB, abase));
+        if (++ar > H) { ar = 0; ++af; }
+    };
+    auto fetchG = [&](auto SET) {
+        constexpr int X = decltype(SET)::value;
+        const bool real = gr >= 1 && gf < nf;
+        const __amdgpu_buffer_rsrc_t rg = vad_rsrc((const char*)p.g + (size_t)(f0 + gf) * H * W * pix_g, real ? g_bytes : 0u);
+        const unsigned gbase = (unsigned)((gr - 1) * W + lx) * pix_g + (unsigned)(cgp * CG) * ES;
+#pragma unroll
+        for (int j = 0; j < JG; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                sg[X][j][q] = __builtin_bit_cast(u32x4, vad_bload4(rg, (unsigned)(eg[j] + q) < (unsigned)W ? vog[j] + (unsigned)q * pix_g : VAD_OOB, gbase));
+        if (++gr > H) { gr = 0; ++gf; }
+    };
+    // two pixels x CPL channels -> CPL dwords (pixel, pixel + 1) of one channel each, written down a column of the [channel][pixel] plane
+    auto put = [&](unsigned char* dst, int plane_bytes, const u32x4& p0, const u32x4& p1) {
+        if constexpr (FMT == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *(unsigned*)(dst + (2 * k) * PITCH) = __builtin_amdgcn_perm(p1[k], p0[k], 0x05040100u);       // low halves: channel 2k
+                *(unsigned*)(dst + (2 * k + 1) * PITCH) = __builtin_amdgcn_perm(p1[k], p0[k], 0x07060302u);   // high halves: channel 2k + 1
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hi, lo;
+                wg_split2_fast(__uint_as_float(p0[e]), __uint_as_float(p1[e]), hi, lo);
+                *(unsigned*)(dst + e * PITCH) = hi;
+                *(unsigned*)(dst + e * PITCH + plane_bytes) = lo;
+            }
+        }
+    };
+    auto stashA = [&](auto SET, int slot) {
+        constexpr int X = decltype(SET)::value;
+#pragma unroll
+        for (int j = 0; j < JA; ++j)
+            put(lds + (ea[j] < (1 << 30) ? slot * SLOT_A + wa[j] : DUMP), PLANE_A, sa[X][j][0], sa[X][j][1]);
+    };
+    auto stashG = [&](auto SET, int buf) {
+        constexpr int X = decltype(SET)::value;
+#pragma unroll
+        for (int j = 0; j < JG; ++j)
+            put(lds + (eg[j] < (1 << 30) ? buf * BUF_G + wgo[j] : DUMP), PLANE_G, sg[X][j][0], sg[X][j][1]);
+    };
+    auto compute = [&](int s) {
+        const unsigned char* G = lds + 4 * SLOT_A + (s & 1) * BUF_G + (wn * 32 + li) * PITCH;
+#pragma unroll
+        for (int sub = 0; sub < GP / 16; ++sub) {
+            const int off = 2 * (16 * sub + 8 * kb);                       // byte offset of element px0 (pixel lx + px0 - 1)
+            const u32x4 gh4 = *(const u32x4*)(G + off);
+            u32x4 gl4 = gh4;
+            if constexpr (FMT) gl4 = *(const u32x4*)(G + PLANE_G + off);
+#pragma unroll
+            for (int k = 0; k < KRW; ++k) {
+                const int kr = FMT ? kw : k;                               // kernel row: activation row (output row - 1 + kr)
+                const unsigned char* A = lds + ((s - 1 + kr) & 3) * SLOT_A + (wm * 32 + li) * PITCH + off;
+                const u32x4 ah4 = *(const u32x4*)A;
+                const unsigned ah5 = (*(const u32x2*)(A + 16))[0];            // (as 8 bytes: a ds_read_b32 of this column is a 4-way bank conflict on 80-byte rows)
+                const u32x4 f1h = {__builtin_amdgcn_alignbit(ah4[1], ah4[0], 16), __builtin_amdgcn_alignbit(ah4[2], ah4[1], 16),
+                                   __builtin_amdgcn_alignbit(ah4[3], ah4[2], 16), __builtin_amdgcn_alignbit(ah5, ah4[3], 16)};
+                const u32x4 f2h = {ah4[1], ah4[2], ah4[3], ah5};
+                if constexpr (FMT == 0) {
+                    acc[3 * k + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, ah4), __builtin_bit_cast(wg_bf16x8, gh4), acc[3 * k + 0], 0, 0, 0);
+                    acc[3 * k + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, f1h), __builtin_bit_cast(wg_bf16x8, gh4), acc[3 * k + 1], 0, 0, 0);
+                    acc[3 * k + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, f2h), __builtin_bit_cast(wg_bf16x8, gh4), acc[3 * k + 2], 0, 0, 0);
+                } else {
+                    const u32x4 al4 = *(const u32x4*)(A + PLANE_A);
+                    const unsigned al5 = (*(const u32x2*)(A + PLANE_A + 16))[0];
+                    const u32x4 f1l = {__builtin_amdgcn_alignbit(al4[1], al4[0], 16), __builtin_amdgcn_alignbit(al4[2], al4[1], 16),
+                                       __builtin_amdgcn_alignbit(al4[3], al4[2], 16), __builtin_amdgcn_alignbit(al5, al4[3], 16)};
+                    const u32x4 f2l = {al4[1], al4[2], al4[3], al5};
+                    const wg_f16x8 gh = __builtin_bit_cast(wg_f16x8, gh4), gl = __builtin_bit_cast(wg_f16x8, gl4);
+                    const wg_f16x8 fh[3] = {__builtin_bit_cast(wg_f16x8, ah4), __builtin_bit_cast(wg_f16x8, f1h), __builtin_bit_cast(wg_f16x8, f2h)};
+                    const wg_f16x8 fl[3] = {__builtin_bit_cast(wg_f16x8, al4), __builtin_bit_cast(wg_f16x8, f1l), __builtin_bit_cast(wg_f16x8, f2l)};
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[d], gh, acc[d], 0, 0, 0);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) cor[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[d], gl, cor[d], 0, 0, 0);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) cor[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[d], gh, cor[d], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (nf > 0) {                                       // (uniform over the work-group)
+        const std::integral_constant<int, 0> S0;
+        const std::integral_constant<int, 1> S1;
+        fetchA(S0); stashA(S0, 0);
+        fetchA(S0); stashA(S0, 1);
+        fetchA(S0); stashA(S0, 2);
+        fetchG(S0); stashG(S0, 1);
+        fetchA(S1); fetchG(S1);                         // activation position 3, gradient position 2: written to LDS in step 1
+        fetchA(S0); fetchG(S0);                         // positions 4 and 3: step 2
+        __syncthreads();
+        const int S = nf * (H + 1) - 1;                 // steps 1 .. S; step s is an output row unless s % (H + 1) == 0
+        // Step s: write the rows fetched two steps ago (activation position s + 2 into the ring slot last read - as position
+        // s - 2 - in step s - 1, gradient position s + 1 into the buffer step s - 1 read), fetch positions s + 4 / s + 3 into the
+        // registers that held them, multiply.  Nothing a step writes is read before the barrier that ends it.  Positions past
+        // the end are zero rows (zero-sized descriptors: no memory traffic).
+        auto step = [&](auto SET, int s) {
+            stashA(SET, (s + 2) & 3);
+            stashG(SET, (s + 1) & 1);
+            fetchA(SET); fetchG(SET);
+            compute(s);         // (also on the idle step between two frames: its gradient row is a zero row, the products add nothing -
+                                //  and without a branch the step is one block in which the stores above interleave with the MFMAs)
+            __syncthreads();
+        };
+        for (int s = 1; s <= S; s += 2) {
+            step(S1, s);
+            if (s + 1 <= S) step(S0, s + 1);
+        }
+    }
+    const size_t slot = (size_t)fs * p.strips + strip;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+        const int tap = FMT ? 3 * kw + t : t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ct * CA + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+            float v = acc[t][r];
+            if constexpr (FMT) v = fmaf(cor[t][r], 1.0f / 2048.0f, v);
+            p.ws[((slot * 9 + tap) * p.cin + ci) * p.ncols + cgp * CG + wn * 32 + li] = v;
+        }
+    }
+}
+
 // bf16 TENSORS, cin and ncols multiples of 64: the same GEMM with DWORD loads.  A dword holds the channel pair (2l, 2l+1) of
 // one pixel, so the 10 (3x3: 8 pixels + halo) dwords a lane loads for a row feed TWO M-tiles - the tile's even channels from
 // the low halves, its odd channels from the high halves (one v_perm per packed pair) - and the 8 dwords of the gradient feed
@@ -2013,8 +2233,8 @@ int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const
 
 // debug / A-B: 0 = the bf16-tensor mode uses the one-channel-per-lane kernel everywhere, 1 = paired-channel kernel (dword loads
 // per wave) where cin and ncols are multiples of 64, 2 (default) = its LDS-staged work-group form where ncols is a multiple of 128
-static std::atomic<int> g_wgrad_x2{2};
-static std::atomic<int> g_wgrad_split{2};   // debug / A-B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3), 1 = the per-lane split-fp16 kernel, 2 = its LDS-staged form where it applies
+static std::atomic<int> g_wgrad_x2{3};     // 3 = the row-ring kernel for the 3x3 layers it takes (round 4)
+static std::atomic<int> g_wgrad_split{3};   // debug / A-B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3), 1 = the per-lane split-fp16 kernel, 2 = its LDS-staged form where it applies
 extern "C" int vad_debug_set_wgrad_pairs(int on) { g_wgrad_x2 = on; return VAD_OK; }
 extern "C" int vad_debug_set_wgrad_split(int on) { g_wgrad_split = on; return VAD_OK; }
 
@@ -2044,6 +2264,36 @@ static int wgrad_split_lds_splits(long long tiles, int total_rows) {
 // kernel - 102 / 206 / 231 us against 78 / 164 / 219 us on the decoder's three)
 static bool wgrad_split_lds_ok(int taps, int w, int cin, int ncols) { return taps == 9 && ncols % 64 == 0 && (cin % 64 == 0 || (cin == 32 && w > 16)); }
 
+// Row-ring kernel: tile shape and the frames each work-group walks.  One work-group = WM x WN (x 3, split-fp16) waves; the chip holds
+// `cap` of them at once; frames per item are chosen so that the launch is as few FULL rounds of that as possible, never more
+// partial slots than 128 MB of fp32 (what vad_conv_wgrad_ws_floats, which does not know the map width, reserves).
+static long long ring_max_slots(int cin, int ncols) { const long long s = (128ll << 20) / 4 / (9ll * cin * ncols); return s < 1 ? 1 : s; }
+struct RingPlan { bool ok; int wm, wn, gp, strips, fps, fsplits, ci_tiles, col_groups; };
+static RingPlan ring_plan(int fmt, int n, int h, int w, int cin, int ncols) {
+    RingPlan r{};
+    r.ok = ncols % 64 == 0 && (cin % 64 == 0 || cin == 32) && n > 0 && h > 0 && w > 0;
+    if (!r.ok) return r;
+    r.wm = cin % 64 == 0 ? 2 : 1;
+    r.wn = (fmt == 0 && ncols % 128 == 0) ? 4 : 2;
+    r.gp = w <= 16 ? 16 : 32;
+    r.strips = (w + r.gp - 1) / r.gp;
+    r.ci_tiles = cin / (32 * r.wm); r.col_groups = ncols / (32 * r.wn);
+    const int waves = r.wm * r.wn * (fmt ? 3 : 1), per_cu = (fmt ? 12 : 8) / waves;
+    const long long cap = 256ll * (per_cu > 0 ? per_cu : 1);
+    const long long tiles = (long long)r.ci_tiles * r.col_groups * r.strips;
+    const long long max_slots = ring_max_slots(cin, ncols);                  // partial slots = fsplits * strips
+    if (r.strips > max_slots) { r.ok = false; return r; }
+    long long best = -1;
+    for (int fps = 1; fps <= n; ++fps) {
+        const long long fsplits = (n + fps - 1) / fps;
+        if (fsplits * r.strips > max_slots) continue;
+        const long long rounds = (tiles * fsplits + cap - 1) / cap;
+        const long long cost = rounds * ((long long)fps * (h + 1) + 4);        // steps per item + the prologue
+        if (best < 0 || cost < best) { best = cost; r.fps = fps; r.fsplits = (int)fsplits; }
+    }
+    return r;
+}
+
 extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int ncols) {
     if (n <= 0 || h <= 0 || cin <= 0 || ncols <= 0 || cin % 32 || ncols % 32 || (taps != 9 && taps != 1)) return 0;
     const int nt = (taps == 1 && ncols % 128 == 0) ? 4 : 1;
@@ -2060,6 +2310,10 @@ extern "C" size_t vad_conv_wgrad_ws_floats(int n, int h, int taps, int cin, int 
             if (s3 > 2048) s3 = 2048;
             if (s3 * ps > splits) splits = (int)(s3 * ps);
         }
+    }
+    if (taps == 9 && ncols % 64 == 0 && (cin % 64 == 0 || cin == 32)) {      // the row-ring kernels: up to ring_max_slots partial slots
+        const long long s5 = ring_max_slots(cin, ncols);
+        if (s5 > splits) splits = (int)s5;
     }
     if (taps == 9 && ncols % 64 == 0 && (cin % 64 == 0 || cin == 32)) {      // the LDS-staged split-fp16 kernel (any map width: upper bound)
         const int wm = cin % 64 == 0 ? 2 : 1, ps = wm == 1 ? 2 : 1;
@@ -2084,6 +2338,35 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     // 192 accumulators + staging registers spill: 0.85 ms against 0.38 ms of the per-wave kernel on enc.8), 1x1 / transposed
     // layers with 64- or 128-channel tiles
     const bool lds_ok = ncols % 128 == 0 && (taps == 9 ? (cin % 128 == 0 || (cin % 64 == 0 && w > 16)) : cin % 64 == 0);
+    {   // row-ring kernels (3x3 layers; bf16 tensors and split-fp16)
+        const bool ring16 = precision == VAD_PREC_BF16S && g_wgrad_x2.load(std::memory_order_relaxed) >= 3;
+        const bool ring32 = precision == VAD_PREC_SPLIT && g_wgrad_split.load(std::memory_order_relaxed) >= 3;
+        const RingPlan rp = (taps == 9 && (ring16 || ring32)) ? ring_plan(ring32 ? 1 : 0, n, h, w, cin, ncols) : RingPlan{};
+        if (rp.ok) {
+            WgradRingP q{};
+            q.a = a; q.g = g; q.ws = ws; q.n = n; q.h = h; q.w = w; q.cin = cin; q.ncols = ncols;
+            q.ci_tiles = rp.ci_tiles; q.col_groups = rp.col_groups; q.strips = rp.strips; q.frames_per_split = rp.fps;
+            const long long slots = (long long)rp.fsplits * rp.strips;
+            const long long items5 = (long long)rp.ci_tiles * rp.col_groups * slots;
+            VAD_REQUIRE(items5 < (1ll << 31), "conv_wgrad: too many work items");
+            VAD_REQUIRE((size_t)slots * 9 * cin * ncols <= vad_conv_wgrad_ws_floats(n, h, taps, cin, ncols),
+                        "conv_wgrad: internal error: %lld partial slots exceed the size vad_conv_wgrad_ws_floats reports", slots);
+            hipStream_t s5 = (hipStream_t)stream;
+            const dim3 g5((unsigned)items5);
+#define WRL(F_, WM_, WN_, GP_) hipLaunchKernelGGL((conv_wgrad_ring_kernel<F_, WM_, WN_, GP_>), g5, dim3(64 * WM_ * WN_ * (F_ ? 3 : 1)), 0, s5, q)
+#define WRL_GP(F_, WM_, WN_) do { if (rp.gp == 16) WRL(F_, WM_, WN_, 16); else WRL(F_, WM_, WN_, 32); } while (0)
+            if (ring32) { if (rp.wm == 2) WRL_GP(1, 2, 2); else WRL_GP(1, 1, 2); }
+            else if (rp.wm == 2) { if (rp.wn == 4) WRL_GP(0, 2, 4); else WRL_GP(0, 2, 2); }
+            else { if (rp.wn == 4) WRL_GP(0, 1, 4); else WRL_GP(0, 1, 2); }
+#undef WRL_GP
+#undef WRL
+            VAD_LAUNCH_CHECK();
+            const long long total5 = 9ll * cin * ncols;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total5 + 63) / 64)), dim3(256), 0, s5, (const float*)ws, (int)slots, taps, cin, ncols, layout, dw);
+            VAD_LAUNCH_CHECK();
+            return VAD_OK;
+        }
+    }
     if (precision == VAD_PREC_BF16S && lds_ok && g_wgrad_x2.load(std::memory_order_relaxed) >= 2) {
         const int npass = taps == 9 ? 3 : 1, wm = cin % 128 == 0 ? 2 : 1;
         const int ps = (taps == 9 && wm == 1) ? 2 : 1;               // 3x3 with 64-channel tiles: pixel halves (see the kernel)
