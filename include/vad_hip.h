@@ -356,10 +356,12 @@ size_t vad_vid_train_workspace_bytes(int b, int t, int h, int w, int latent, int
 int vad_debug_set_train_decisions(void* buf, size_t bytes);
 size_t vad_debug_train_decisions_used(void);
 /* A/B: 0 = the weight gradients of the bf16-tensor mode use the one-channel-per-lane kernel everywhere; 1 = the paired-channel
- * kernel (dword loads, 64 x 64 wave tiles) where cin and ncols are multiples of 64; 2 (default) = its LDS-staged work-group
- * form where ncols is a multiple of 128. */
+ * kernel (dword loads, 64 x 64 wave tiles) where cin and ncols are multiples of 64; 2 = its LDS-staged work-group
+ * form where ncols is a multiple of 128; 3 (default) = the row-ring kernel for the 3x3 layers with ncols % 64 == 0 and cin % 64 == 0
+ * or cin == 32 (every operand row staged once per work-group, csrc/train_ops.hip), 2 elsewhere. */
 int vad_debug_set_wgrad_pairs(int on);
-/* A/B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3); 1 (default) = the split-fp16 kernel. */
+/* A/B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3); 1 = the per-lane split-fp16 kernel; 2 = its
+ * LDS-staged form for the 3x3 layers it takes; 3 (default) = the row-ring kernel for those layers. */
 int vad_debug_set_wgrad_split(int on);
 /* 1 (default): the BatchNorm forward / backward-apply passes on bf16 tensors take eight channels per thread (16-byte accesses);
  * 0: four, like the fp32 form.  Identical results (every element goes through the same expressions). */
