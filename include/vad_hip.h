@@ -363,6 +363,8 @@ int vad_debug_set_wgrad_pairs(int on);
 /* A/B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3); 1 = the per-lane split-fp16 kernel; 2 = its
  * LDS-staged form for the 3x3 layers it takes; 3 (default) = the row-ring kernel for those layers. */
 int vad_debug_set_wgrad_split(int on);
+/* A/B: 0 = exact-fp32 3x3 weight gradients on the per-wave kernel (rounds 1-3); 1 (default) = the row-ring kernel where it applies. */
+int vad_debug_set_wgrad_ring_f32(int on);
 /* 1 (default): the BatchNorm forward / backward-apply passes on bf16 tensors take eight channels per thread (16-byte accesses);
  * 0: four, like the fp32 form.  Identical results (every element goes through the same expressions). */
 int vad_debug_set_bn_wide(int on);

@@ -263,6 +263,18 @@ def test_split_weight_gradient_kernel_forms(vad, n, h, w, cin, ncols, taps):
     _close(out[1], out[0], 2e-6, "per-lane split kernel")
     _close(out[2], out[0], 2e-6, "LDS-staged split kernel")
     _close(out[3], out[0], 2e-6, "row-ring split kernel (3x3 layers; else the LDS-staged one again)")
+    # exact fp32 (precision 0): the row-ring kernel (default for the 3x3 layers it takes) against the per-wave kernel - the same
+    # products, fp32 sums in another order
+    dwr = torch.full(shape, float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv_wgrad(a.data_ptr(), g.data_ptr(), dwr.data_ptr(), ws.data_ptr(), n, h, w, cin, ncols, taps, layout, 0, H.stream()))
+    l.vad_debug_set_wgrad_ring_f32(0)
+    try:
+        dwp = torch.full(shape, float("nan"), device="cuda")
+        vad.hip.check(l.vad_conv_wgrad(a.data_ptr(), g.data_ptr(), dwp.data_ptr(), ws.data_ptr(), n, h, w, cin, ncols, taps, layout, 0, H.stream()))
+    finally:
+        l.vad_debug_set_wgrad_ring_f32(1)
+    assert torch.equal(dwp.cpu(), torch.from_numpy(out[0]))
+    _close(dwr.cpu().numpy(), out[0], 2e-6, "exact row-ring kernel")
 
 
 def _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision):

@@ -23,11 +23,11 @@ for name, n, h, w, cin, ncols, taps, layout in shapes:
     flops = 2.0 * taps * cin * ncols * n * h * w
     line = [f"{name:7s} {flops / 1e9:6.1f} GF"]
     a16, g16 = a.to(torch.bfloat16), g.to(torch.bfloat16)
-    for label, prec, split_mode, pairs_mode in (("fp32", 0, 3, 3), ("split/1", 1, 1, 3), ("split/2", 1, 2, 3), ("split/3", 1, 3, 3), ("bf16op", 2, 3, 3),
+    for label, prec, split_mode, pairs_mode in (("fp32/0", 0, 3, 3), ("fp32", 0, 3, 3), ("split/1", 1, 1, 3), ("split/2", 1, 2, 3), ("split/3", 1, 3, 3), ("bf16op", 2, 3, 3),
                                                 ("bf16t/1", 3, 3, 1), ("bf16t/2", 3, 3, 2), ("bf16t/3", 3, 3, 3)):
         if FORMS and label not in FORMS.split(","):
             continue
-        l.vad_debug_set_wgrad_split(split_mode); l.vad_debug_set_wgrad_pairs(pairs_mode)
+        l.vad_debug_set_wgrad_split(split_mode); l.vad_debug_set_wgrad_pairs(pairs_mode); l.vad_debug_set_wgrad_ring_f32(0 if label == "fp32/0" else 1)
         pa, pg = (a16, g16) if prec == 3 else (a, g)
         call = lambda: l.vad_conv_wgrad(pa.data_ptr(), pg.data_ptr(), dw.data_ptr(), ws.data_ptr(), n, h, w, cin, ncols, taps, layout, prec, s)
         for _ in range(3):

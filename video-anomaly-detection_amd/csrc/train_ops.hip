@@ -1108,6 +1108,7 @@ __global__ __launch_bounds__(64 * WM * WN * PS, 3) void conv_wgrad_split_lds_ker
 // FMT 0: bf16 tensors, v_mfma_f32_32x32x16_bf16, a wave holds the nine taps of its 32 x 32 tile (144 accumulator registers).
 // FMT 1: fp32 tensors in split-fp16 arithmetic (hi / lo planes, three MFMAs per product): two accumulator sets per tap, so the
 // three kernel rows of a tile go to three wave groups (96 registers each) that share the staged rows.
+// FMT 2: fp32 tensors in exact fp32 (v_mfma_f32_32x32x2_f32): the bf16 form's tiling with fp32 planes and 16-pixel strips.
 struct WgradRingP {
     const void* a; const void* g; float* ws;
     int n, h, w, cin, ncols;
@@ -1115,18 +1116,21 @@ struct WgradRingP {
 };
 
 template <int FMT, int WM, int WN, int GP>
-__global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void conv_wgrad_ring_kernel(WgradRingP p) {
+__global__ __launch_bounds__(64 * WM * WN * (FMT == 1 ? 3 : 1), FMT == 1 ? 3 : 2) void conv_wgrad_ring_kernel(WgradRingP p) {
     static_assert(GP == 16 || GP == 32, "strips of 16 or 32 pixels");
-    constexpr int ES = FMT ? 4 : 2, CPL = 16 / ES;                   // element bytes, channels per 16-byte load
-    constexpr int NKW = FMT ? 3 : 1, KRW = 3 / NKW;                  // wave groups over kernel rows, kernel rows per wave
+    constexpr bool SPLIT = FMT == 1, F32 = FMT == 2;
+    static_assert(!F32 || GP == 16, "exact fp32: 16-pixel strips (the planes of 32 would not fit 64 KB of LDS)");
+    constexpr int ES = FMT ? 4 : 2, CPL = 16 / ES;                   // element bytes in memory, channels per 16-byte load
+    constexpr int EB = F32 ? 4 : 2;                                  // element bytes in LDS
+    constexpr int NKW = SPLIT ? 3 : 1, KRW = 3 / NKW;                // wave groups over kernel rows, kernel rows per wave
     constexpr int NTH = 64 * WM * WN * NKW;
     constexpr int CA = 32 * WM, CG = 32 * WN;
     constexpr int NEA = GP + 2, PAIRS_A = NEA / 2, PAIRS_G = GP / 2;
-    constexpr int PITCH = GP == 32 ? 80 : 48;                        // bytes per [channel] row (16-byte multiple; b128 reads of 16 lanes cover all banks)
+    constexpr int PITCH = (GP == 32 || F32) ? 80 : 48;               // bytes per [channel] row >= EB (GP + 2) (16-byte multiple; b128 reads of 16 lanes cover all banks)
     constexpr int NCA = CA / CPL, NCG = CG / CPL;
     constexpr int UA = PAIRS_A * NCA, UG = PAIRS_G * NCG;
     constexpr int JA = (UA + NTH - 1) / NTH, JG = (UG + NTH - 1) / NTH;
-    constexpr int NPL = FMT ? 2 : 1;                                 // planes: hi, lo
+    constexpr int NPL = SPLIT ? 2 : 1;                               // planes: hi, lo
     constexpr int PLANE_A = CA * PITCH, PLANE_G = CG * PITCH;
     constexpr int SLOT_A = NPL * PLANE_A, BUF_G = NPL * PLANE_G;
     constexpr int DUMP = 4 * SLOT_A + 2 * BUF_G;                     // where threads without a staging unit store (no branch in the step)
@@ -1144,11 +1148,11 @@ __global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void con
     const unsigned pix_a = (unsigned)p.cin * ES, pix_g = (unsigned)p.ncols * ES;
     const unsigned a_bytes = (unsigned)(H * W) * pix_a, g_bytes = (unsigned)(H * W) * pix_g;
     constexpr int NACC = 3 * KRW;
-    f32x16 acc[NACC], cor[FMT ? NACC : 1];
+    f32x16 acc[NACC], cor[SPLIT ? NACC : 1];
 #pragma unroll
     for (int t = 0; t < NACC; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if constexpr (FMT) cor[t][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; if constexpr (SPLIT) cor[t][r] = 0.f; }
 
     // Staging units (unit u = tid + NTH j), invariants as in the kernel above - but PIXEL PAIR fastest (pr = u % PAIRS, channel chunk
     // c = u / PAIRS): a unit's ds_write_b32 go CPL rows apart, and rows CPL apart share their banks whatever the (16-byte
@@ -1164,14 +1168,14 @@ __global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void con
         const int u = tid + NTH * j, pr = (u / 4) % PAIRS_A, c = (u / (4 * PAIRS_A)) * 4 + (u & 3);
         voa[j] = (unsigned)(2 * pr) * pix_a + (unsigned)c * 16u;
         ea[j] = u < UA ? 2 * pr - 1 + lx : (1 << 30);                // pixel of the pair's first element (no such unit: never in range)
-        wa[j] = (CPL * c) * PITCH + 4 * pr;
+        wa[j] = (CPL * c) * PITCH + 2 * EB * pr;
     }
 #pragma unroll
     for (int j = 0; j < JG; ++j) {
         const int u = tid + NTH * j, pr = (u / 4) % PAIRS_G, c = (u / (4 * PAIRS_G)) * 4 + (u & 3);
         vog[j] = (unsigned)(2 * pr) * pix_g + (unsigned)c * 16u;
         eg[j] = u < UG ? 2 * pr + lx : (1 << 30);
-        wgo[j] = 4 * SLOT_A + (CPL * c) * PITCH + 4 * pr;
+        wgo[j] = 4 * SLOT_A + (CPL * c) * PITCH + 2 * EB * pr;
     }
     // The stream of activation rows: position q = f (H + 1) + r is the zero row for r = 0 and row r - 1 of frame f0 + f otherwise
     // (position nf (H + 1) is the zero row that closes the last frame).  Output rows sit at the positions with r >= 1.
@@ -1211,6 +1215,9 @@ __global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void con
                 *(unsigned*)(dst + (2 * k) * PITCH) = __builtin_amdgcn_perm(p1[k], p0[k], 0x05040100u);       // low halves: channel 2k
                 *(unsigned*)(dst + (2 * k + 1) * PITCH) = __builtin_amdgcn_perm(p1[k], p0[k], 0x07060302u);   // high halves: channel 2k + 1
             }
+        } else if constexpr (F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *(u32x2*)(dst + e * PITCH) = u32x2{p0[e], p1[e]};
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1235,15 +1242,37 @@ __global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void con
     };
     auto compute = [&](int s) {
         const unsigned char* G = lds + 4 * SLOT_A + (s & 1) * BUF_G + (wn * 32 + li) * PITCH;
+        if constexpr (F32) {
+            // exact fp32 (v_mfma_f32_32x32x2_f32, K = 2 pixels): k-step j of an 8-pixel group pairs pixel j (lanes 0-31) with pixel
+            // 4 + j (lanes 32-63), so each half reads ITS four pixels (+ 2 of halo) as one ds_read_b128 + one ds_read_b64 and the
+            // operand of (j, dx) is register j + dx of that window: no VALU work beside the MFMAs on the pipe they share.
+#pragma unroll
+            for (int grp = 0; grp < GP / 8; ++grp) {
+                const int off = 4 * (8 * grp + 4 * kb);
+                const f32x4 g4 = *(const f32x4*)(G + off);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned char* A = lds + ((s - 1 + k) & 3) * SLOT_A + (wm * 32 + li) * PITCH + off;
+                    const f32x4 a4 = *(const f32x4*)A;
+                    const f32x2 a2 = *(const f32x2*)(A + 16);
+                    const float av[6] = {a4[0], a4[1], a4[2], a4[3], a2[0], a2[1]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+                            acc[3 * k + d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + d], g4[j], acc[3 * k + d], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int sub = 0; sub < GP / 16; ++sub) {
             const int off = 2 * (16 * sub + 8 * kb);                       // byte offset of element px0 (pixel lx + px0 - 1)
             const u32x4 gh4 = *(const u32x4*)(G + off);
             u32x4 gl4 = gh4;
-            if constexpr (FMT) gl4 = *(const u32x4*)(G + PLANE_G + off);
+            if constexpr (SPLIT) gl4 = *(const u32x4*)(G + PLANE_G + off);
 #pragma unroll
             for (int k = 0; k < KRW; ++k) {
-                const int kr = FMT ? kw : k;                               // kernel row: activation row (output row - 1 + kr)
+                const int kr = SPLIT ? kw : k;                             // kernel row: activation row (output row - 1 + kr)
                 const unsigned char* A = lds + ((s - 1 + kr) & 3) * SLOT_A + (wm * 32 + li) * PITCH + off;
                 const u32x4 ah4 = *(const u32x4*)A;
                 const unsigned ah5 = (*(const u32x2*)(A + 16))[0];            // (as 8 bytes: a ds_read_b32 of this column is a 4-way bank conflict on 80-byte rows)
@@ -1271,6 +1300,7 @@ __global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void con
                     for (int d = 0; d < 3; ++d) cor[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[d], gh, cor[d], 0, 0, 0);
                 }
             }
+        }
         }
     };
     if (nf > 0) {                                       // (uniform over the work-group)
@@ -1304,12 +1334,12 @@ __global__ __launch_bounds__(64 * WM * WN * (FMT ? 3 : 1), FMT ? 3 : 2) void con
     const size_t slot = (size_t)fs * p.strips + strip;
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
-        const int tap = FMT ? 3 * kw + t : t;
+        const int tap = SPLIT ? 3 * kw + t : t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ct * CA + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
             float v = acc[t][r];
-            if constexpr (FMT) v = fmaf(cor[t][r], 1.0f / 2048.0f, v);
+            if constexpr (SPLIT) v = fmaf(cor[t][r], 1.0f / 2048.0f, v);
             p.ws[((slot * 9 + tap) * p.cin + ci) * p.ncols + cgp * CG + wn * 32 + li] = v;
         }
     }
@@ -2237,6 +2267,8 @@ static std::atomic<int> g_wgrad_x2{3};     // 3 = the row-ring kernel for the 3x
 static std::atomic<int> g_wgrad_split{3};   // debug / A-B: 0 = VAD_PREC_SPLIT weight gradients on the exact-fp32 kernel (rounds 2-3), 1 = the per-lane split-fp16 kernel, 2 = its LDS-staged form where it applies
 extern "C" int vad_debug_set_wgrad_pairs(int on) { g_wgrad_x2 = on; return VAD_OK; }
 extern "C" int vad_debug_set_wgrad_split(int on) { g_wgrad_split = on; return VAD_OK; }
+static std::atomic<int> g_wgrad_ring_f32{1};   // debug / A-B: 0 = exact-fp32 3x3 weight gradients on the per-wave kernel (rounds 1-3)
+extern "C" int vad_debug_set_wgrad_ring_f32(int on) { g_wgrad_ring_f32 = on != 0; return VAD_OK; }
 
 // split-K factor: enough waves to fill the chip (~4096), never more splits than image rows.  Measured on both training
 // steps (32 clips / 128 images): a 2048-wave target is within noise of 4096 (35.8 vs 35.6-36.0 ms, 38.5 vs 39.0 ms), 1024
@@ -2274,11 +2306,11 @@ static RingPlan ring_plan(int fmt, int n, int h, int w, int cin, int ncols) {
     r.ok = ncols % 64 == 0 && (cin % 64 == 0 || cin == 32) && n > 0 && h > 0 && w > 0;
     if (!r.ok) return r;
     r.wm = cin % 64 == 0 ? 2 : 1;
-    r.wn = (fmt == 0 && ncols % 128 == 0) ? 4 : 2;
-    r.gp = w <= 16 ? 16 : 32;
+    r.wn = (fmt != 1 && ncols % 128 == 0) ? 4 : 2;
+    r.gp = (w <= 16 || fmt == 2) ? 16 : 32;
     r.strips = (w + r.gp - 1) / r.gp;
     r.ci_tiles = cin / (32 * r.wm); r.col_groups = ncols / (32 * r.wn);
-    const int waves = r.wm * r.wn * (fmt ? 3 : 1), per_cu = (fmt ? 12 : 8) / waves;
+    const int waves = r.wm * r.wn * (fmt == 1 ? 3 : 1), per_cu = (fmt == 1 ? 12 : 8) / waves;
     const long long cap = 256ll * (per_cu > 0 ? per_cu : 1);
     const long long tiles = (long long)r.ci_tiles * r.col_groups * r.strips;
     const long long max_slots = ring_max_slots(cin, ncols);                  // partial slots = fsplits * strips
@@ -2341,7 +2373,8 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     {   // row-ring kernels (3x3 layers; bf16 tensors and split-fp16)
         const bool ring16 = precision == VAD_PREC_BF16S && g_wgrad_x2.load(std::memory_order_relaxed) >= 3;
         const bool ring32 = precision == VAD_PREC_SPLIT && g_wgrad_split.load(std::memory_order_relaxed) >= 3;
-        const RingPlan rp = (taps == 9 && (ring16 || ring32)) ? ring_plan(ring32 ? 1 : 0, n, h, w, cin, ncols) : RingPlan{};
+        const bool ringf = precision == VAD_PREC_FP32 && g_wgrad_ring_f32.load(std::memory_order_relaxed);
+        const RingPlan rp = (taps == 9 && (ring16 || ring32 || ringf)) ? ring_plan(ring32 ? 1 : ringf ? 2 : 0, n, h, w, cin, ncols) : RingPlan{};
         if (rp.ok) {
             WgradRingP q{};
             q.a = a; q.g = g; q.ws = ws; q.n = n; q.h = h; q.w = w; q.cin = cin; q.ncols = ncols;
@@ -2353,9 +2386,13 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
                         "conv_wgrad: internal error: %lld partial slots exceed the size vad_conv_wgrad_ws_floats reports", slots);
             hipStream_t s5 = (hipStream_t)stream;
             const dim3 g5((unsigned)items5);
-#define WRL(F_, WM_, WN_, GP_) hipLaunchKernelGGL((conv_wgrad_ring_kernel<F_, WM_, WN_, GP_>), g5, dim3(64 * WM_ * WN_ * (F_ ? 3 : 1)), 0, s5, q)
+#define WRL(F_, WM_, WN_, GP_) hipLaunchKernelGGL((conv_wgrad_ring_kernel<F_, WM_, WN_, GP_>), g5, dim3(64 * WM_ * WN_ * (F_ == 1 ? 3 : 1)), 0, s5, q)
 #define WRL_GP(F_, WM_, WN_) do { if (rp.gp == 16) WRL(F_, WM_, WN_, 16); else WRL(F_, WM_, WN_, 32); } while (0)
-            if (ring32) { if (rp.wm == 2) WRL_GP(1, 2, 2); else WRL_GP(1, 1, 2); }
+            if (ringf) {
+                if (rp.wm == 2) { if (rp.wn == 4) WRL(2, 2, 4, 16); else WRL(2, 2, 2, 16); }
+                else { if (rp.wn == 4) WRL(2, 1, 4, 16); else WRL(2, 1, 2, 16); }
+            }
+            else if (ring32) { if (rp.wm == 2) WRL_GP(1, 2, 2); else WRL_GP(1, 1, 2); }
             else if (rp.wm == 2) { if (rp.wn == 4) WRL_GP(0, 2, 4); else WRL_GP(0, 2, 2); }
             else { if (rp.wn == 4) WRL_GP(0, 1, 4); else WRL_GP(0, 1, 2); }
 #undef WRL_GP

@@ -169,6 +169,7 @@ SIGNATURES = {
     "vad_conv3x3_c3_bf16op": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_debug_set_wgrad_pairs": (_i, [_i]),
     "vad_debug_set_wgrad_split": (_i, [_i]),
+    "vad_debug_set_wgrad_ring_f32": (_i, [_i]),
     "vad_debug_set_bn_wide": (_i, [_i]),
     "vad_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "vad_train_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
