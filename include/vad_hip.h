@@ -486,6 +486,33 @@ int vad_vid_score_windows(const float* frames, long long nframes, int t, int str
                           int layers, const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_windows,
                           float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
 
+/* Models with in_channels > 3 (round 4).  ConvAutoencoder(in_channels=...) / VideoAutoencoder(in_channels=...) take any width
+ * (models/autoencoder.py:161, models/video_autoencoder.py:290-296; every reference call site passes 3: evaluate.py:35,
+ * evaluate_video.py:99-104).  The `_c` forms below take in_ch in [3, VAD_MAX_IN_CHANNELS]; with in_ch == 3 they ARE the forms
+ * above.  A wider model runs its first and last layer on the generic kernels over planes zero-padded to 32 channels
+ * (csrc/wide_io.hip: one NCHW -> padded-NHWC copy on the way in, Tanh + squared error on the way out); blobs come from
+ * vad_img_pack(..., in_ch, ...) / vad_vid_pack_c, inputs are float NCHW [.., in_ch, H, W] (uint8 frames are 3-channel
+ * images), recon comes back with in_ch planes, scores and error maps average over in_ch planes.  1- and 2-channel models: pack
+ * and score them as 3-channel models with zero weights on the extra planes (what the Python layer does). */
+#define VAD_MAX_IN_CHANNELS 32
+size_t vad_img_workspace_bytes_c(int chunk, int h, int w, int latent, int in_ch);
+int vad_img_score_c(const void* x, int x_format, int precision, int in_ch, long long b, int h, int w, int latent,
+                    const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk, float* scores, float* errmap,
+                    float* recon_nchw, float* latent_nchw, void* stream);
+size_t vad_vid_packed_floats_c(int in_ch, int latent, int hid, int layers);
+int vad_vid_pack_c(const float* const* params, int nparams, int in_ch, int latent, int hid, int layers, int precision,
+                   float* packed_host);
+size_t vad_vid_workspace_bytes_c(int chunk_clips, int t, int h, int w, int latent, int hid, int layers, int in_ch);
+int vad_vid_score_c(const void* x, int x_format, int precision, int in_ch, long long b, int t, int h, int w, int latent, int hid,
+                    int layers, const float* packed_dev, void* workspace, size_t workspace_bytes, int chunk_clips,
+                    float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream);
+size_t vad_vid_windows_workspace_bytes_c(int chunk_windows, int t, int stride, int h, int w, int latent, int hid, int layers,
+                                         int in_ch);
+int vad_vid_score_windows_c(const void* frames, int x_format, int precision, int in_ch, long long nframes, int t, int stride,
+                            int h, int w, int latent, int hid, int layers, const float* packed_dev, void* workspace,
+                            size_t workspace_bytes, int chunk_windows, float* seq_scores, float* frame_scores, float* errmap,
+                            float* recon, void* stream);
+
 /* ------------------------------------------------------------------ hipGraph capture / replay of a scoring call
  * vad_graph_begin(stream); <one vad_img_score* / vad_vid_score* call on `stream`>; vad_graph_end(stream, &exec) captures
  * the call's launch sequence (kernels, and the fork / join with the library's helper streams) into an instantiated

@@ -46,9 +46,9 @@ def load_synthetic(vad_pkg, module, seed):
     return st
 
 
-IMG_GOLDENS = ["img_l32_32.npz", "img_l256_64.npz", "img_l100_32.npz", "img_c1_l24_32.npz"]
+IMG_GOLDENS = ["img_l32_32.npz", "img_l256_64.npz", "img_l100_32.npz", "img_c1_l24_32.npz", "img_c5_l32_32.npz"]
 VID_GOLDENS = ["vid_default_64.npz", "vid_proj_32.npz", "vid_l3_32.npz", "vid_l48_h96_32.npz", "vid_l100_32.npz",
-               "vid_c2_l32_h40_32.npz"]
+               "vid_c2_l32_h40_32.npz", "vid_c4_l32_32.npz"]
 
 
 def in_channels_of(g) -> int:

@@ -324,6 +324,9 @@ FIXTURES = {
     # the reference takes any positive width (models/autoencoder.py:161, models/video_autoencoder.py:290-296)
     "img_l100_32.npz": lambda n: image_fixture(n, latent=100, wseed=14, xseed=104, n=2, hw=32),
     "img_c1_l24_32.npz": lambda n: image_fixture(n, latent=24, wseed=15, xseed=105, n=2, hw=32, in_ch=1),
+    # more than 3 planes (round 4: the library's generic first / last layers, csrc/wide_io.hip)
+    "img_c5_l32_32.npz": lambda n: image_fixture(n, latent=32, wseed=16, xseed=106, n=3, hw=32, in_ch=5),
+    "vid_c4_l32_32.npz": lambda n: video_fixture(n, latent=32, hid=32, layers=2, wseed=28, xseed=208, b=2, t=3, hw=32, in_ch=4),
     "vid_l48_h96_32.npz": lambda n: video_fixture(n, latent=48, hid=96, layers=2, wseed=25, xseed=205, b=2, t=3, hw=32),
     "vid_l100_32.npz": lambda n: video_fixture(n, latent=100, hid=100, layers=1, wseed=26, xseed=206, b=1, t=3, hw=32),
     "vid_c2_l32_h40_32.npz": lambda n: video_fixture(n, latent=32, hid=40, layers=1, wseed=27, xseed=207, b=1, t=2, hw=32, in_ch=2),

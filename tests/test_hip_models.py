@@ -591,6 +591,89 @@ def test_captured_graph_replays_bit_identically(vad):
     torch.cuda.synchronize()
 
 
+def test_wide_channel_models_all_entry_points_and_modes(vad, golden):
+    """Models with MORE than 3 planes (round 4; csrc/wide_io.hip): the reference's own scores / reconstructions for a 5-channel
+    image model and a 4-channel video model (tests/golden/make_golden.py) through the eager call, hipGraph capture / replay,
+    `get_latent`, chunking, the opt-in arithmetic modes and dense windows."""
+    g = golden("img_c5_l32_32.npz")
+    cin = in_channels_of(g)
+    assert cin == 5
+    mi, sti = _img_model(vad, int(g["latent_dim"]), int(g["wseed"]), cin)
+    n, hw = int(g["n"]), int(g["hw"])
+    xa = torch.from_numpy(vad.synth.frames(int(g["xseed"]), 0, n, cin, hw, hw)).cuda()
+    xb = torch.from_numpy(vad.synth.frames(int(g["xseed"]) + 1, 0, n, cin, hw, hw)).cuda()
+    with torch.no_grad():
+        ea, eb = mi.score_all(xa), mi.score_all(xb)
+        assert ea["recon"].shape == xa.shape and ea["errmap"].shape == (n, 1, hw, hw)
+        assert rel_err(ea["scores"].cpu().numpy(), g["scores"]) < SCORE_RTOL
+        assert max_abs(ea["recon"].cpu().numpy(), g["recon"]) < ACT_ATOL
+        assert max_abs(mi.get_latent(xa).cpu().numpy(), g["latent"]) < 2e-4
+        assert torch.equal(mi(xa), ea["recon"]) and torch.equal(mi.get_reconstruction_error(xa), ea["scores"])
+        assert torch.equal(mi.get_reconstruction_error(xa, per_pixel=True), ea["errmap"])
+        mi.chunk = 2                                                          # chunking never changes a bit
+        assert torch.equal(mi.get_reconstruction_error(xa), ea["scores"])
+        mi.chunk = 128
+        cap = mi.capture(xa, scores=True, errmap=True, recon=True, latent=True)
+        for _ in range(2):
+            ob = cap.replay(xb)
+            for k in ("scores", "errmap", "recon"):
+                assert torch.equal(ob[k], eb[k]), k
+        for mode in ("split", "winograd"):
+            mi.precision = mode
+            assert rel_err(mi.get_reconstruction_error(xa).cpu().numpy(), g["scores"]) < SCORE_RTOL, mode
+        mi.precision = "fp32"
+        with pytest.raises(vad.hip.VadError, match="uint8 .* needs in_channels == 3"):
+            mi.get_reconstruction_error(torch.zeros(n, hw, hw, cin, dtype=torch.uint8).cuda())
+    # a frame size and a batch the golden does not have, against the CPU oracle
+    xo = vad.synth.frames(991, 0, 3, cin, 48, 80)
+    ref = torch_oracle.img_scores({k: torch.from_numpy(np.asarray(v)) for k, v in sti.items()}, torch.from_numpy(xo))
+    with torch.no_grad():
+        assert rel_err(mi.get_reconstruction_error(torch.from_numpy(xo).cuda()).cpu().numpy(), ref["scores"].numpy()) < SCORE_RTOL
+
+    gv = golden("vid_c4_l32_32.npz")
+    cv = in_channels_of(gv)
+    assert cv == 4
+    mv, stv = _vid_model(vad, int(gv["latent_dim"]), int(gv["hid"]), int(gv["layers"]), int(gv["wseed"]), cv)
+    b, t, hw = int(gv["b"]), int(gv["t"]), int(gv["hw"])
+    ca = torch.from_numpy(vad.synth.clips(int(gv["xseed"]), 0, b, t, cv, hw, hw)).cuda()
+    cb = torch.from_numpy(vad.synth.clips(int(gv["xseed"]) + 1, 0, b, t, cv, hw, hw)).cuda()
+    with torch.no_grad():
+        wa, wb = mv.score_all(ca), mv.score_all(cb)
+        assert wa["recon"].shape == ca.shape
+        assert rel_err(wa["frame"].cpu().numpy(), gv["frame"]) < SCORE_RTOL and rel_err(wa["seq"].cpu().numpy(), gv["seq"]) < SCORE_RTOL
+        assert max_abs(wa["recon"].cpu().numpy(), gv["recon"]) < ACT_ATOL
+        mv.chunk = 1
+        assert torch.equal(mv.score_all(ca)["frame"], wa["frame"])
+        mv.chunk = 64
+        cap = mv.capture(ca, seq=True, frame=True, errmap=True, recon=True)
+        for _ in range(2):
+            ob = cap.replay(cb)
+            for k in ("seq", "frame", "errmap", "recon"):
+                assert torch.equal(ob[k], wb[k]), k
+        for mode in ("split", "winograd"):
+            mv.precision = mode
+            assert rel_err(mv.score_all(ca)["frame"].cpu().numpy(), gv["frame"]) < SCORE_RTOL, mode
+        mv.precision = "fp32"
+        frames = torch.from_numpy(vad.synth.frames(78, 0, 9, cv, hw, hw)).cuda()
+        tw = 4
+        dense = mv.score_windows(frames, sequence_length=tw, stride=2, errmap=True, recon=True)
+        clips = torch.stack([frames[k:k + tw] for k in range(0, 9 - tw + 1, 2)])
+        each = mv.score_all(clips)
+    assert dense["recon"].shape == clips.shape
+    for k in ("seq", "frame", "errmap", "recon"):
+        assert torch.equal(dense[k], each[k]), k
+    # 32 planes (the largest width the library takes) against the oracle; 33 is refused before anything is packed
+    m32 = vad.ConvAutoencoder(in_channels=32, latent_dim=32)
+    st32 = load_synthetic(vad, m32, 77)
+    m32 = m32.cuda().eval()
+    x32 = vad.synth.frames(992, 0, 2, 32, 32, 32)
+    ref = torch_oracle.img_scores({k: torch.from_numpy(np.asarray(v)) for k, v in st32.items()}, torch.from_numpy(x32))
+    with torch.no_grad():
+        assert rel_err(m32.get_reconstruction_error(torch.from_numpy(x32).cuda()).cpu().numpy(), ref["scores"].numpy()) < SCORE_RTOL
+        with pytest.raises(vad.hip.VadError, match="in_channels"):
+            vad.ConvAutoencoder(in_channels=33, latent_dim=32).cuda().eval().get_reconstruction_error(torch.zeros(1, 33, 32, 32).cuda())
+
+
 def test_one_and_two_channel_models_capture_latent_and_windows(vad, golden):
     """1- and 2-channel models (models/autoencoder.py:161, models/video_autoencoder.py:290 take any in_channels) through the
     entry points the per-call narrowing does not cover by itself: hipGraph capture / replay (the captured kernels work on 3

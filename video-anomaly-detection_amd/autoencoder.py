@@ -114,8 +114,10 @@ class _HipScorer:
         evaluate_video.py:99).  A model built with 1 or 2 input channels is scored as the 3-channel model whose extra
         input taps and extra output channels are zero: first conv weight (32,C,3,3) -> (32,3,3,3), last layer (Conv2d
         weight (C,32,3,3) or ConvTranspose2d weight (32,C,2,2), bias (C)) -> 3 outputs.  The extra planes reconstruct
-        tanh(0) = 0 against a zero input plane, so they add nothing to the squared error (the callers rescale the mean)."""
-        if in_channels == 3:
+        tanh(0) = 0 against a zero input plane, so they add nothing to the squared error (the callers rescale the mean).
+        Models with MORE than 3 channels are packed as they are (`kernel_channels`): the library runs their first and last
+        layer on its generic kernels (csrc/wide_io.hip)."""
+        if in_channels >= 3:
             return params
         params = list(params)
         w0 = params[0]
@@ -128,6 +130,11 @@ class _HipScorer:
         params[-2] = np.ascontiguousarray(wl)
         params[-1] = np.ascontiguousarray(np.concatenate([bl, np.zeros(3 - in_channels, np.float32)]))
         return params
+
+    @staticmethod
+    def kernel_channels(in_channels: int) -> int:
+        """Planes the library reads and reconstructs for a model of `in_channels`: 3 for 1-3 (zero-widened), else as built."""
+        return max(3, int(in_channels))
 
     @staticmethod
     def check_input(x: torch.Tensor, ndim: int, in_channels: int, what: str = "input") -> None:
@@ -149,7 +156,7 @@ class _HipScorer:
     @staticmethod
     def widen_input(x: torch.Tensor, in_channels: int, u8: bool) -> torch.Tensor:
         """Zero planes appended to a 1- or 2-channel input (channel axis: last for uint8 NHWC, -3 for float NCHW)."""
-        if in_channels == 3:
+        if in_channels >= 3:
             return x
         shape = list(x.shape)
         axis = x.dim() - 1 if u8 else x.dim() - 3
@@ -215,14 +222,15 @@ class ConvAutoencoder(nn.Module):
             raise hip.VadError("precision 'bf16' / 'bf16_operands' / 'bf16_tensors' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32', 'split' or 'winograd'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
-            n = l.vad_img_packed_floats(3, self.latent_dim) if 1 <= self.in_channels <= 3 else 0
+            kc = _HipScorer.kernel_channels(self.in_channels)
+            n = l.vad_img_packed_floats(kc, self.latent_dim) if 1 <= self.in_channels <= hip.MAX_IN_CHANNELS else 0
             if n == 0:
                 raise hip.VadError(
                     f"ConvAutoencoder(in_channels={self.in_channels}, latent_dim={self.latent_dim}) is not "
-                    f"supported by the HIP path (needs 1 <= in_channels <= 3 and 1 <= latent_dim <= {hip.MAX_WIDTH})")
+                    f"supported by the HIP path (needs 1 <= in_channels <= {hip.MAX_IN_CHANNELS} and 1 <= latent_dim <= {hip.MAX_WIDTH})")
             params = _HipScorer.widen_to_rgb(_HipScorer.float_params(self), self.in_channels, last_transposed=False)
             blob = np.empty(n, dtype=np.float32)
-            hip.check(l.vad_img_pack(hip.pointer_array(params), len(params), 3,
+            hip.check(l.vad_img_pack(hip.pointer_array(params), len(params), kc,
                                      self.latent_dim, mode, blob.ctypes.data), "vad_img_pack")
             self._hip.packed = torch.from_numpy(blob).to(device)
             self._hip.key = key
@@ -259,15 +267,16 @@ class ConvAutoencoder(nn.Module):
                                      x.dtype == torch.uint8).clone()
         eager = self._run_hip(xs3, prewidened=True, **want)   # packs weights, sizes the workspace, creates helper state
         out = {k: torch.empty_like(v) for k, v in eager.items()}
-        view = xs3 if self.in_channels == 3 else xs3[:, :self.in_channels]
+        view = xs3 if self.in_channels >= 3 else xs3[:, :self.in_channels]
         return hip.CapturedCall(lambda: self._run_hip(xs3, out=out, prewidened=True, **want), view, out,
                                 keep=(self._hip.packed, self._hip.ws, xs3),
-                                post=None if self.in_channels == 3 else self._narrow_outputs)
+                                post=None if self.in_channels >= 3 else self._narrow_outputs)
 
     def _run_hip(self, x: torch.Tensor, scores=False, errmap=False, recon=False, latent=False, out=None, prewidened=False):
-        """`prewidened` (captured calls): `x` already has the kernels' 3 planes and the outputs stay at kernel shape."""
+        """`prewidened` (captured calls): `x` already has the kernels' planes and the outputs stay at kernel shape."""
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,H,W,3]: normalised inside the kernels (row f-3)
-        cin = 3 if prewidened else self.in_channels
+        kc = _HipScorer.kernel_channels(self.in_channels)
+        cin = kc if prewidened else self.in_channels
         _HipScorer.check_input(x, 4, cin)
         if u8:
             b, h, w, _ = x.shape
@@ -280,7 +289,7 @@ class ConvAutoencoder(nn.Module):
         packed = self._packed(dev)
         x = _HipScorer.widen_input(x, cin, u8)
         chunk = max(1, min(int(self.chunk), b))
-        nbytes = l.vad_img_workspace_bytes(chunk, h, w, self.latent_dim)
+        nbytes = l.vad_img_workspace_bytes_c(chunk, h, w, self.latent_dim, kc)
         if nbytes == 0:
             raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
         ws = self._hip.workspace(nbytes, dev)
@@ -291,13 +300,13 @@ class ConvAutoencoder(nn.Module):
             if errmap:
                 out["errmap"] = torch.empty(b, 1, h, w, dtype=torch.float32, device=dev)
             if recon:
-                out["recon"] = torch.empty(b, 3, h, w, dtype=torch.float32, device=dev)
+                out["recon"] = torch.empty(b, kc, h, w, dtype=torch.float32, device=dev)
             if latent:
                 out["latent"] = torch.empty(b, self.latent_dim, h // 16, w // 16, dtype=torch.float32, device=dev)
         if b == 0:                                        # an empty batch gives empty outputs, as the reference's modules do
             return out
         with torch.cuda.device(dev):
-            hip.check(l.vad_img_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, h, w,
+            hip.check(l.vad_img_score_c(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, kc, b, h, w,
                                         self.latent_dim, packed.data_ptr(), ws.data_ptr(),
                                         ws.numel(), chunk, hip.ptr(out.get("scores")), hip.ptr(out.get("errmap")),
                                         hip.ptr(out.get("recon")), hip.ptr(out.get("latent")), hip.current_stream()),
@@ -309,7 +318,7 @@ class ConvAutoencoder(nn.Module):
         """Undo the 3-plane view of a 1- / 2-channel model (`_HipScorer.widen_to_rgb`): the kernels averaged over 3
         planes of which 3 - in_channels are exactly zero."""
         cin = self.in_channels
-        if cin == 3:
+        if cin >= 3:
             return out
         out = dict(out)
         for k in ("scores", "errmap"):

@@ -285,9 +285,10 @@ extern "C" int vad_blob_precision(const float* packed_host) {
 // (VAD_PREC_WINO blobs); one layout for every arithmetic mode keeps the size queries of the C ABI mode-free.
 static size_t conv3x3_slot_floats(int cout, int cin) { return vad_pack_conv3x3_wino_floats(cout, cin); }
 
-ImgLayout img_layout(int latent_real) {
+ImgLayout img_layout(int in_ch, int latent_real) {
     ImgLayout L{};
     const int latent = L.latent_p = vad_img_latent_p(latent_real);
+    const int wide = L.wide = in_ch > 3 ? vad_wide_p(in_ch) : 0;
     const int ch[5] = {3, 32, 64, 128, latent};
     size_t off = VAD_BLOB_HEADER_FLOATS;
     int li = 0;
@@ -298,7 +299,8 @@ ImgLayout img_layout(int latent_real) {
         s.b = off; off = align4(off + (size_t)cout);
     };
     for (int b = 0; b < 4; ++b) {   // encoder blocks (models/autoencoder.py:38-79)
-        if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
+        if (b == 0 && wide) add(LK_CONV, wide, 32, conv3x3_slot_floats(32, wide));
+        else if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
         else add(LK_CONV, ch[b], ch[b + 1], conv3x3_slot_floats(ch[b + 1], ch[b]));
         add(LK_CONV, ch[b + 1], ch[b + 1], conv3x3_slot_floats(ch[b + 1], ch[b + 1]));
     }
@@ -306,6 +308,7 @@ ImgLayout img_layout(int latent_real) {
     for (int b = 0; b < 4; ++b) {   // decoder blocks (models/autoencoder.py:103-139)
         add(LK_CONVT, dch[b], dch[b + 1], vad_pack_convt2x2_floats(dch[b], dch[b + 1]));
         if (b < 3) add(LK_CONV, dch[b + 1], dch[b + 1], conv3x3_slot_floats(dch[b + 1], dch[b + 1]));
+        else if (wide) add(LK_CONV, 32, wide, conv3x3_slot_floats(wide, 32));     // Conv2d(32 -> in_ch) un-activated; Tanh + score: wide_io.hip
         else add(LK_TAIL_CONV, 32, 3, vad_pack_conv3x3_to3_floats(32));
     }
     L.nlayers = li;
@@ -314,20 +317,20 @@ ImgLayout img_layout(int latent_real) {
 }
 
 extern "C" size_t vad_img_packed_floats(int in_ch, int latent) {
-    if (in_ch != 3 || latent <= 0 || latent > VAD_MAX_WIDTH) return 0;
-    return img_layout(latent).total;
+    if (in_ch < 3 || in_ch > VAD_MAX_IN_CH || latent <= 0 || latent > VAD_MAX_WIDTH) return 0;
+    return img_layout(in_ch, latent).total;
 }
 
 extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int latent, int precision, float* out) {
     REQ(P && out, "img_pack: null pointer");
     REQ_PREC("img_pack");
-    REQ(in_ch == 3, "img_pack: in_channels=%d unsupported (every reference call site uses 3)", in_ch);
+    REQ(in_ch >= 3 && in_ch <= VAD_MAX_IN_CH, "img_pack: in_channels=%d out of range [3,%d] (1- and 2-channel models: widen to 3 planes with zero weights)", in_ch, VAD_MAX_IN_CH);
     REQ(latent > 0 && latent <= VAD_MAX_WIDTH, "img_pack: latent_dim=%d out of range [1,%d]", latent, VAD_MAX_WIDTH);
     REQ(nparams == VAD_IMG_NPARAMS, "img_pack: expected %d parameter tensors, got %d", VAD_IMG_NPARAMS, nparams);
     for (int i = 0; i < nparams; ++i) REQ(P[i], "img_pack: parameter %d is NULL", i);
-    const ImgLayout L = img_layout(latent);
+    const ImgLayout L = img_layout(in_ch, latent);
     memset(out, 0, L.total * sizeof(float));
-    put_header(out, VAD_BLOB_IMG, precision, latent, 0);
+    put_header(out, VAD_BLOB_IMG, precision, latent, in_ch);
     int pi = 0, rc = VAD_OK;
     for (int li = 0; li < L.nlayers && rc == VAD_OK; ++li) {
         const LayerSlot& s = L.layer[li];
@@ -338,7 +341,17 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
             pi += 2;
             continue;
         }
+        if (L.wide && li == 15) {                  // last layer of a wide model: Conv2d(32 -> in_ch) + bias, no BatchNorm
+            rc = pack_conv3x3_slot(w, b, nullptr, in_ch, 32, s, precision, out);
+            pi += 2;
+            continue;
+        }
         const float* bn[4] = {P[pi + 2], P[pi + 3], P[pi + 4], P[pi + 5]};
+        if (L.wide && li == 0) {                   // first layer of a wide model: a generic 3x3 layer over the zero-padded planes
+            rc = pack_conv3x3_slot(w, b, bn, 32, in_ch, s, precision, out);
+            pi += 6;
+            continue;
+        }
         // real widths of this layer: only enc4.0 (cout), enc4.3 (both) and dec1.0 (cin) carry latent_dim
         const int cin = s.cin == L.latent_p && (li == 7 || li == 8) ? latent : s.cin;
         const int cout = s.cout == L.latent_p && (li == 6 || li == 7) ? latent : s.cout;
@@ -354,8 +367,9 @@ extern "C" int vad_img_pack(const float* const* P, int nparams, int in_ch, int l
 }
 
 // --------------------------------------------------------------------------- video autoencoder
-VidLayout vid_layout(int latent_real, int hid_real, int layers) {
+VidLayout vid_layout(int in_ch, int latent_real, int hid_real, int layers) {
     VidLayout L{};
+    const int wide = L.wide = in_ch > 3 ? vad_wide_p(in_ch) : 0;
     const int latent = L.latent_p = vad_vid_latent_p(latent_real, hid_real);
     const int hid = L.hid_p = vad_vid_hid_p(latent_real, hid_real);
     size_t off = VAD_BLOB_HEADER_FLOATS;
@@ -368,7 +382,8 @@ VidLayout vid_layout(int latent_real, int hid_real, int layers) {
     };
     const int ch[5] = {3, 32, 64, 128, latent};
     for (int b = 0; b < 4; ++b) {   // VideoEncoder (models/video_autoencoder.py:191-215)
-        if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
+        if (b == 0 && wide) add(LK_CONV, wide, 32, conv3x3_slot_floats(32, wide));
+        else if (b == 0) add(LK_CONV_C3, 3, 32, vad_pack_conv3x3_c3_floats(32));
         else add(LK_CONV, ch[b], ch[b + 1], conv3x3_slot_floats(ch[b + 1], ch[b]));
     }
     for (int l = 0; l < layers; ++l) {   // ConvLSTM cells (models/video_autoencoder.py:118-125)
@@ -379,7 +394,8 @@ VidLayout vid_layout(int latent_real, int hid_real, int layers) {
     if (L.has_proj) add(LK_PROJ, hid, latent, vad_pack_conv1x1_floats(latent, hid));
     const int dch[4] = {latent, 128, 64, 32};
     for (int b = 0; b < 3; ++b) add(LK_CONVT, dch[b], dch[b + 1], vad_pack_convt2x2_floats(dch[b], dch[b + 1]));
-    add(LK_TAIL_CONVT, 32, 3, (size_t)32 * 12);   // VideoDecoder (models/video_autoencoder.py:242-261)
+    if (wide) add(LK_CONVT, 32, wide, vad_pack_convt2x2_floats(32, wide));     // ConvTranspose2d(32 -> in_ch) un-activated; Tanh + score: wide_io.hip
+    else add(LK_TAIL_CONVT, 32, 3, (size_t)32 * 12);   // VideoDecoder (models/video_autoencoder.py:242-261)
     L.nlayers = li;
     L.total = off;
     return L;
@@ -394,17 +410,23 @@ static int vid_dims_ok(int latent, int hid, int layers) {
     return VAD_OK;
 }
 
-extern "C" size_t vad_vid_packed_floats(int latent, int hid, int layers) {
-    if (vid_dims_ok(latent, hid, layers) != VAD_OK) return 0;
-    return vid_layout(latent, hid, layers).total;
+extern "C" size_t vad_vid_packed_floats(int latent, int hid, int layers) { return vad_vid_packed_floats_c(3, latent, hid, layers); }
+extern "C" size_t vad_vid_packed_floats_c(int in_ch, int latent, int hid, int layers) {
+    if (in_ch < 3 || in_ch > VAD_MAX_IN_CH || vid_dims_ok(latent, hid, layers) != VAD_OK) return 0;
+    return vid_layout(in_ch, latent, hid, layers).total;
 }
 
 extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int hid, int layers, int precision, float* out) {
+    return vad_vid_pack_c(P, nparams, 3, latent, hid, layers, precision, out);
+}
+
+extern "C" int vad_vid_pack_c(const float* const* P, int nparams, int in_ch, int latent, int hid, int layers, int precision, float* out) {
     REQ(P && out, "vid_pack: null pointer");
     REQ_PREC("vid_pack");
+    REQ(in_ch >= 3 && in_ch <= VAD_MAX_IN_CH, "vid_pack: in_channels=%d out of range [3,%d] (1- and 2-channel models: widen to 3 planes with zero weights)", in_ch, VAD_MAX_IN_CH);
     int rc = vid_dims_ok(latent, hid, layers);
     if (rc != VAD_OK) return rc;
-    const VidLayout L = vid_layout(latent, hid, layers);
+    const VidLayout L = vid_layout(in_ch, latent, hid, layers);
     REQ(nparams == vad_vid_nparams(layers, L.has_proj), "vid_pack: expected %d parameter tensors, got %d",
         vad_vid_nparams(layers, L.has_proj), nparams);
     for (int i = 0; i < nparams; ++i) REQ(P[i], "vid_pack: parameter %d is NULL", i);
@@ -419,9 +441,13 @@ extern "C" int vad_vid_pack(const float* const* P, int nparams, int latent, int 
         switch (s.kind) {
         case LK_CONV_C3: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];
             rc = vad_pack_conv3x3_c3(w, b, bn, s.cout, out + s.w, out + s.b); pi += 6; break;
-        case LK_CONV: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];     // encoder.12 is the one whose cout is latent_dim
-            rc = pack_conv3x3_slot(w, b, bn, li == 3 ? latent : s.cout, s.cin, s, precision, out); pi += 6; break;
-        case LK_CONVT: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];    // decoder.0 is the one whose cin is latent_dim
+        case LK_CONV: for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];     // encoder.12 is the one whose cout is latent_dim; encoder.0 of a wide model reads in_ch planes
+            rc = pack_conv3x3_slot(w, b, bn, li == 3 ? latent : s.cout, (li == 0 && L.wide) ? in_ch : s.cin, s, precision, out); pi += 6; break;
+        case LK_CONVT:
+            if (L.wide && li == L.nlayers - 1) {   // last layer of a wide model: ConvTranspose2d(32 -> in_ch) + bias, no BatchNorm; exact fp32 like the 3-plane tail
+                rc = pack_convt2x2_slot(w, b, nullptr, 32, in_ch, s, VAD_PREC_FP32, out); pi += 2; break;
+            }
+            for (int i = 0; i < 4; ++i) bn[i] = P[pi + 2 + i];    // decoder.0 is the one whose cin is latent_dim
             rc = pack_convt2x2_slot(w, b, bn, li == first_convt ? latent : s.cin, s.cout, s, precision, out); pi += 6; break;
         case LK_LSTM: {   // weight (4*hid, x + hid, 3, 3): gate blocks i,f,g,o and the x / h input halves are padded separately
             const int xr = (li == 4) ? latent : hid, xp = (li == 4) ? L.latent_p : L.hid_p, hp = L.hid_p;

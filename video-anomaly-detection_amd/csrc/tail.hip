@@ -425,14 +425,14 @@ int vad_convt2x2_to3_score_fmt(const float* in, const float* w_iohw, const float
 
 extern "C" int vad_score_finalize(const float* partials, int nparts, int n, int h2, int w2,
                                   float* frame_scores, float* seq_scores, int t, void* stream) {
-    return vad_score_finalize_tagged(partials, nparts, n, h2, w2, frame_scores, seq_scores, t, nullptr, 0u, stream);
+    return vad_score_finalize_tagged(partials, nparts, n, h2, w2, 3, frame_scores, seq_scores, t, nullptr, 0u, stream);
 }
 
-int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, float* frame_scores,
+int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, int channels, float* frame_scores,
                               float* seq_scores, int t, const unsigned* hdr, unsigned want_tag, void* stream) {
-    VAD_REQUIRE(partials && nparts > 0 && n > 0 && t > 0 && n % t == 0, "score_finalize: bad arguments");
+    VAD_REQUIRE(partials && nparts > 0 && n > 0 && t > 0 && n % t == 0 && channels > 0, "score_finalize: bad arguments");
     VAD_REQUIRE(frame_scores || seq_scores, "score_finalize: no output requested");
-    const float denom = 3.0f * (float)h2 * (float)w2;
+    const float denom = (float)channels * (float)h2 * (float)w2;
     hipLaunchKernelGGL(score_finalize_kernel, dim3(n / t), dim3(256), 0, (hipStream_t)stream,
                        partials, nparts, denom, frame_scores, seq_scores, t, hdr, want_tag);
     VAD_LAUNCH_CHECK();

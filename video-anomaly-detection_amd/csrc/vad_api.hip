@@ -141,12 +141,17 @@ static size_t img_act_floats(int h, int w, int latent) {
 
 // per-frame partial sums: the larger of the two tails' counts (unfused 32x32 tiles; fused: one per output row, strip and wave)
 static size_t img_partials(int h, int w) {
-    const size_t a = (size_t)vad_score_partials(0, h, w), b = (size_t)vad_dec4_score_partials(h, w);
-    return a > b ? a : b;
+    const size_t a = (size_t)vad_score_partials(0, h, w), b = (size_t)vad_dec4_score_partials(h, w), c = (size_t)vad_wide_score_partials(h, w);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 static std::atomic<int> g_vad_dec4_fused{1};   // debug / A-B: 0 = dec4.0 and the scoring tail as two launches (the round-2 path)
 extern "C" int vad_debug_set_dec4_fused(int on) { g_vad_dec4_fused = on; return VAD_OK; }
+
+extern "C" size_t vad_img_workspace_bytes_c(int chunk, int h, int w, int latent, int in_ch) {
+    if (in_ch < 3 || in_ch > VAD_MAX_IN_CH) return 0;
+    return vad_img_workspace_bytes(chunk, h, w, latent);          // (the planes of a wide model pad to 32 channels: the size of the largest map either way)
+}
 
 extern "C" size_t vad_img_workspace_bytes(int chunk, int h, int w, int latent) {
     if (chunk <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16 || latent <= 0 || latent > VAD_MAX_WIDTH) return 0;
@@ -166,9 +171,17 @@ extern "C" int vad_img_score(const float* x, long long b, int h, int w, int late
 extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long long b, int h, int w, int latent_real,
                                const float* packed, void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
                                float* recon, float* latent_out, void* stream) {
+    return vad_img_score_c(xv, x_format, precision, 3, b, h, w, latent_real, packed, ws, ws_bytes, chunk, scores, errmap, recon, latent_out, stream);
+}
+
+extern "C" int vad_img_score_c(const void* xv, int x_format, int precision, int in_ch, long long b, int h, int w, int latent_real,
+                               const float* packed, void* ws, size_t ws_bytes, int chunk, float* scores, float* errmap,
+                               float* recon, float* latent_out, void* stream) {
     VAD_REQUIRE(xv && packed && ws, "img_score: null pointer");
     REQ_PREC("img_score");
     VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "img_score: unknown input format %d", x_format);
+    VAD_REQUIRE(in_ch >= 3 && in_ch <= VAD_MAX_IN_CH, "img_score: in_channels=%d out of range [3,%d]", in_ch, VAD_MAX_IN_CH);
+    VAD_REQUIRE(in_ch == 3 || x_format == VAD_X_F32_NCHW, "img_score: uint8 frames are 3-channel images (in_channels=%d)", in_ch);
     const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
     const char* x = (const char*)xv;
     VAD_REQUIRE(b > 0 && chunk > 0, "img_score: batch=%lld chunk=%d must be positive", b, chunk);
@@ -181,8 +194,9 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
     VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "img_score: workspace must be 256-B and weights 16-B aligned");
 
     hipStream_t s = (hipStream_t)stream;
-    const ImgLayout L = img_layout(latent_real);
+    const ImgLayout L = img_layout(in_ch, latent_real);
     const int latent = L.latent_p;                  // the width the kernels see (zero-padded to a multiple of 32, vad_layout.h)
+    const int wide = L.wide;                        // in_channels > 3: generic first / last layers over planes padded to `wide` channels
     const size_t act = up256(sizeof(float) * chunk * img_act_floats(h, w, latent));
     float* A = (float*)ws;
     float* B = (float*)((char*)ws + act);
@@ -197,10 +211,15 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
 
     for (long long f0 = 0; f0 < b; f0 += chunk) {
         const int n = (int)((b - f0 < chunk) ? (b - f0) : chunk);
-        const char* xin = x + (size_t)f0 * 3 * h * w * xelem;
+        const char* xin = x + (size_t)f0 * in_ch * h * w * xelem;
         int hh = h, ww = w;
         // encoder: 4 x [conv-BN-LeakyReLU, conv-BN-LeakyReLU-MaxPool] (models/autoencoder.py:38-79)
-        if (precision == VAD_PREC_WINO) {   // first layer on its own (K = 27: nothing to gain from Winograd), then enc1.3 + pool in Winograd form
+        if (wide) {                         // csrc/wide_io.hip: planes -> zero-padded NHWC, then two generic layers
+            { VadProfScope ps(0, s);
+              TRY(vad_nchw_to_nhwc_pad((const float*)xin, B, n, hh, ww, in_ch, wide, s));
+              TRY(conv3x3_mode(B, W_(0), B_(0), A, n, hh, ww, wide, 32, VAD_ACT_LEAKY, 0, precision, s)); }
+            { VadProfScope ps(1, s); TRY(conv3x3_mode(A, W_(1), B_(1), B, n, hh, ww, 32, 32, VAD_ACT_LEAKY, 1, precision, s)); }
+        } else if (precision == VAD_PREC_WINO) {   // first layer on its own (K = 27: nothing to gain from Winograd), then enc1.3 + pool in Winograd form
             { VadProfScope ps(0, s); TRY(vad_conv3x3_c3_fmt(xin, x_format, W_(0), B_(0), A, n, hh, ww, 32, VAD_ACT_LEAKY, 0, s)); }
             { VadProfScope ps(1, s); TRY(conv3x3_mode(A, W_(1), B_(1), B, n, hh, ww, 32, 32, VAD_ACT_LEAKY, 1, precision, s)); }
         } else {
@@ -234,7 +253,14 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
         // on MI355X this does NOT pay (15.2 k frames/s whole group vs 14.9 k at 16 frames), so the default is the whole group.
         const size_t in_f = (size_t)hh * ww * 32;
         int nparts = nparts_tail;
-        if (g_vad_dec4_fused.load(std::memory_order_relaxed)) {
+        if (wide) {                         // convT 32 -> 32, Conv2d(32 -> in_ch) into padded planes, Tanh + score (wide_io.hip)
+            nparts = vad_wide_score_partials(h, w);
+            { VadProfScope ps(14, s); TRY(vad_convt2x2(B, 0, W_(14), B_(14), A, 0, n, hh, ww, 32, 32, VAD_ACT_RELU, VAD_PREC_FP32, s)); }
+            { VadProfScope ps(15, s);
+              TRY(conv3x3_mode(A, W_(15), B_(15), B, n, h, w, 32, wide, VAD_ACT_NONE, 0, precision, s));
+              TRY(vad_tanh_score_nhwc(B, wide, (const float*)xin, in_ch, parts, recon ? recon + (size_t)f0 * in_ch * h * w : nullptr,
+                                      errmap ? errmap + (size_t)f0 * h * w : nullptr, n, h, w, 0, 0, s)); }
+        } else if (g_vad_dec4_fused.load(std::memory_order_relaxed)) {
             nparts = vad_dec4_score_partials(h, w);
             VadProfScope ps(18, s);
             TRY(vad_dec4_score_fmt(B, W_(14), B_(14), W_(15) + 8 * 108, B_(15), xin, x_format, parts,
@@ -256,7 +282,7 @@ extern "C" int vad_img_score_x(const void* xv, int x_format, int precision, long
         }
         if (scores) {
             VadProfScope ps(16, s);
-            TRY(vad_score_finalize_tagged(parts, nparts, n, h, w, scores + f0, nullptr, 1, (const unsigned*)packed,
+            TRY(vad_score_finalize_tagged(parts, nparts, n, h, w, in_ch, scores + f0, nullptr, 1, (const unsigned*)packed,
                                           vad_blob_tag(VAD_BLOB_IMG, precision), s));
         }
     }
@@ -279,17 +305,18 @@ struct VidWs {
 // work-groups of one ConvLSTM step in the large (32x32x2) tiling: below one per CU the layers run as a wavefront on helper
 // streams and the steps' x halves are computed ahead of the recurrence
 long long vid_lstm_groups(int nc, int h16, int w16, int hid) { return (long long)nc * ((w16 + 15) / 16) * ((h16 + 3) / 4) * (hid / 64); }
-VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_real, int layers) {
+VidWs vid_ws(int chunk, int t, int cs, int h, int w, int latent_real, int hid_real, int layers, int in_ch) {
     VidWs z{};
+    const bool wide = in_ch > 3;
     const int latent = vad_vid_latent_p(latent_real, hid_real), hid = vad_vid_hid_p(latent_real, hid_real);
     const size_t n = (size_t)chunk * t, nf = (size_t)(chunk - 1) * cs + t, p16 = (size_t)(h / 16) * (w / 16);
     const size_t nmax = n > nf ? n : nf;
-    z.act = up256(sizeof(float) * nmax * (size_t)h * w * 8);       // [frames, H/2, W/2, 32]
+    z.act = up256(sizeof(float) * nmax * (size_t)h * w * (wide ? 32 : 8));       // [frames, H/2, W/2, 32]; wide models: [frames, H, W, 32] padded planes
     z.enc = up256(sizeof(float) * nf * p16 * latent);
     z.hseq = up256(sizeof(float) * n * p16 * hid);
     z.cst = up256(sizeof(float) * (size_t)chunk * p16 * hid);
     z.proj = (hid_real != latent_real) ? up256(sizeof(float) * n * p16 * latent) : 0;
-    z.parts = up256(sizeof(float) * n * (size_t)vad_score_partials(1, h, w));
+    z.parts = up256(sizeof(float) * n * (size_t)(wide ? vad_wide_score_partials(h, w) : vad_score_partials(1, h, w)));
     // small launch groups: bias + x half of every step's gate pre-activations, [frames][h/16][w/16][4*hid] - layer 0 per SOURCE
     // frame (overlapping windows share them), the layers above per (clip, t)
     const bool small = vid_lstm_groups(chunk, h / 16, w / 16, hid) < 256;
@@ -340,7 +367,7 @@ extern "C" int vad_debug_set_lstm_wavefront(int on) { g_vad_lstm_wavefront = on;
 extern "C" int vad_lstm_wavefront_mode(void) { return g_vad_lstm_wavefront.load(std::memory_order_relaxed); }   // the training step shares the switch
 
 // clips [c0, c0+nc) of a stream whose clip c starts at source frame c*cs; x points at source frame 0 of the stream
-int vid_run(const void* xv, int x_format, int precision, long long nclips, int t, int cs, int h, int w, int latent_real, int hid_real, int layers,
+int vid_run(const void* xv, int x_format, int precision, int in_ch, long long nclips, int t, int cs, int h, int w, int latent_real, int hid_real, int layers,
             const float* packed, void* ws, size_t ws_bytes, int chunk, float* seq_scores, float* frame_scores,
             float* errmap, float* recon, hipStream_t s, const char* who) {
     VAD_REQUIRE(x_format == VAD_X_F32_NCHW || x_format == VAD_X_U8_NHWC, "%s: unknown input format %d", who, x_format);
@@ -350,11 +377,14 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
     if (wino) precision = VAD_PREC_FP32;                                          // everything but the encoder's 3x3 convolutions
     const size_t xelem = x_format == VAD_X_U8_NHWC ? 1 : 4;
     const char* x = (const char*)xv;
-    const VidWs Z = vid_ws(chunk, t, cs, h, w, latent_real, hid_real, layers);
+    VAD_REQUIRE(in_ch >= 3 && in_ch <= VAD_MAX_IN_CH, "%s: in_channels=%d out of range [3,%d]", who, in_ch, VAD_MAX_IN_CH);
+    VAD_REQUIRE(in_ch == 3 || x_format == VAD_X_F32_NCHW, "%s: uint8 frames are 3-channel images (in_channels=%d)", who, in_ch);
+    const VidWs Z = vid_ws(chunk, t, cs, h, w, latent_real, hid_real, layers, in_ch);
     if (ws_bytes < Z.total) return vad_fail(VAD_ERR_WS, "%s: workspace %zu B < required %zu B", who, ws_bytes, Z.total);
     VAD_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)packed & 15) == 0, "%s: workspace must be 256-B and weights 16-B aligned", who);
-    const VidLayout L = vid_layout(latent_real, hid_real, layers);
+    const VidLayout L = vid_layout(in_ch, latent_real, hid_real, layers);
     const int latent = L.latent_p, hid = L.hid_p;   // the widths the kernels see (zero-padded, vad_layout.h)
+    const int wide = L.wide;                        // in_channels > 3: generic first / last layers over planes padded to `wide` channels
     char* base = (char*)ws;
     float* A = (float*)base; base += Z.act;
     float* Bf = (float*)base; base += Z.act;
@@ -373,7 +403,7 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
     }
     float* ZW[8];                                   // per layer: the layers of a small launch group run concurrently (wavefront)
     for (int l = 0; l < layers; ++l) { ZW[l] = (float*)base; base += Z.zw; }
-    const int nparts = vad_score_partials(1, h, w);
+    const int nparts = wide ? vad_wide_score_partials(h, w) : vad_score_partials(1, h, w);
     const int h16 = h / 16, w16 = w / 16;
     const long long fs_lat = (long long)h16 * w16 * latent, fs_hid = (long long)h16 * w16 * hid;
 #define W_(i) (packed + L.layer[i].w)
@@ -383,10 +413,14 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         const int nc = (int)((nclips - c0 < chunk) ? (nclips - c0) : chunk);
         const int n = nc * t;                       // (clip, t) frames that are decoded and scored
         const int nf = (nc - 1) * cs + t;           // distinct source frames that are encoded
-        const char* xin = x + (size_t)c0 * cs * 3 * h * w * xelem;
+        const char* xin = x + (size_t)c0 * cs * in_ch * h * w * xelem;
         // VideoEncoder: 4 x conv-BN-LeakyReLU-MaxPool on the flattened frames
         // (models/video_autoencoder.py:191-215, :222-228)
-        { VadProfScope ps(0, s); TRY(vad_conv3x3_c3_fmt(xin, x_format, W_(0), B_(0), A, nf, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
+        if (wide) {
+            VadProfScope ps(0, s);
+            TRY(vad_nchw_to_nhwc_pad((const float*)xin, Bf, nf, h, w, in_ch, wide, s));
+            TRY(conv3x3_mode(Bf, W_(0), B_(0), A, nf, h, w, wide, 32, VAD_ACT_LEAKY, 1, mprec, s));
+        } else { VadProfScope ps(0, s); TRY(vad_conv3x3_c3_fmt(xin, x_format, W_(0), B_(0), A, nf, h, w, 32, VAD_ACT_LEAKY, 1, s)); }
         { VadProfScope ps(1, s); TRY(conv3x3_mode(A, W_(1), B_(1), Bf, nf, h / 2, w / 2, 32, 64, VAD_ACT_LEAKY, 1, mprec, s)); }
         { VadProfScope ps(2, s); TRY(conv3x3_mode(Bf, W_(2), B_(2), A, nf, h / 4, w / 4, 64, 128, VAD_ACT_LEAKY, 1, mprec, s)); }
         { VadProfScope ps(3, s); TRY(conv3x3_mode(A, W_(3), B_(3), E, nf, h / 8, w / 8, 128, latent, VAD_ACT_LEAKY, 1, mprec, s)); }
@@ -484,14 +518,19 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
         { VadProfScope ps(6, s); TRY(vad_convt2x2(dec_in, 0, W_(li), B_(li), A, 0, n, h16, w16, latent, 128, VAD_ACT_RELU, precision, s)); }
         { VadProfScope ps(7, s); TRY(vad_convt2x2(A, 0, W_(li + 1), B_(li + 1), Bf, 0, n, h / 8, w / 8, 128, 64, VAD_ACT_RELU, precision, s)); }
         { VadProfScope ps(8, s); TRY(vad_convt2x2(Bf, 0, W_(li + 2), B_(li + 2), A, 0, n, h / 4, w / 4, 64, 32, VAD_ACT_RELU, precision, s)); }
-        { VadProfScope ps(9, s);
+        if (wide) {                         // ConvTranspose2d(32 -> in_ch) into padded planes, Tanh + score (wide_io.hip)
+            VadProfScope ps(9, s);
+            TRY(vad_convt2x2(A, 0, W_(li + 3), B_(li + 3), Bf, 0, n, h / 2, w / 2, 32, wide, VAD_ACT_NONE, VAD_PREC_FP32, s));
+            TRY(vad_tanh_score_nhwc(Bf, wide, (const float*)xin, in_ch, parts, recon ? recon + (size_t)c0 * t * in_ch * h * w : nullptr,
+                                    errmap ? errmap + (size_t)c0 * t * h * w : nullptr, n, h, w, t, cs, s));
+        } else { VadProfScope ps(9, s);
           TRY(vad_convt2x2_to3_score_fmt(A, W_(li + 3), B_(li + 3), xin, x_format, parts,
                                      recon ? recon + (size_t)c0 * t * 3 * h * w : nullptr,
                                      errmap ? errmap + (size_t)c0 * t * h * w : nullptr, n, h / 2, w / 2, 32,
                                      t, cs, s)); }
         if (seq_scores || frame_scores) {
             VadProfScope ps(10, s);
-            TRY(vad_score_finalize_tagged(parts, nparts, n, h, w, frame_scores ? frame_scores + (size_t)c0 * t : nullptr,
+            TRY(vad_score_finalize_tagged(parts, nparts, n, h, w, in_ch, frame_scores ? frame_scores + (size_t)c0 * t : nullptr,
                                           seq_scores ? seq_scores + c0 : nullptr, t, (const unsigned*)packed,
                                           vad_blob_tag(VAD_BLOB_VID, mprec), s));
         }
@@ -503,9 +542,12 @@ int vid_run(const void* xv, int x_format, int precision, long long nclips, int t
 }  // namespace
 
 extern "C" size_t vad_vid_workspace_bytes(int chunk, int t, int h, int w, int latent, int hid, int layers) {
+    return vad_vid_workspace_bytes_c(chunk, t, h, w, latent, hid, layers, 3);
+}
+extern "C" size_t vad_vid_workspace_bytes_c(int chunk, int t, int h, int w, int latent, int hid, int layers, int in_ch) {
     if (chunk <= 0 || t <= 0 || h <= 0 || w <= 0 || h % 16 || w % 16) return 0;
-    if (vad_vid_packed_floats(latent, hid, layers) == 0) return 0;
-    return vid_ws(chunk, t, t, h, w, latent, hid, layers).total;
+    if (vad_vid_packed_floats_c(in_ch, latent, hid, layers) == 0) return 0;
+    return vid_ws(chunk, t, t, h, w, latent, hid, layers, in_ch).total;
 }
 
 extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, int latent, int hid, int layers,
@@ -518,13 +560,19 @@ extern "C" int vad_vid_score(const float* x, long long b, int t, int h, int w, i
 extern "C" int vad_vid_score_x(const void* x, int x_format, int precision, long long b, int t, int h, int w, int latent, int hid, int layers,
                                const float* packed, void* ws, size_t ws_bytes, int chunk,
                                float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
+    return vad_vid_score_c(x, x_format, precision, 3, b, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap, recon, stream);
+}
+
+extern "C" int vad_vid_score_c(const void* x, int x_format, int precision, int in_ch, long long b, int t, int h, int w, int latent, int hid, int layers,
+                               const float* packed, void* ws, size_t ws_bytes, int chunk,
+                               float* seq_scores, float* frame_scores, float* errmap, float* recon, void* stream) {
     VAD_REQUIRE(x && packed && ws, "vid_score: null pointer");
     VAD_REQUIRE(b > 0 && t > 0 && chunk > 0, "vid_score: clips=%lld T=%d chunk=%d must be positive", b, t, chunk);
     VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0,
                 "vid_score: H=%d W=%d must be positive multiples of 16 (4 MaxPool2d(2) stages)", h, w);
     if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;   // message already set
     VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score: no output requested");
-    return vid_run(x, x_format, precision, b, t, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap,
+    return vid_run(x, x_format, precision, in_ch, b, t, t, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk, seq_scores, frame_scores, errmap,
                    recon, (hipStream_t)stream, "vid_score");
 }
 
@@ -534,9 +582,12 @@ extern "C" long long vad_vid_num_windows(long long frames, int t, int stride) {
 }
 
 extern "C" size_t vad_vid_windows_workspace_bytes(int chunk, int t, int stride, int h, int w, int latent, int hid, int layers) {
+    return vad_vid_windows_workspace_bytes_c(chunk, t, stride, h, w, latent, hid, layers, 3);
+}
+extern "C" size_t vad_vid_windows_workspace_bytes_c(int chunk, int t, int stride, int h, int w, int latent, int hid, int layers, int in_ch) {
     if (chunk <= 0 || t <= 0 || stride <= 0 || stride > t || h <= 0 || w <= 0 || h % 16 || w % 16) return 0;
-    if (vad_vid_packed_floats(latent, hid, layers) == 0) return 0;
-    return vid_ws(chunk, t, stride, h, w, latent, hid, layers).total;
+    if (vad_vid_packed_floats_c(in_ch, latent, hid, layers) == 0) return 0;
+    return vid_ws(chunk, t, stride, h, w, latent, hid, layers, in_ch).total;
 }
 
 extern "C" int vad_vid_score_windows(const float* frames, long long nframes, int t, int stride, int h, int w,
@@ -551,12 +602,20 @@ extern "C" int vad_vid_score_windows_x(const void* frames, int x_format, int pre
                                        int latent, int hid, int layers, const float* packed, void* ws, size_t ws_bytes,
                                        int chunk, float* seq_scores, float* frame_scores, float* errmap, float* recon,
                                        void* stream) {
+    return vad_vid_score_windows_c(frames, x_format, precision, 3, nframes, t, stride, h, w, latent, hid, layers, packed, ws, ws_bytes, chunk,
+                                   seq_scores, frame_scores, errmap, recon, stream);
+}
+
+extern "C" int vad_vid_score_windows_c(const void* frames, int x_format, int precision, int in_ch, long long nframes, int t, int stride, int h, int w,
+                                       int latent, int hid, int layers, const float* packed, void* ws, size_t ws_bytes,
+                                       int chunk, float* seq_scores, float* frame_scores, float* errmap, float* recon,
+                                       void* stream) {
     VAD_REQUIRE(frames && packed && ws, "vid_score_windows: null pointer");
     VAD_REQUIRE(t > 0 && stride > 0 && stride <= t && chunk > 0, "vid_score_windows: need 0 < stride <= T (got T=%d stride=%d) and chunk > 0", t, stride);
     VAD_REQUIRE(nframes >= t, "vid_score_windows: %lld frames are fewer than one window of %d", nframes, t);
     VAD_REQUIRE(h > 0 && w > 0 && h % 16 == 0 && w % 16 == 0, "vid_score_windows: H=%d W=%d must be positive multiples of 16", h, w);
     if (vad_vid_packed_floats(latent, hid, layers) == 0) return VAD_ERR_ARG;
     VAD_REQUIRE(seq_scores || frame_scores || errmap || recon, "vid_score_windows: no output requested");
-    return vid_run(frames, x_format, precision, vad_vid_num_windows(nframes, t, stride), t, stride, h, w, latent, hid, layers, packed, ws,
+    return vid_run(frames, x_format, precision, in_ch, vad_vid_num_windows(nframes, t, stride), t, stride, h, w, latent, hid, layers, packed, ws,
                    ws_bytes, chunk, seq_scores, frame_scores, errmap, recon, (hipStream_t)stream, "vid_score_windows");
 }

@@ -177,7 +177,13 @@ int vad_nhwc_to_nchw_ld(const float* in, int in_c, float* out, int n, int h, int
 int vad_conv3x3_c3_stats_t(const void* x, int fmt, const float* w, const float* bias, void* out, int out16, int n, int h, int wd, int cout,
                            int act, int pool, float* stats, int* stats_blocks, void* stream);
 // vad_score_finalize + the device-side blob check: when hdr != NULL and hdr[1] != want_tag every score becomes NaN
-int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, float* frame_scores,
+// csrc/wide_io.hip (models with in_channels > 3)
+int vad_nchw_to_nhwc_pad(const float* x, float* out, long long n, int h, int w, int c, int cpad, void* stream);
+int vad_wide_score_partials(int h, int w);
+int vad_tanh_score_nhwc(const float* pre, int cpad, const float* x, int c, float* partials, float* recon, float* errmap,
+                        int n, int h, int w, int t, int clip_stride, void* stream);
+// (channels: the planes a frame's squared error is averaged over - 3 on the 3-plane path)
+int vad_score_finalize_tagged(const float* partials, int nparts, int n, int h2, int w2, int channels, float* frame_scores,
                               float* seq_scores, int t, const unsigned* hdr, unsigned want_tag, void* stream);
 int vad_conv3x3_to3_score_fmt(const float* in, const float* w_packed, const float* bias3, const void* x, int fmt,
                               float* partials, float* recon, float* errmap, int n, int h2, int w2, int cin, void* stream);

@@ -34,15 +34,21 @@ inline int vad_vid_latent_p(int latent, int hid) { return hid == latent ? vad_pa
 struct ImgLayout {
     LayerSlot layer[16];
     int nlayers;
+    int wide;              // in_ch > 3: padded channel count of the input / output planes, else 0
     int latent_p;          // padded latent width (layer[].cin / cout hold padded widths too)
     size_t total;
 };
 struct VidLayout {
     LayerSlot layer[4 + 8 + 1 + 4];
     int nlayers;
+    int wide;              // as in ImgLayout
     int has_proj;          // from the REAL dimensions: lstm_hidden_dim != latent_dim (models/video_autoencoder.py:311-312)
     int latent_p, hid_p;
     size_t total;
 };
-ImgLayout img_layout(int latent);                       // real dimensions in, padded slots out
-VidLayout vid_layout(int latent, int hid, int layers);
+// in_ch <= 3: the 3-plane path (K = 27 first layer, Cout = 3 tails; 1- and 2-channel models are widened with zero planes by the
+// caller).  in_ch > 3 (csrc/wide_io.hip): first and last layer in generic slots of vad_wide_p(in_ch) channels.
+constexpr int VAD_MAX_IN_CH = VAD_MAX_IN_CHANNELS;
+inline int vad_wide_p(int in_ch) { return vad_pad_up(in_ch, 32); }
+ImgLayout img_layout(int in_ch, int latent);            // real dimensions in, padded slots out
+VidLayout vid_layout(int in_ch, int latent, int hid, int layers);

@@ -16,10 +16,11 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_DIR = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = Path(os.environ.get("VAD_LIB", PKG_DIR / "libvad_hip.so"))
-SOURCES = ["conv_mfma.hip", "conv_wino.hip", "dec4_fused.hip", "tail.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
+SOURCES = ["conv_mfma.hip", "conv_wino.hip", "dec4_fused.hip", "tail.hip", "wide_io.hip", "ssim.hip", "train_ops.hip", "train_step.hip", "train_step_img.hip", "vad_api.hip", "pack.cpp"]
 
 VAD_OK = 0
 ABI_VERSION = 3
+MAX_IN_CHANNELS = 32    # include/vad_hip.h VAD_MAX_IN_CHANNELS
 PREC_FP32, PREC_SPLIT, PREC_BF16, PREC_BF16S, PREC_WINO = 0, 1, 2, 3, 4
 # bf16 modes: training entry points only.  "bf16_operands" = bf16 MFMA operands converted from fp32 tensors; "bf16_tensors" =
 # the activation / gradient tensors themselves are bf16 in HBM (VAD_PREC_BF16S, video training step only)
@@ -216,6 +217,15 @@ SIGNATURES = {
     "vad_vid_score_windows_x": (_i, [_vp, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_num_windows": (_ll, [_ll, _i, _i]),
     "vad_vid_windows_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    # in_channels > 3 (the `_c` forms take in_ch; in_ch == 3 is the form above)
+    "vad_img_workspace_bytes_c": (_sz, [_i, _i, _i, _i, _i]),
+    "vad_img_score_c": (_i, [_vp, _i, _i, _i, _ll, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_vid_packed_floats_c": (_sz, [_i, _i, _i, _i]),
+    "vad_vid_pack_c": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vad_vid_workspace_bytes_c": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "vad_vid_score_c": (_i, [_vp, _i, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
+    "vad_vid_windows_workspace_bytes_c": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "vad_vid_score_windows_c": (_i, [_vp, _i, _i, _i, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_vid_score_windows": (_i, [_vp, _ll, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp]),
     "vad_graph_begin": (_i, [_vp]),
     "vad_graph_end": (_i, [_vp, C.POINTER(_vp)]),

@@ -158,17 +158,19 @@ class VideoAutoencoder(nn.Module):
             raise hip.VadError("precision 'bf16' / 'bf16_operands' / 'bf16_tensors' is a training mode (VideoTrainer / ImageTrainer): scoring is exact 'fp32', 'split' or 'winograd'")
         key = (mode,) + _HipScorer.state_key(self)
         if self._hip.key != key or self._hip.packed is None or self._hip.packed.device != device:
-            n = l.vad_vid_packed_floats(self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
-            if n == 0 or not 1 <= self.in_channels <= 3:
+            kc = _HipScorer.kernel_channels(self.in_channels)
+            n = (l.vad_vid_packed_floats_c(kc, self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
+                 if 1 <= self.in_channels <= hip.MAX_IN_CHANNELS else 0)
+            if n == 0:
                 raise hip.VadError(
                     f"VideoAutoencoder(in_channels={self.in_channels}, latent_dim={self.latent_dim}, "
                     f"lstm_hidden_dim={self.lstm_hidden_dim}, lstm_num_layers={self.lstm_num_layers}) is not "
-                    f"supported by the HIP path (needs 1 <= in_channels <= 3, latent_dim and lstm_hidden_dim in "
+                    f"supported by the HIP path (needs 1 <= in_channels <= {hip.MAX_IN_CHANNELS}, latent_dim and lstm_hidden_dim in "
                     f"[1, {hip.MAX_WIDTH}], 1 <= layers <= 8)")
             params = _HipScorer.widen_to_rgb(_HipScorer.float_params(self), self.in_channels, last_transposed=True)
             blob = np.empty(n, dtype=np.float32)
-            hip.check(l.vad_vid_pack(hip.pointer_array(params), len(params), self.latent_dim,
-                                     self.lstm_hidden_dim, self.lstm_num_layers, mode, blob.ctypes.data), "vad_vid_pack")
+            hip.check(l.vad_vid_pack_c(hip.pointer_array(params), len(params), kc, self.latent_dim,
+                                       self.lstm_hidden_dim, self.lstm_num_layers, mode, blob.ctypes.data), "vad_vid_pack")
             self._hip.packed = torch.from_numpy(blob).to(device)
             self._hip.key = key
             self._hip.mode = mode
@@ -197,15 +199,16 @@ class VideoAutoencoder(nn.Module):
                                      x.dtype == torch.uint8).clone()
         eager = self._run_hip(xs3, prewidened=True, **want)
         out = {k: torch.empty_like(v) for k, v in eager.items()}
-        view = xs3 if self.in_channels == 3 else xs3[:, :, :self.in_channels]
+        view = xs3 if self.in_channels >= 3 else xs3[:, :, :self.in_channels]
         return hip.CapturedCall(lambda: self._run_hip(xs3, out=out, prewidened=True, **want), view, out,
                                 keep=(self._hip.packed, self._hip.ws, xs3),
-                                post=None if self.in_channels == 3 else self._narrow_outputs)
+                                post=None if self.in_channels >= 3 else self._narrow_outputs)
 
     def _run_hip(self, x: torch.Tensor, seq=False, frame=False, errmap=False, recon=False, out=None, prewidened=False):
         """`prewidened` (captured calls): `x` already has the kernels' 3 planes and the outputs stay at kernel shape."""
         u8 = x.dtype == torch.uint8       # raw decoded frames [B,T,H,W,3]: normalised inside the kernels (row f-3)
-        cin = 3 if prewidened else self.in_channels
+        kc = _HipScorer.kernel_channels(self.in_channels)
+        cin = kc if prewidened else self.in_channels
         _HipScorer.check_input(x, 5, cin)
         if u8:
             b, t, h, w, _ = x.shape
@@ -219,7 +222,7 @@ class VideoAutoencoder(nn.Module):
         x = _HipScorer.widen_input(x, cin, u8)
         chunk = max(1, min(int(self.chunk), b))
         dims = (self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
-        nbytes = l.vad_vid_workspace_bytes(chunk, t, h, w, *dims)
+        nbytes = l.vad_vid_workspace_bytes_c(chunk, t, h, w, *dims, kc)
         if nbytes == 0:
             raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
         ws = self._hip.workspace(nbytes, dev)
@@ -232,11 +235,11 @@ class VideoAutoencoder(nn.Module):
             if errmap:
                 out["errmap"] = torch.empty(b, t, 1, h, w, dtype=torch.float32, device=dev)
             if recon:
-                out["recon"] = torch.empty(b, t, 3, h, w, dtype=torch.float32, device=dev)
+                out["recon"] = torch.empty(b, t, kc, h, w, dtype=torch.float32, device=dev)
         if b == 0:                                        # an empty batch gives empty outputs, as the reference's modules do
             return out
         with torch.cuda.device(dev):
-            hip.check(l.vad_vid_score_x(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, b, t, h, w, *dims,
+            hip.check(l.vad_vid_score_c(x.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, kc, b, t, h, w, *dims,
                                         packed.data_ptr(), ws.data_ptr(), ws.numel(),
                                       chunk, hip.ptr(out.get("seq")), hip.ptr(out.get("frame")),
                                       hip.ptr(out.get("errmap")), hip.ptr(out.get("recon")), hip.current_stream()),
@@ -248,7 +251,7 @@ class VideoAutoencoder(nn.Module):
         """Undo the 3-plane view of a 1- / 2-channel model (`_HipScorer.widen_to_rgb`): the kernels averaged over 3
         planes of which 3 - in_channels are exactly zero."""
         cin = self.in_channels
-        if cin == 3:
+        if cin >= 3:
             return out
         out = dict(out)
         for k in ("seq", "frame", "errmap"):
@@ -318,7 +321,8 @@ class VideoAutoencoder(nn.Module):
         frames = _HipScorer.widen_input(frames, cin, u8)
         chunk = max(1, min(int(self.window_chunk), nw))
         dims = (self.latent_dim, self.lstm_hidden_dim, self.lstm_num_layers)
-        nbytes = l.vad_vid_windows_workspace_bytes(chunk, t, int(stride), h, w, *dims)
+        kc = _HipScorer.kernel_channels(cin)
+        nbytes = l.vad_vid_windows_workspace_bytes_c(chunk, t, int(stride), h, w, *dims, kc)
         if nbytes == 0:
             raise hip.VadError(f"unsupported frame size {h}x{w}: H and W must be multiples of 16")
         ws = self._hip.workspace(nbytes, dev)
@@ -327,9 +331,9 @@ class VideoAutoencoder(nn.Module):
         if errmap:
             out["errmap"] = torch.empty(nw, t, 1, h, w, dtype=torch.float32, device=dev)
         if recon:
-            out["recon"] = torch.empty(nw, t, 3, h, w, dtype=torch.float32, device=dev)
+            out["recon"] = torch.empty(nw, t, kc, h, w, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(l.vad_vid_score_windows_x(frames.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, f, t,
+            hip.check(l.vad_vid_score_windows_c(frames.data_ptr(), hip.X_U8_NHWC if u8 else hip.X_F32_NCHW, self._hip.mode, kc, f, t,
                                                 int(stride), h, w, *dims, packed.data_ptr(),
                                               ws.data_ptr(), ws.numel(), chunk, out["seq"].data_ptr(),
                                               out["frame"].data_ptr(), hip.ptr(out.get("errmap")),
