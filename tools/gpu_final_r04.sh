@@ -31,7 +31,13 @@ done
 rm -rf $R/$O/${T}_trace_train
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${T}_trace_train -- python3 $R/tools/train_bench.py --clips 32 --steps 5 --warmup 2 --precision bf16 > $R/$O/${T}_trace_train.json 2> $R/$O/${T}_trace_train.err
 f=$(find $R/$O/${T}_trace_train -name "*kernel_stats.csv" | head -1); cp $f $R/$O/${T}_kernel_stats_train_bf16.csv && echo "trace train done"
+for prec in fp32 split; do
+  rm -rf $R/$O/${T}_trace_train_$prec
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${T}_trace_train_$prec -- python3 $R/tools/train_bench.py --clips 32 --steps 5 --warmup 2 --precision $prec > $R/$O/${T}_trace_train_$prec.json 2> $R/$O/${T}_trace_train_$prec.err
+  f=$(find $R/$O/${T}_trace_train_$prec -name "*kernel_stats.csv" | head -1); cp $f $R/$O/${T}_kernel_stats_train_$prec.csv && echo "trace train $prec done"
+done
 cd $R
+timeout -k 10 300 python tools/wgrad_bench.py > $O/${T}_wgrad_kernel_forms.txt 2>/dev/null && echo "wgrad forms done"
 bash tools/pmc_mfma.sh ${T}_image > /dev/null 2>&1 && echo "mfma image done"
 bash tools/pmc_mfma.sh ${T}_winograd --precision winograd > /dev/null 2>&1 && echo "mfma winograd done"
 bash tools/pmc_mfma.sh ${T}_video --workload video > /dev/null 2>&1 && echo "mfma video done"
