@@ -41,6 +41,9 @@ timeout -k 10 300 python tools/wgrad_bench.py > $O/${T}_wgrad_kernel_forms.txt 2
 bash tools/pmc_mfma.sh ${T}_image > /dev/null 2>&1 && echo "mfma image done"
 bash tools/pmc_mfma.sh ${T}_winograd --precision winograd > /dev/null 2>&1 && echo "mfma winograd done"
 bash tools/pmc_mfma.sh ${T}_video --workload video > /dev/null 2>&1 && echo "mfma video done"
+( cd /tmp && rm -rf $R/$O/pmc_mfma_${T}_train_bf16 && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE \
+    --kernel-trace --output-format csv -d $R/$O/pmc_mfma_${T}_train_bf16 -- python3 $R/tools/train_bench.py --clips 32 --steps 2 --warmup 1 --precision bf16 > /dev/null 2>&1 ) \
+  && python3 tools/pmc_mfma_summary.py $O/pmc_mfma_${T}_train_bf16 > $O/pmc_mfma_${T}_train_bf16.json && echo "mfma train bf16 done"
 bash tools/pmc_traffic.sh > /dev/null 2>&1 && cp gpurun_out/pmc_traffic.json gpurun_out/${T}_pmc_traffic_image.json && echo "traffic image done"
 bash tools/pmc_traffic.sh --workload video > /dev/null 2>&1 && cp gpurun_out/pmc_traffic.json gpurun_out/${T}_pmc_traffic_video.json && echo "traffic video done"
 ls gpurun_out | grep "${T}_" | grep -v trace_ | head -30

@@ -1725,35 +1725,40 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_lds_kernel(WgradC3P p) {
 //   layout 4: Conv2d k1 OIHW         dst[col*cin + ci]                                 (taps 1)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int splits, int taps, int cin, int ncols, int layout,
                                                            float* dst) {
-    // 64 consecutive elements x 4 slices of the split range per work-group; slice sums combined in a fixed order
-    __shared__ float part[4][64];
-    const long long total = (long long)taps * cin * ncols;
+    // 256 consecutive elements (four per lane: a wave reads 1 KB of one partial slot per load) x 4 slices of the split range per
+    // work-group (slot k belongs to slice k % 4); a slice adds its slots in increasing order, the slice sums are combined in a
+    // fixed order.  Eight slots in flight per thread.  (Round 4: one element per lane made every load a 256-byte request -
+    // 0.68 ms per bf16 training step for ~350 MB of partials; the sums and their order are unchanged.)
+    __shared__ f32x4 part[4][64];
+    const long long total = (long long)taps * cin * ncols;          // a multiple of 4 (cin and ncols are multiples of 32)
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + e;
-    float s = 0.f;
+    const long long idx = ((long long)blockIdx.x * 64 + e) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (idx < total) {
-        // four partials in flight per thread, added in the same order (one at a time the pass was a chain of memory round trips:
-        // 0.93 ms per training step for ~1.2 GB of partials)
         int k = sl;
-        for (; k + 12 < splits; k += 16) {
-            float v[4];
+        for (; k + 28 < splits; k += 32) {
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ws[(size_t)(k + 4 * u) * total + idx];
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(ws + (size_t)(k + 4 * u) * total + idx);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; k < splits; k += 4) s += ws[(size_t)k * total + idx];
+        for (; k < splits; k += 4) s += *(const f32x4*)(ws + (size_t)k * total + idx);
     }
     part[sl][e] = s;
     __syncthreads();
     if (sl != 0 || idx >= total) return;
     s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-    const int col = (int)(idx % ncols), ci = (int)((idx / ncols) % cin), tap = (int)(idx / ((long long)ncols * cin));
-    if (layout == 0) dst[((size_t)col * cin + ci) * 9 + tap] = s;
-    else if (layout == 1) { const int cout = ncols / 4, q = col / cout, co = col - q * cout; dst[((size_t)ci * cout + co) * 4 + q] = s; }
-    else if (layout == 2) { if (ci < 27) dst[(size_t)col * 27 + ci] = s; }
-    else if (layout == 4) dst[(size_t)col * cin + ci] = s;
-    else if (col < 12) { const int q = col / 3, c = col - q * 3; dst[((size_t)ci * 3 + c) * 4 + q] = s; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long id = idx + j;
+        const int col = (int)(id % ncols), ci = (int)((id / ncols) % cin), tap = (int)(id / ((long long)ncols * cin));
+        if (layout == 0) dst[((size_t)col * cin + ci) * 9 + tap] = s[j];
+        else if (layout == 1) { const int cout = ncols / 4, q = col / cout, co = col - q * cout; dst[((size_t)ci * cout + co) * 4 + q] = s[j]; }
+        else if (layout == 2) { if (ci < 27) dst[(size_t)col * 27 + ci] = s[j]; }
+        else if (layout == 4) dst[(size_t)col * cin + ci] = s[j];
+        else if (col < 12) { const int q = col / 3, c = col - q * 3; dst[((size_t)ci * 3 + c) * 4 + q] = s[j]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ last layer + loss
@@ -2369,7 +2374,9 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
     // LDS-staged work-group tiles: 3x3 layers with 128-channel tiles (the 64-channel form has half the waves per tile and its
     // 192 accumulators + staging registers spill: 0.85 ms against 0.38 ms of the per-wave kernel on enc.8), 1x1 / transposed
     // layers with 64- or 128-channel tiles
-    const bool lds_ok = ncols % 128 == 0 && (taps == 9 ? (cin % 128 == 0 || (cin % 64 == 0 && w > 16)) : cin % 64 == 0);
+    // (1x1 / transposed layers with 64-channel tiles: 136 us against 111 us of the per-wave kernel on the 64 -> 4 x 32 @ 64x64 layer,
+    // which is the HBM time of its 0.5 GB - profiles/r04_wgrad_kernel_forms.txt)
+    const bool lds_ok = ncols % 128 == 0 && (taps == 9 ? (cin % 128 == 0 || (cin % 64 == 0 && w > 16)) : cin % 128 == 0);
     {   // row-ring kernels (3x3 layers; bf16 tensors and split-fp16)
         const bool ring16 = precision == VAD_PREC_BF16S && g_wgrad_x2.load(std::memory_order_relaxed) >= 3;
         const bool ring32 = precision == VAD_PREC_SPLIT && g_wgrad_split.load(std::memory_order_relaxed) >= 3;
@@ -2399,7 +2406,7 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
 #undef WRL
             VAD_LAUNCH_CHECK();
             const long long total5 = 9ll * cin * ncols;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total5 + 63) / 64)), dim3(256), 0, s5, (const float*)ws, (int)slots, taps, cin, ncols, layout, dw);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total5 + 255) / 256)), dim3(256), 0, s5, (const float*)ws, (int)slots, taps, cin, ncols, layout, dw);
             VAD_LAUNCH_CHECK();
             return VAD_OK;
         }
@@ -2433,7 +2440,7 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
 #undef WGL
         VAD_LAUNCH_CHECK();
         const long long total3 = (long long)taps * cin * ncols;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total3 + 63) / 64)), dim3(256), 0, s3, (const float*)ws, p.splits * ps, taps, cin, ncols, layout, dw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0, s3, (const float*)ws, p.splits * ps, taps, cin, ncols, layout, dw);
         VAD_LAUNCH_CHECK();
         return VAD_OK;
     }
@@ -2457,7 +2464,7 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
 #undef WSL
         VAD_LAUNCH_CHECK();
         const long long total4 = (long long)taps * cin * ncols;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s4, (const float*)ws, p.splits * ps, taps, cin, ncols, layout, dw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s4, (const float*)ws, p.splits * ps, taps, cin, ncols, layout, dw);
         VAD_LAUNCH_CHECK();
         return VAD_OK;
     }
@@ -2478,7 +2485,7 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
         else hipLaunchKernelGGL(conv_wgrad_bf16x2_kernel<1>, dim3((unsigned)((items2 + 3) / 4)), dim3(256), 0, s2, p);
         VAD_LAUNCH_CHECK();
         const long long total2 = (long long)taps * cin * ncols;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total2 + 63) / 64)), dim3(256), 0, s2, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, s2, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
         VAD_LAUNCH_CHECK();
         return VAD_OK;
     }
@@ -2512,7 +2519,7 @@ extern "C" int vad_conv_wgrad(const float* a, const float* g, float* dw, float* 
 #undef WG16
     VAD_LAUNCH_CHECK();
     const long long total = (long long)taps * cin * ncols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ws, p.splits, taps, cin, ncols, layout, dw);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
@@ -2550,7 +2557,7 @@ int vad_conv_c3_wgrad_t(const float* x_nchw, const void* g, int io16, float* dw,
         else hipLaunchKernelGGL(conv_c3_wgrad_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p);
     }
     VAD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((32ll * cout + 63) / 64)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((32ll * cout + 255) / 256)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }
