@@ -245,6 +245,7 @@ struct BnBwdP {     // y / dout / dy: fp32 or bf16 (the kernels' storage type)
     int n, h, w, c, act, pool;
     long long opix, chunk;   // pooled-resolution pixels (n*oh*ow), per block
     unsigned char* dec;   // debug (nullable): [opix][c] bytes, bits 0-1 = pooling argmax (window scan order), bit 2 = value > 0
+    unsigned char* codes; // nullable: the same bytes as an OUTPUT of pass A (the routed first-layer weight gradient reads them)
 };
 
 __device__ __forceinline__ float act_grad(float v, int act) {
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(BnBwdP p) {
                 const float y4[4] = {yv[0][e], yv[1][e], yv[2][e], yv[3][e]};
                 const Routed r = bn_route(y4, nwin, mean[e], invstd[e], gamma[e], beta[e], g[e], ACT);
                 if (p.dec) p.dec[q * p.c + 4 * c4 + e] = (unsigned char)(r.am | (r.v > 0.f ? 4 : 0));
+                if (p.codes) p.codes[q * p.c + 4 * c4 + e] = (unsigned char)(r.am | (r.v > 0.f ? 4 : 0));
                 s0[e] += r.gz;
                 s1[e] += r.gz * r.xh;
             }
@@ -1717,6 +1719,139 @@ __global__ __launch_bounds__(256) void conv_c3_wgrad_lds_kernel(WgradC3P p) {
     }
 }
 
+// ROUTED first-layer weight gradient (bf16-tensor mode, round 4).  The first layer's conv-output gradient dy has ONE consumer -
+// this weight gradient - and BatchNorm's backward makes it dense: dy = sc (dz - k1 - xhat k2), sc = gamma invstd, with dz the routed
+// gradient (non-zero at the pooling argmax of each 2x2 window only).  Writing dy (1.3 GB of bf16 at 320 x 256x256) and reading it
+// back was 1.2 of the step's 10.1 ms.  With X[p][k] the 27 taps of pixel p and y = W X + b the layer's own output,
+//     dW[co][k] = sc ( T1[k][co] - k1 SX[k] - k2 invstd ( (W S)[co][k] + (b - mean) SX[k] ) ),
+//     T1 = sum_p dz[p][co] X[p][k],   S = X^T X (the Gram matrix of the input patches),   SX[k] = sum_p X[p][k]:
+// the xhat term needs no pass over y at all, and T1 is a GEMM over the POOLED gradient: this kernel reads the pooled d(out)
+// (bf16), one byte of routing code per pooled element (pass A of the BatchNorm backward writes it: argmax position and sign)
+// and the input planes - 0.76 GB instead of 4.6 - and never forms dy.  bf16 MFMAs (the mode's arithmetic for every other
+// layer's gradients): A = the taps of 16 pixels (fp32 planes rounded as they are packed; row 27 is the constant 1 so that column
+// 27 of S is SX), B = the routed gradient for T1 and A itself for S.  A wave owns a slice of ROW PAIRS (one pooled row) and keeps
+// the four input rows x three planes, the pooled gradient row and its codes in its own LDS region (coalesced 16-byte loads, one
+// pair ahead in registers).  vad_conv_c3_wgrad_routed reduces the partials and applies the formula above.
+struct WgradC3RP {
+    const float* x; const vad_bf16* dout; const unsigned char* codes; float* ws;
+    int n, h, w, splits, pairs_per_split;
+    unsigned nitems;
+};
+
+template <int MAXQ>      // W <= 256 MAXQ, W % 16 == 0, H even
+__global__ __launch_bounds__(128) void conv_c3_wgrad_routed_kernel(WgradC3RP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    const int lane = threadIdx.x & 63, li = lane & 31, kb = lane >> 5, wave = threadIdx.x >> 6;
+    const unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 2 + wave);
+    if (item >= p.nitems) return;
+    const int H = p.h, W = p.w, OW = W / 2, RS = W + 12, W4 = W / 4;           // RS: floats per staged input row (data at float 4)
+    const int total_pairs = p.n * (H / 2);
+    const int r0 = item * p.pairs_per_split, r1 = (r0 + p.pairs_per_split < total_pairs) ? r0 + p.pairs_per_split : total_pairs;
+    const size_t region = (size_t)12 * RS * 4 + (size_t)OW * 64 + (size_t)OW * 32;
+    float* xs = (float*)(dyn_lds + (size_t)wave * region);                         // [plane c][row d = 0..3 <-> 2r - 1 + d][RS]
+    vad_bf16* ds = (vad_bf16*)(dyn_lds + (size_t)wave * region + (size_t)12 * RS * 4);        // [OW][32]
+    unsigned char* cs = dyn_lds + (size_t)wave * region + (size_t)12 * RS * 4 + (size_t)OW * 64;   // [OW][32]
+    // lane constants: tap li of the A operand (rows 28..31 are zero, row 27 is the constant one)
+    const int kc = li < 27 ? li / 9 : 0, kt = li < 27 ? li - kc * 9 : 0, kdy = kt / 3 - 1, kdx = kt % 3 - 1;
+    const int abase = (kc * 4 + kdy + 1) * RS + 4 + kdx + 8 * kb;                   // + yy * RS + x0 + j
+    f32x16 accT, accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accT[r] = 0.f; accS[r] = 0.f; }
+    for (int q = lane; q < 24; q += 64) xs[(q >> 1) * RS + ((q & 1) ? 4 + W : 3)] = 0.f;     // the zero columns left and right of every row
+
+    constexpr int JD = 8 * MAXQ, JC = 4 * MAXQ;
+    f32x4 sx[12][MAXQ];
+    u32x4 sd[JD], sc_[JC];
+    const int dchunks = OW * 4, cchunks = OW * 2;                                // 16-byte chunks of the gradient row / the code row
+    auto fetch = [&](int pr) {
+        const int n = pr / (H / 2), r = pr - n * (H / 2);
+        const float* fx = p.x + (size_t)n * 3 * H * W;
+#pragma unroll
+        for (int s12 = 0; s12 < 12; ++s12) {
+            const int yy = 2 * r - 1 + (s12 & 3);
+            const bool rok = yy >= 0 && yy < H;                                  // (uniform)
+            const float* src = fx + ((size_t)(s12 >> 2) * H + (rok ? yy : 0)) * W;
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) {
+                const int q = lane + 64 * j;
+                sx[s12][j] = (rok && q < W4) ? *(const f32x4*)(src + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const u32x4* gd = (const u32x4*)(p.dout + ((size_t)n * (H / 2) + r) * OW * 32);
+        const u32x4* gc = (const u32x4*)(p.codes + ((size_t)n * (H / 2) + r) * OW * 32);
+#pragma unroll
+        for (int j = 0; j < JD; ++j) { const int q = lane + 64 * j; sd[j] = q < dchunks ? gd[q] : u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+        for (int j = 0; j < JC; ++j) { const int q = lane + 64 * j; sc_[j] = q < cchunks ? gc[q] : u32x4{0u, 0u, 0u, 0u}; }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int s12 = 0; s12 < 12; ++s12)
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) { const int q = lane + 64 * j; if (q < W4) *(f32x4*)&xs[s12 * RS + 4 + 4 * q] = sx[s12][j]; }
+#pragma unroll
+        for (int j = 0; j < JD; ++j) { const int q = lane + 64 * j; if (q < dchunks) ((u32x4*)ds)[q] = sd[j]; }
+#pragma unroll
+        for (int j = 0; j < JC; ++j) { const int q = lane + 64 * j; if (q < cchunks) ((u32x4*)cs)[q] = sc_[j]; }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int pr = r0; pr < r1; ++pr) {
+        store();                                                 // (behind every read of the previous pair: LDS operations of a wave execute in order)
+        if (pr + 1 < r1) fetch(pr + 1);
+        for (int x0 = 0; x0 < W; x0 += 16) {
+            // the four windows of this lane's eight pixels: gradient and code of ITS column
+            float dv[4];
+            unsigned cv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int wx = (x0 + 8 * kb) / 2 + j;
+                dv[j] = vad_bf16_f(ds[wx * 32 + li]);
+                cv[j] = cs[wx * 32 + li];
+            }
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                float av[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = xs[abase + yy * RS + x0 + j];
+                if (li >= 27) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = li == 27 ? 1.f : 0.f;
+                }
+                wg_bf16x8 af, bf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    af[j] = (__bf16)av[j];
+                    const unsigned c = cv[j >> 1];
+                    const float g = ((c & 3u) == (unsigned)(2 * yy + (j & 1))) ? dv[j >> 1] * ((c & 4u) ? 1.f : 0.2f) : 0.f;
+                    bf[j] = (__bf16)g;
+                }
+                accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, accT, 0, 0, 0);
+                accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, af, accS, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * kb;
+        p.ws[((size_t)item * 64 + k) * 32 + li] = accT[r];                        // rows 0..31: T1[k][co]
+        p.ws[((size_t)item * 64 + 32 + k) * 32 + li] = accS[r];                   // rows 32..63: S[k][k']
+    }
+}
+
+// tmp[col][64]: T1[k][co] at [co][k], S[k][k'] at [k'][32 + k] (wgrad_reduce_kernel layout 4 of the [64][32] partial tiles)
+__global__ __launch_bounds__(256) void c3_routed_finalize_kernel(const float* tmp, const float* w0, const float* b0, const float* stats,
+                                                                 const float* gamma, const float* ksums, float* dw) {
+    for (int idx = threadIdx.x; idx < 32 * 27; idx += 256) {
+        const int co = idx / 27, k = idx - co * 27;
+        const float mean = stats[co], invstd = stats[32 + co], k1 = ksums[co], k2 = ksums[32 + co];
+        const float sx = tmp[27 * 64 + 32 + k];                                   // S[k][27] = SX[k]
+        float ws_ = 0.f;
+        for (int kk = 0; kk < 27; ++kk) ws_ = fmaf(vad_bf16_f(vad_f_bf16(w0[co * 27 + kk])), tmp[k * 64 + 32 + kk], ws_);   // (W S)[co][k]: S[kk][k] sits at tmp[k][32 + kk]
+        const float v = invstd * (ws_ + (b0[co] - mean) * sx);
+        dw[co * 27 + k] = gamma[co] * invstd * (tmp[co * 64 + k] - k1 * sx - k2 * v);
+    }
+}
+
 // Fixed-order sum of the split-K partials, written in the torch parameter layout.
 //   layout 0: Conv2d OIHW            dst[(col*cin + ci)*9 + tap]                       (taps 9)
 //   layout 1: ConvTranspose2d IOHW   col = q*cout + co -> dst[(ci*cout + co)*4 + q]    (taps 1, ncols = 4*cout)
@@ -2189,7 +2324,18 @@ int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const flo
                           long long dout_fs, int dout_ps, int remap_t, int remap_b, void* dy, int s2d,
                           float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
                           int pool, void* stream) {
-    VAD_REQUIRE(y && stats && gamma && beta && dout && dy && dgamma && dbeta && ksums && ws, "bn_act_pool_bwd: null pointer");
+    return vad_bn_act_pool_bwd_codes_t(y, io16, stats, gamma, beta, dout, dout_fs, dout_ps, remap_t, remap_b, dy, s2d, dgamma, dbeta, ksums, ws,
+                                       n, h, w, c, act, pool, nullptr, stream);
+}
+
+// codes != NULL: pass A (the sums, dgamma / dbeta, k1 / k2) ONLY, and it also writes one routing byte per pooled element -
+// argmax position | sign << 2 - to `codes` ([n * oh * ow][c]); dy is not touched (may be NULL).  For a layer whose dy has a
+// single consumer that can work from the routed gradient: vad_conv_c3_wgrad_routed.
+int vad_bn_act_pool_bwd_codes_t(const void* y, int io16, const float* stats, const float* gamma, const float* beta, const void* dout,
+                                long long dout_fs, int dout_ps, int remap_t, int remap_b, void* dy, int s2d,
+                                float* dgamma, float* dbeta, float* ksums, float* ws, int n, int h, int w, int c, int act,
+                                int pool, unsigned char* codes, void* stream) {
+    VAD_REQUIRE(y && stats && gamma && beta && dout && (dy || codes) && dgamma && dbeta && ksums && ws, "bn_act_pool_bwd: null pointer");
     VAD_REQUIRE(n > 0 && h > 0 && w > 0 && chan_ok(c) && act >= 0 && act <= 2, "bn_act_pool_bwd: bad arguments");
     VAD_REQUIRE(!pool || (h % 2 == 0 && w % 2 == 0), "bn_act_pool_bwd: pooling needs even H, W");
     VAD_REQUIRE(!s2d || (!pool && h % 2 == 0 && w % 2 == 0), "bn_act_pool_bwd: space-to-depth output is for un-pooled layers with even H, W");
@@ -2206,6 +2352,7 @@ int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const flo
     VAD_REQUIRE(p.opix * (c / 4) < (1ll << 31), "bn_act_pool_bwd: %lld items are too many for the kernels' 32-bit index arithmetic", p.opix * (c / 4));
     p.chunk = stats_chunk(p.opix);
     p.dec = nullptr;
+    p.codes = codes;
     if (g_dec_buf) {
         const size_t need = (size_t)p.opix * c;
         VAD_REQUIRE(g_dec_used + need <= g_dec_cap, "bn_act_pool_bwd: decision buffer too small (%zu + %zu > %zu)", g_dec_used, need, g_dec_cap);
@@ -2221,6 +2368,7 @@ int vad_bn_act_pool_bwd_t(const void* y, int io16, const float* stats, const flo
                        (double)n * h * w, 1, 0.f, 0.f, ksums, (float*)nullptr, (float*)nullptr, dgamma, dbeta, (const float*)nullptr);
     VAD_LAUNCH_CHECK();
     p.dec = nullptr;
+    if (codes) return VAD_OK;                     // pass A only
     if (io16 && c % 8 == 0 && p.dout_ps % 8 == 0 && p.dout_fs % 8 == 0 && g_bn_wide.load(std::memory_order_relaxed)) {
         BN8_DISPATCH(bn_bwd_apply8_kernel, dim3(grid_for(p.opix * (c / 8))), s)
     } else
@@ -2558,6 +2706,49 @@ int vad_conv_c3_wgrad_t(const float* x_nchw, const void* g, int io16, float* dw,
     }
     VAD_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((32ll * cout + 255) / 256)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 32, cout, 2, dw);
+    VAD_LAUNCH_CHECK();
+    return VAD_OK;
+}
+
+// Routed first-layer weight gradient (see conv_c3_wgrad_routed_kernel): ws = [splits][64][32] partial tiles + [32][64] reduced.
+static int c3_routed_splits(int n, int h) { return wgrad_splits(1, n * (h / 2)); }
+size_t vad_conv_c3_wgrad_routed_ws_floats(int n, int h) {
+    if (n <= 0 || h <= 0 || h % 2) return 0;
+    return (size_t)c3_routed_splits(n, h) * 2048 + 2048;
+}
+static std::atomic<int> g_c3_routed{1};          // debug / A-B: 0 = BatchNorm backward pass B + the plain first-layer weight gradient (rounds 1-3)
+extern "C" int vad_debug_set_c3_routed(int on) { g_c3_routed = on != 0; return VAD_OK; }
+int vad_c3_routed_enabled(void) { return g_c3_routed.load(std::memory_order_relaxed); }
+int vad_conv_c3_wgrad_routed_ok(int h, int w, int cout) { return cout == 32 && h % 2 == 0 && w % 16 == 0 && w <= 1024; }
+
+int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout_bf16, const unsigned char* codes, const float* w0, const float* b0,
+                             const float* stats, const float* gamma, const float* ksums, float* dw, float* ws, int n, int h, int w,
+                             int cout, void* stream) {
+    VAD_REQUIRE(x_nchw && dout_bf16 && codes && w0 && b0 && stats && gamma && ksums && dw && ws && n > 0, "conv_c3_wgrad_routed: bad arguments");
+    VAD_REQUIRE(vad_conv_c3_wgrad_routed_ok(h, w, cout), "conv_c3_wgrad_routed: needs 32 output channels, even H, W %% 16 == 0 and W <= 1024 (got %dx%d, %d)", h, w, cout);
+    WgradC3RP p{};
+    p.x = x_nchw; p.dout = (const vad_bf16*)dout_bf16; p.codes = codes; p.ws = ws; p.n = n; p.h = h; p.w = w;
+    const int total_pairs = n * (h / 2);
+    p.splits = c3_routed_splits(n, h);
+    p.pairs_per_split = (total_pairs + p.splits - 1) / p.splits;
+    p.splits = (total_pairs + p.pairs_per_split - 1) / p.pairs_per_split;
+    p.nitems = (unsigned)p.splits;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 2 * ((size_t)12 * (w + 12) * 4 + (size_t)(w / 2) * 96);
+    VAD_REQUIRE(lds <= 64 * 1024 || w > 256, "conv_c3_wgrad_routed: internal error: %zu B of LDS", lds);
+    const dim3 grid((unsigned)((p.splits + 1) / 2));
+    if (w <= 256) hipLaunchKernelGGL(conv_c3_wgrad_routed_kernel<1>, grid, dim3(128), lds, s, p);
+    else {
+        static bool attr_set = false;              // > 64 KB of dynamic LDS needs the attribute once per process
+        if (!attr_set) { VAD_HIP_TRY(hipFuncSetAttribute((const void*)conv_c3_wgrad_routed_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        VAD_REQUIRE(lds <= 160 * 1024, "conv_c3_wgrad_routed: frame too wide");
+        hipLaunchKernelGGL(conv_c3_wgrad_routed_kernel<4>, grid, dim3(128), lds, s, p);
+    }
+    VAD_LAUNCH_CHECK();
+    float* tmp = ws + (size_t)p.splits * 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2048 + 255) / 256)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 64, 32, 4, tmp);
+    VAD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(c3_routed_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)tmp, w0, b0, stats, gamma, ksums, dw);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

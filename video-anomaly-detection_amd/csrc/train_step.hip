@@ -109,6 +109,7 @@ bool make_plan(Plan& p, int B, int T, int H, int W, int L, int Hd, int NL) {
         chan((long long)N * hk * wk, co);
         const size_t wg = k == 0 ? vad_conv_c3_wgrad_ws_floats(p.N, hk, co) : vad_conv_wgrad_ws_floats(p.N, hk, 9, ci, co);
         if (wg > max_wgrad) max_wgrad = wg;
+        if (k == 0 && vad_conv_c3_wgrad_routed_ws_floats(p.N, hk) > max_wgrad) max_wgrad = vad_conv_c3_wgrad_routed_ws_floats(p.N, hk);
     }
     for (int l = 0; l < NL; ++l) {
         const int cin = p.lstm_cin(l) + Hd;
@@ -537,8 +538,14 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     for (int k = 3; k >= 0; --k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         g2 = acquire_dy();
+        // bf16 tensors: the first layer's dy has one consumer, its weight gradient, which works from the POOLED gradient and one
+        // routing byte per pooled element instead (conv_c3_wgrad_routed_kernel): pass A only, no dy (its buffer holds the bytes)
+        const bool routed = k == 0 && io && vad_c3_routed_enabled() && vad_conv_c3_wgrad_routed_ok(hk, wk, co);
         { PS(TS_BN_BWD);
-        if (k == 3)
+        if (routed)
+            TRY(vad_bn_act_pool_bwd_codes_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, nullptr, 0,
+                                            G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, (unsigned char*)g2, s));
+        else if (k == 3)
             TRY(vad_bn_act_pool_bwd_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], A(p.dcat[0]), 0, L + Hd, T, B, g2, 0,
                                       G + p.e_g[k], G + p.e_be[k], ws + p.ksums, ws + p.chan_ws, N, hk, wk, co, VAD_ACT_LEAKY, 1, s));
         else
@@ -547,7 +554,11 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         }
         VAD_HIP_TRY(hipMemsetAsync(G + p.e_b[k], 0, (size_t)co * sizeof(float), s));      // structurally zero, see the decoder loop
         TRY(wg_begin());
-        if (k == 0) {
+        if (routed) {
+            PSS(TS_C3_WGRAD, wgs);
+            TRY(vad_conv_c3_wgrad_routed(x, g0, (const unsigned char*)g2, P + p.e_w[0], P + p.e_b[0], ws + p.st_e[0], P + p.e_g[0], ws + p.ksums,
+                                         G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, wgs));
+        } else if (k == 0) {
             PSS(TS_C3_WGRAD, wgs);
             TRY(vad_conv_c3_wgrad_t(x, g2, io, G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, wgs));
         } else {
