@@ -310,7 +310,7 @@ int vad_lstm_gates_bwd_t(const void* gates, int io16, const float* c_prev, const
 /* Routed first-layer weight gradient of the bf16-tensor step (round 4; csrc/train_ops.hip conv_c3_wgrad_routed_kernel): BatchNorm's
  * backward pass A with `codes` != NULL writes one routing byte per pooled element (argmax position | sign << 2) instead of running
  * pass B; vad_conv_c3_wgrad_routed then forms dW of Conv2d(3 -> 32) + BatchNorm + LeakyReLU + MaxPool2 from the POOLED gradient
- * d(out) (bf16 [n, h/2, w/2, 32]), the codes, the input planes and the layer's own weights / statistics (dW = sc (T1 - k1 SX - k2
+ * d(out) ([n, h/2, w/2, 32]: bf16 with io16, bf16 MFMAs throughout; else fp32, T1 on the exact-fp32 MFMA and S in split-fp16), the codes, the input planes and the layer's own weights / statistics (dW = sc (T1 - k1 SX - k2
  * invstd ((W S) + (b - mean) SX)), S the Gram matrix of the input patches) - the dense conv-output gradient is never formed. */
 int vad_bn_act_pool_bwd_codes_t(const void* y, int io16, const float* stats, const float* gamma, const float* beta, const void* dout,
                                 long long dout_fs, int dout_ps, int remap_t, int remap_b, void* dy, int s2d, float* dgamma,
@@ -318,7 +318,7 @@ int vad_bn_act_pool_bwd_codes_t(const void* y, int io16, const float* stats, con
                                 unsigned char* codes, void* stream);
 size_t vad_conv_c3_wgrad_routed_ws_floats(int n, int h);
 int vad_conv_c3_wgrad_routed_ok(int h, int w, int cout);
-int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout_bf16, const unsigned char* codes, const float* w0, const float* b0,
+int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout, int io16, const unsigned char* codes, const float* w0, const float* b0,
                              const float* stats, const float* gamma, const float* ksums, float* dw, float* ws, int n, int h, int w,
                              int cout, void* stream);
 int vad_debug_set_c3_routed(int on);     /* A/B: 0 = pass B + vad_conv_c3_wgrad_t (rounds 1-3); default 1 */

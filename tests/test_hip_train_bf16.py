@@ -257,7 +257,7 @@ def test_routed_first_layer_weight_gradient(vad, n, h, w):
     assert torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(ks2, ks) and int(codes.max()) <= 7
     assert l.vad_conv_c3_wgrad_routed_ok(h, w, 32) == 1
     dw_new = _nan32(32, 3, 3, 3)
-    vad.hip.check(l.vad_conv_c3_wgrad_routed(x.data_ptr(), dout16.data_ptr(), codes.data_ptr(), w0d.data_ptr(), b0d.data_ptr(), stats.data_ptr(),
+    vad.hip.check(l.vad_conv_c3_wgrad_routed(x.data_ptr(), dout16.data_ptr(), 1, codes.data_ptr(), w0d.data_ptr(), b0d.data_ptr(), stats.data_ptr(),
                                              gd.data_ptr(), ks.data_ptr(), dw_new.data_ptr(), wws.data_ptr(), n, h, w, 32, H.stream()))
     scale = float(ref.abs().max())
     e_old = float((dw_old.double().cpu() - ref).abs().max()) / scale

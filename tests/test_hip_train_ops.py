@@ -235,6 +235,65 @@ def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
     _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 32, 48), (5, 12, 80), (2, 64, 256), (1, 8, 272)])
+def test_routed_first_layer_weight_gradient_fp32(vad, n, h, w):
+    """fp32 form of the routed first-layer weight gradient (csrc/train_ops.hip conv_c3_wgrad_routed_f32_kernel; the bf16 form:
+    tests/test_hip_train_bf16.py): dW of Conv2d(3->32) + BatchNorm(batch statistics) + LeakyReLU(0.2) + MaxPool2 from the POOLED
+    gradient, one routing byte per pooled element and the Gram matrix of the input patches, against a float64 evaluation that
+    takes every decision from the stored fp32 conv output as the kernels do - and against the form it replaces (pass B + the plain
+    weight gradient), which must be no closer to float64 than a few 1e-6."""
+    import hip_helpers as H
+    l, rng = vad.hip.lib(), _rng(11 * n + h + w)
+    x = H.dev(rng.uniform(-1, 1, (n, 3, h, w)))
+    w0 = (rng.standard_normal((32, 3, 3, 3)) * 0.3).astype(np.float32)
+    b0 = (rng.standard_normal(32) * 0.1).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, 32).astype(np.float32), (rng.standard_normal(32) * 0.1).astype(np.float32)
+    dout = H.dev(rng.standard_normal((n, h // 2, w // 2, 32)) * 1e-3)
+    wp, bo = H.pack_conv3x3(w0, b0)
+    y = torch.full((n, h, w, 32), float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv3x3_c3(x.data_ptr(), wp.data_ptr(), bo.data_ptr(), y.data_ptr(), n, h, w, 32, 0, 0, H.stream()))
+    stats, cws = _ws(64), _ws(l.vad_chan_ws_floats(n * h * w, 32))
+    vad.hip.check(l.vad_bn_stats(y.data_ptr(), n * h * w, 32, 1e-5, 0.1, stats.data_ptr(), None, None, cws.data_ptr(), H.stream()))
+    mean, invstd = stats[:32].double().cpu(), stats[32:].double().cpu()
+    g64, be64 = torch.from_numpy(gamma).double(), torch.from_numpy(beta).double()
+    yq = y.double().cpu().permute(0, 3, 1, 2)
+    xhat = (yq - mean[None, :, None, None]) * invstd[None, :, None, None]
+    zq = F.leaky_relu(xhat * g64[None, :, None, None] + be64[None, :, None, None], 0.2)
+    zz = zq.view(n, 32, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, 32, h // 2, w // 2, 4)
+    am = zz.argmax(-1)
+    val = zz.gather(-1, am[..., None])[..., 0]
+    gz = dout.double().cpu().permute(0, 3, 1, 2) * torch.where(val > 0, 1.0, 0.2)
+    dz = torch.zeros(n, 32, h // 2, w // 2, 4, dtype=torch.float64).scatter_(-1, am[..., None], gz[..., None])
+    dz = dz.view(n, 32, h // 2, w // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, 32, h, w)
+    m_ = n * h * w
+    k1, k2 = dz.sum((0, 2, 3)) / m_, (dz * xhat).sum((0, 2, 3)) / m_
+    dy = (g64 * invstd)[None, :, None, None] * (dz - k1[None, :, None, None] - xhat * k2[None, :, None, None])
+    X = F.unfold(x.double().cpu(), 3, padding=1).permute(0, 2, 1).reshape(-1, 27)
+    ref = (dy.permute(0, 2, 3, 1).reshape(-1, 32).t() @ X).reshape(32, 3, 3, 3)
+    gd, bd, w0d, b0d = H.dev(gamma), H.dev(beta), H.dev(w0), H.dev(b0)
+    dg, db, ks = _ws(32), _ws(32), _ws(64)
+    dyd = torch.full((n, h, w, 32), float("nan"), device="cuda")
+    vad.hip.check(l.vad_bn_act_pool_bwd(y.data_ptr(), stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), dout.data_ptr(), 0, 0, 0, 0,
+                                        dyd.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), ks.data_ptr(), cws.data_ptr(), n, h, w, 32, 1, 1, H.stream()))
+    wws = _ws(max(l.vad_conv_c3_wgrad_ws_floats(n, h, 32), l.vad_conv_c3_wgrad_routed_ws_floats(n, h)))
+    dw_old = torch.full((32, 3, 3, 3), float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv_c3_wgrad(x.data_ptr(), dyd.data_ptr(), dw_old.data_ptr(), wws.data_ptr(), n, h, w, 32, H.stream()))
+    codes = torch.full((n * (h // 2) * (w // 2), 32), 255, dtype=torch.uint8, device="cuda")
+    dg2, db2, ks2 = _ws(32), _ws(32), _ws(64)
+    vad.hip.check(l.vad_bn_act_pool_bwd_codes_t(y.data_ptr(), 0, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), dout.data_ptr(), 0, 0, 0, 0,
+                                                None, 0, dg2.data_ptr(), db2.data_ptr(), ks2.data_ptr(), cws.data_ptr(), n, h, w, 32, 1, 1,
+                                                codes.data_ptr(), H.stream()))
+    assert torch.equal(ks2, ks) and torch.equal(dg2, dg) and int(codes.max()) <= 7
+    dw_new = torch.full((32, 3, 3, 3), float("nan"), device="cuda")
+    vad.hip.check(l.vad_conv_c3_wgrad_routed(x.data_ptr(), dout.data_ptr(), 0, codes.data_ptr(), w0d.data_ptr(), b0d.data_ptr(), stats.data_ptr(),
+                                             gd.data_ptr(), ks.data_ptr(), dw_new.data_ptr(), wws.data_ptr(), n, h, w, 32, H.stream()))
+    scale = float(ref.abs().max())
+    e_old = float((dw_old.double().cpu() - ref).abs().max()) / scale
+    e_new = float((dw_new.double().cpu() - ref).abs().max()) / scale
+    print(f"first-layer dW (fp32) vs float64 ({n}x{h}x{w}): routed {e_new:.2e}, pass B + plain {e_old:.2e} of max |dW|")
+    assert bool(torch.isfinite(dw_new).all()) and e_new < 2e-6 and e_old < 2e-6, (e_new, e_old)
+
+
 @pytest.mark.parametrize("n,h,w,cin,ncols,taps", [(2, 24, 40, 64, 64, 9), (3, 12, 33, 32, 64, 9), (2, 16, 16, 128, 256, 9), (5, 7, 20, 64, 128, 9),
                                                   (2, 9, 64, 32, 128, 9), (7, 5, 70, 64, 64, 9), (2, 24, 40, 64, 256, 1), (3, 12, 33, 32, 128, 1), (4, 16, 16, 128, 128, 1)])
 def test_split_weight_gradient_kernel_forms(vad, n, h, w, cin, ncols, taps):

@@ -1838,15 +1838,128 @@ __global__ __launch_bounds__(128) void conv_c3_wgrad_routed_kernel(WgradC3RP p) 
     }
 }
 
+// The same for fp32 tensors (the exact, split-fp16 and Winograd steps): T1 on the exact-fp32 MFMA (32x32x2: lane half lh supplies
+// pixel x + lh of a pair, i.e. ONE column of a pooling window), the Gram matrix S - a property of the input frames alone - in
+// split-fp16 arithmetic (22-bit products, three 32x32x16 MFMAs per 16 pixels: an exact-fp32 S would double the kernel's matrix
+// work for a correction term).  d(out) is fp32 [n, h/2, w/2, 32].
+struct WgradC3RFP {
+    const float* x; const float* dout; const unsigned char* codes; float* ws;
+    int n, h, w, splits, pairs_per_split;
+    unsigned nitems;
+};
+
+template <int MAXQ>
+__global__ __launch_bounds__(128) void conv_c3_wgrad_routed_f32_kernel(WgradC3RFP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
+    const unsigned item = __builtin_amdgcn_readfirstlane(blockIdx.x * 2 + wave);
+    if (item >= p.nitems) return;
+    const int H = p.h, W = p.w, OW = W / 2, RS = W + 12, W4 = W / 4;
+    const int total_pairs = p.n * (H / 2);
+    const int r0 = item * p.pairs_per_split, r1 = (r0 + p.pairs_per_split < total_pairs) ? r0 + p.pairs_per_split : total_pairs;
+    const size_t region = (size_t)12 * RS * 4 + (size_t)OW * 128 + (size_t)OW * 32;
+    float* xs = (float*)(dyn_lds + (size_t)wave * region);
+    const float* ds = (const float*)(dyn_lds + (size_t)wave * region + (size_t)12 * RS * 4);          // [OW][32]
+    const unsigned char* cs = dyn_lds + (size_t)wave * region + (size_t)12 * RS * 4 + (size_t)OW * 128;
+    const int kc = li < 27 ? li / 9 : 0, kt = li < 27 ? li - kc * 9 : 0, kdy = kt / 3 - 1, kdx = kt % 3 - 1;
+    const int abase = (kc * 4 + kdy + 1) * RS + 4 + kdx;                          // + yy * RS + pixel
+    f32x16 accT, accS, corS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accT[r] = 0.f; accS[r] = 0.f; corS[r] = 0.f; }
+    for (int q = lane; q < 24; q += 64) xs[(q >> 1) * RS + ((q & 1) ? 4 + W : 3)] = 0.f;
+
+    constexpr int JD = 16 * MAXQ, JC = 4 * MAXQ;
+    f32x4 sx[12][MAXQ];
+    u32x4 sd[JD], sc_[JC];
+    const int dchunks = OW * 8, cchunks = OW * 2;
+    auto fetch = [&](int pr) {
+        const int n = pr / (H / 2), r = pr - n * (H / 2);
+        const float* fx = p.x + (size_t)n * 3 * H * W;
+#pragma unroll
+        for (int s12 = 0; s12 < 12; ++s12) {
+            const int yy = 2 * r - 1 + (s12 & 3);
+            const bool rok = yy >= 0 && yy < H;
+            const float* src = fx + ((size_t)(s12 >> 2) * H + (rok ? yy : 0)) * W;
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) {
+                const int q = lane + 64 * j;
+                sx[s12][j] = (rok && q < W4) ? *(const f32x4*)(src + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const u32x4* gd = (const u32x4*)(p.dout + ((size_t)n * (H / 2) + r) * OW * 32);
+        const u32x4* gc = (const u32x4*)(p.codes + ((size_t)n * (H / 2) + r) * OW * 32);
+#pragma unroll
+        for (int j = 0; j < JD; ++j) { const int q = lane + 64 * j; sd[j] = q < dchunks ? gd[q] : u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+        for (int j = 0; j < JC; ++j) { const int q = lane + 64 * j; sc_[j] = q < cchunks ? gc[q] : u32x4{0u, 0u, 0u, 0u}; }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int s12 = 0; s12 < 12; ++s12)
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) { const int q = lane + 64 * j; if (q < W4) *(f32x4*)&xs[s12 * RS + 4 + 4 * q] = sx[s12][j]; }
+#pragma unroll
+        for (int j = 0; j < JD; ++j) { const int q = lane + 64 * j; if (q < dchunks) ((u32x4*)ds)[q] = sd[j]; }
+#pragma unroll
+        for (int j = 0; j < JC; ++j) { const int q = lane + 64 * j; if (q < cchunks) ((u32x4*)cs)[q] = sc_[j]; }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int pr = r0; pr < r1; ++pr) {
+        store();
+        if (pr + 1 < r1) fetch(pr + 1);
+        for (int x0 = 0; x0 < W; x0 += 16) {
+            float dv[8];
+            unsigned cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                                         // the eight windows of these sixteen pixels, this lane's column
+                dv[u] = ds[(x0 / 2 + u) * 32 + li];
+                cv[u] = cs[(x0 / 2 + u) * 32 + li];
+            }
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                // T1: exact fp32, one pixel pair (= the two columns of one window) per MFMA
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float a = xs[abase + yy * RS + x0 + 2 * u + lh];
+                    if (li >= 27) a = li == 27 ? 1.f : 0.f;
+                    const float g = ((cv[u] & 3u) == (unsigned)(2 * yy + lh)) ? dv[u] * ((cv[u] & 4u) ? 1.f : 0.2f) : 0.f;
+                    accT = __builtin_amdgcn_mfma_f32_32x32x2f32(a, g, accT, 0, 0, 0);
+                }
+                // S: eight pixels per lane half, split into fp16 (hi, lo) pairs
+                unsigned hq[4], lq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a0 = xs[abase + yy * RS + x0 + 8 * lh + 2 * j], a1 = xs[abase + yy * RS + x0 + 8 * lh + 2 * j + 1];
+                    if (li >= 27) { a0 = li == 27 ? 1.f : 0.f; a1 = a0; }
+                    wg_split2_fast(a0, a1, hq[j], lq[j]);
+                }
+                const wg_f16x8 ah = wg_hfrag(hq[0], hq[1], hq[2], hq[3]), al = wg_hfrag(lq[0], lq[1], lq[2], lq[3]);
+                accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ah, accS, 0, 0, 0);
+                corS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, al, corS, 0, 0, 0);
+                corS = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ah, corS, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        p.ws[((size_t)item * 64 + k) * 32 + li] = accT[r];
+        p.ws[((size_t)item * 64 + 32 + k) * 32 + li] = fmaf(corS[r], 1.0f / 2048.0f, accS[r]);
+    }
+}
+
 // tmp[col][64]: T1[k][co] at [co][k], S[k][k'] at [k'][32 + k] (wgrad_reduce_kernel layout 4 of the [64][32] partial tiles)
 __global__ __launch_bounds__(256) void c3_routed_finalize_kernel(const float* tmp, const float* w0, const float* b0, const float* stats,
-                                                                 const float* gamma, const float* ksums, float* dw) {
+                                                                 const float* gamma, const float* ksums, float* dw, int round_w) {
     for (int idx = threadIdx.x; idx < 32 * 27; idx += 256) {
         const int co = idx / 27, k = idx - co * 27;
         const float mean = stats[co], invstd = stats[32 + co], k1 = ksums[co], k2 = ksums[32 + co];
         const float sx = tmp[27 * 64 + 32 + k];                                   // S[k][27] = SX[k]
         float ws_ = 0.f;
-        for (int kk = 0; kk < 27; ++kk) ws_ = fmaf(vad_bf16_f(vad_f_bf16(w0[co * 27 + kk])), tmp[k * 64 + 32 + kk], ws_);   // (W S)[co][k]: S[kk][k] sits at tmp[k][32 + kk]
+        for (int kk = 0; kk < 27; ++kk) {          // (W S)[co][k]: S[kk][k] sits at tmp[k][32 + kk]; W as the forward used it (bf16 operands or exact)
+            const float wv = round_w ? vad_bf16_f(vad_f_bf16(w0[co * 27 + kk])) : w0[co * 27 + kk];
+            ws_ = fmaf(wv, tmp[k * 64 + 32 + kk], ws_);
+        }
         const float v = invstd * (ws_ + (b0[co] - mean) * sx);
         dw[co * 27 + k] = gamma[co] * invstd * (tmp[co * 64 + k] - k1 * sx - k2 * v);
     }
@@ -2721,34 +2834,45 @@ extern "C" int vad_debug_set_c3_routed(int on) { g_c3_routed = on != 0; return V
 int vad_c3_routed_enabled(void) { return g_c3_routed.load(std::memory_order_relaxed); }
 int vad_conv_c3_wgrad_routed_ok(int h, int w, int cout) { return cout == 32 && h % 2 == 0 && w % 16 == 0 && w <= 1024; }
 
-int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout_bf16, const unsigned char* codes, const float* w0, const float* b0,
+int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout_bf16, int io16, const unsigned char* codes, const float* w0, const float* b0,
                              const float* stats, const float* gamma, const float* ksums, float* dw, float* ws, int n, int h, int w,
                              int cout, void* stream) {
     VAD_REQUIRE(x_nchw && dout_bf16 && codes && w0 && b0 && stats && gamma && ksums && dw && ws && n > 0, "conv_c3_wgrad_routed: bad arguments");
     VAD_REQUIRE(vad_conv_c3_wgrad_routed_ok(h, w, cout), "conv_c3_wgrad_routed: needs 32 output channels, even H, W %% 16 == 0 and W <= 1024 (got %dx%d, %d)", h, w, cout);
     WgradC3RP p{};
     p.x = x_nchw; p.dout = (const vad_bf16*)dout_bf16; p.codes = codes; p.ws = ws; p.n = n; p.h = h; p.w = w;
+    WgradC3RFP pf{};
+    pf.x = x_nchw; pf.dout = (const float*)dout_bf16; pf.codes = codes; pf.ws = ws; pf.n = n; pf.h = h; pf.w = w;
     const int total_pairs = n * (h / 2);
     p.splits = c3_routed_splits(n, h);
     p.pairs_per_split = (total_pairs + p.splits - 1) / p.splits;
     p.splits = (total_pairs + p.pairs_per_split - 1) / p.pairs_per_split;
     p.nitems = (unsigned)p.splits;
+    pf.splits = p.splits; pf.pairs_per_split = p.pairs_per_split; pf.nitems = p.nitems;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = 2 * ((size_t)12 * (w + 12) * 4 + (size_t)(w / 2) * 96);
-    VAD_REQUIRE(lds <= 64 * 1024 || w > 256, "conv_c3_wgrad_routed: internal error: %zu B of LDS", lds);
+    const size_t lds = 2 * ((size_t)12 * (w + 12) * 4 + (size_t)(w / 2) * (io16 ? 96 : 160));
+    VAD_REQUIRE(lds <= 160 * 1024, "conv_c3_wgrad_routed: frame too wide (%zu B of LDS)", lds);
     const dim3 grid((unsigned)((p.splits + 1) / 2));
-    if (w <= 256) hipLaunchKernelGGL(conv_c3_wgrad_routed_kernel<1>, grid, dim3(128), lds, s, p);
-    else {
-        static bool attr_set = false;              // > 64 KB of dynamic LDS needs the attribute once per process
-        if (!attr_set) { VAD_HIP_TRY(hipFuncSetAttribute((const void*)conv_c3_wgrad_routed_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-        VAD_REQUIRE(lds <= 160 * 1024, "conv_c3_wgrad_routed: frame too wide");
-        hipLaunchKernelGGL(conv_c3_wgrad_routed_kernel<4>, grid, dim3(128), lds, s, p);
+    // (> 64 KB of dynamic LDS needs the attribute, once per kernel and process)
+    static bool attr_set[4] = {false, false, false, false};
+    auto big = [&](int which, const void* fn) -> int {
+        if (lds > 64 * 1024 && !attr_set[which]) { VAD_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set[which] = true; }
+        return VAD_OK;
+    };
+    int rc = VAD_OK;
+    if (io16) {
+        if (w <= 256) { rc = big(0, (const void*)conv_c3_wgrad_routed_kernel<1>); if (rc == VAD_OK) hipLaunchKernelGGL(conv_c3_wgrad_routed_kernel<1>, grid, dim3(128), lds, s, p); }
+        else { rc = big(1, (const void*)conv_c3_wgrad_routed_kernel<4>); if (rc == VAD_OK) hipLaunchKernelGGL(conv_c3_wgrad_routed_kernel<4>, grid, dim3(128), lds, s, p); }
+    } else {
+        if (w <= 256) { rc = big(2, (const void*)conv_c3_wgrad_routed_f32_kernel<1>); if (rc == VAD_OK) hipLaunchKernelGGL(conv_c3_wgrad_routed_f32_kernel<1>, grid, dim3(128), lds, s, pf); }
+        else { rc = big(3, (const void*)conv_c3_wgrad_routed_f32_kernel<4>); if (rc == VAD_OK) hipLaunchKernelGGL(conv_c3_wgrad_routed_f32_kernel<4>, grid, dim3(128), lds, s, pf); }
     }
+    if (rc != VAD_OK) return rc;
     VAD_LAUNCH_CHECK();
     float* tmp = ws + (size_t)p.splits * 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((2048 + 255) / 256)), dim3(256), 0, s, (const float*)ws, p.splits, 1, 64, 32, 4, tmp);
     VAD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(c3_routed_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)tmp, w0, b0, stats, gamma, ksums, dw);
+    hipLaunchKernelGGL(c3_routed_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)tmp, w0, b0, stats, gamma, ksums, dw, io16 ? 1 : 0);
     VAD_LAUNCH_CHECK();
     return VAD_OK;
 }

@@ -538,9 +538,9 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
     for (int k = 3; k >= 0; --k) {
         const int ci = p.encC[k], co = p.encC[k + 1], hk = H >> k, wk = W >> k;
         g2 = acquire_dy();
-        // bf16 tensors: the first layer's dy has one consumer, its weight gradient, which works from the POOLED gradient and one
+        // The first layer's dy has one consumer, its weight gradient, which works from the POOLED gradient and one
         // routing byte per pooled element instead (conv_c3_wgrad_routed_kernel): pass A only, no dy (its buffer holds the bytes)
-        const bool routed = k == 0 && io && vad_c3_routed_enabled() && vad_conv_c3_wgrad_routed_ok(hk, wk, co);
+        const bool routed = k == 0 && vad_c3_routed_enabled() && vad_conv_c3_wgrad_routed_ok(hk, wk, co);
         { PS(TS_BN_BWD);
         if (routed)
             TRY(vad_bn_act_pool_bwd_codes_t(A(p.y[k]), io, ws + p.st_e[k], P + p.e_g[k], P + p.e_be[k], g0, 0, 0, 0, 0, nullptr, 0,
@@ -556,7 +556,7 @@ extern "C" int vad_vid_train_fwd_bwd(const float* x, int b, int t, int h, int w,
         TRY(wg_begin());
         if (routed) {
             PSS(TS_C3_WGRAD, wgs);
-            TRY(vad_conv_c3_wgrad_routed(x, g0, (const unsigned char*)g2, P + p.e_w[0], P + p.e_b[0], ws + p.st_e[0], P + p.e_g[0], ws + p.ksums,
+            TRY(vad_conv_c3_wgrad_routed(x, g0, io, (const unsigned char*)g2, P + p.e_w[0], P + p.e_b[0], ws + p.st_e[0], P + p.e_g[0], ws + p.ksums,
                                          G + p.e_w[0], ws + p.wgrad_ws, N, hk, wk, co, wgs));
         } else if (k == 0) {
             PSS(TS_C3_WGRAD, wgs);

@@ -175,7 +175,7 @@ SIGNATURES = {
     "vad_conv_c3_wgrad_routed_ok": (_i, [_i, _i, _i]),
     "vad_conv_c3_wgrad_routed_ws_floats": (_sz, [_i, _i]),
     "vad_bn_act_pool_bwd_codes_t": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "vad_conv_c3_wgrad_routed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vad_conv_c3_wgrad_routed": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vad_debug_set_wgrad_ring_f32": (_i, [_i]),
     "vad_debug_set_bn_wide": (_i, [_i]),
     "vad_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _vp]),
