@@ -1857,21 +1857,23 @@ __global__ __launch_bounds__(128) void conv_c3_wgrad_routed_f32_kernel(WgradC3RF
     const int H = p.h, W = p.w, OW = W / 2, RS = W + 12, W4 = W / 4;
     const int total_pairs = p.n * (H / 2);
     const int r0 = item * p.pairs_per_split, r1 = (r0 + p.pairs_per_split < total_pairs) ? r0 + p.pairs_per_split : total_pairs;
-    const size_t region = (size_t)12 * RS * 4 + (size_t)OW * 128 + (size_t)OW * 32;
-    float* xs = (float*)(dyn_lds + (size_t)wave * region);
-    const float* ds = (const float*)(dyn_lds + (size_t)wave * region + (size_t)12 * RS * 4);          // [OW][32]
-    const unsigned char* cs = dyn_lds + (size_t)wave * region + (size_t)12 * RS * 4 + (size_t)OW * 128;
+    // LDS of a wave: the 12 input rows + a row of ones + a row of zeros (taps 27 and 28..31 of the A operand read those: no
+    // select beside the MFMAs on the pipe they share).  The pooled gradient and the codes of a 16-pixel group - 8 windows x 32
+    // columns = 1 KB + 256 B, contiguous - are fetched with ONE 16-byte load per lane (+ one dword for lanes 0..63 of the codes)
+    // a group ahead and turned to the (window, column) order through a small LDS buffer (two per wave): staging the whole
+    // rows (16 KB per wave) left one wave per SIMD, per-lane dword / byte gathers were 16 load instructions per 16 MFMAs.
+    float* xs = (float*)dyn_lds + (size_t)wave * (14 * RS + 2 * 320);
+    float* gbuf = xs + 14 * RS;                                                  // [2][256 gradient floats + 64 code dwords]
     const int kc = li < 27 ? li / 9 : 0, kt = li < 27 ? li - kc * 9 : 0, kdy = kt / 3 - 1, kdx = kt % 3 - 1;
-    const int abase = (kc * 4 + kdy + 1) * RS + 4 + kdx;                          // + yy * RS + pixel
+    const int abase = li < 27 ? (kc * 4 + kdy + 1) * RS + 4 + kdx : (li == 27 ? 12 : 13) * RS + 4;     // + yy * ystep + pixel
+    const int ystep = li < 27 ? RS : 0;
     f32x16 accT, accS, corS;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accT[r] = 0.f; accS[r] = 0.f; corS[r] = 0.f; }
     for (int q = lane; q < 24; q += 64) xs[(q >> 1) * RS + ((q & 1) ? 4 + W : 3)] = 0.f;
+    for (int q = lane; q < RS; q += 64) { xs[12 * RS + q] = 1.f; xs[13 * RS + q] = 0.f; }
 
-    constexpr int JD = 16 * MAXQ, JC = 4 * MAXQ;
     f32x4 sx[12][MAXQ];
-    u32x4 sd[JD], sc_[JC];
-    const int dchunks = OW * 8, cchunks = OW * 2;
     auto fetch = [&](int pr) {
         const int n = pr / (H / 2), r = pr - n * (H / 2);
         const float* fx = p.x + (size_t)n * 3 * H * W;
@@ -1886,53 +1888,56 @@ __global__ __launch_bounds__(128) void conv_c3_wgrad_routed_f32_kernel(WgradC3RF
                 sx[s12][j] = (rok && q < W4) ? *(const f32x4*)(src + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        const u32x4* gd = (const u32x4*)(p.dout + ((size_t)n * (H / 2) + r) * OW * 32);
-        const u32x4* gc = (const u32x4*)(p.codes + ((size_t)n * (H / 2) + r) * OW * 32);
-#pragma unroll
-        for (int j = 0; j < JD; ++j) { const int q = lane + 64 * j; sd[j] = q < dchunks ? gd[q] : u32x4{0u, 0u, 0u, 0u}; }
-#pragma unroll
-        for (int j = 0; j < JC; ++j) { const int q = lane + 64 * j; sc_[j] = q < cchunks ? gc[q] : u32x4{0u, 0u, 0u, 0u}; }
     };
     auto store = [&]() {
 #pragma unroll
         for (int s12 = 0; s12 < 12; ++s12)
 #pragma unroll
             for (int j = 0; j < MAXQ; ++j) { const int q = lane + 64 * j; if (q < W4) *(f32x4*)&xs[s12 * RS + 4 + 4 * q] = sx[s12][j]; }
-#pragma unroll
-        for (int j = 0; j < JD; ++j) { const int q = lane + 64 * j; if (q < dchunks) ((u32x4*)ds)[q] = sd[j]; }
-#pragma unroll
-        for (int j = 0; j < JC; ++j) { const int q = lane + 64 * j; if (q < cchunks) ((u32x4*)cs)[q] = sc_[j]; }
     };
     if (r0 < r1) fetch(r0);
     for (int pr = r0; pr < r1; ++pr) {
         store();
         if (pr + 1 < r1) fetch(pr + 1);
+        const f32x4* drow = (const f32x4*)(p.dout + (size_t)pr * OW * 32);           // (pr = n * (H/2) + r: the pooled rows are contiguous)
+        const unsigned* crow = (const unsigned*)(p.codes + (size_t)pr * OW * 32);
+        f32x4 dq;
+        unsigned cq;
+        auto load_g = [&](int x0) {
+            const int xc = x0 < W ? x0 : 0;                                      // (behind the last group: group 0 again, unused)
+            dq = drow[(xc / 2) * 8 + lane];                                      // windows xc/2 .. xc/2+7: [8][32] floats = 64 lanes x 16 bytes
+            cq = crow[(xc / 2) * 8 + lane];                                      // their codes: [8][32] bytes = 64 dwords
+        };
+        load_g(0);
+        int gb = 0;
         for (int x0 = 0; x0 < W; x0 += 16) {
-            float dv[8];
-            unsigned cv[8];
+            float* gq = gbuf + gb * 320;
+            *(f32x4*)&gq[4 * lane] = dq;                                         // (the buffer's last readers - two groups ago - are behind in program order)
+            ((unsigned*)gq)[256 + lane] = cq;
+            load_g(x0 + 16);
+            float gs[8];
+            unsigned cm[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {                                         // the eight windows of these sixteen pixels, this lane's column
-                dv[u] = ds[(x0 / 2 + u) * 32 + li];
-                cv[u] = cs[(x0 / 2 + u) * 32 + li];
+            for (int u = 0; u < 8; ++u) {
+                const unsigned c = ((const unsigned char*)(gq + 256))[u * 32 + li];
+                gs[u] = gq[u * 32 + li] * ((c & 4u) ? 1.f : 0.2f);
+                cm[u] = c & 3u;
             }
+            gb ^= 1;
 #pragma unroll
             for (int yy = 0; yy < 2; ++yy) {
                 // T1: exact fp32, one pixel pair (= the two columns of one window) per MFMA
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    float a = xs[abase + yy * RS + x0 + 2 * u + lh];
-                    if (li >= 27) a = li == 27 ? 1.f : 0.f;
-                    const float g = ((cv[u] & 3u) == (unsigned)(2 * yy + lh)) ? dv[u] * ((cv[u] & 4u) ? 1.f : 0.2f) : 0.f;
+                    const float a = xs[abase + yy * ystep + x0 + 2 * u + lh];
+                    const float g = cm[u] == (unsigned)(2 * yy + lh) ? gs[u] : 0.f;
                     accT = __builtin_amdgcn_mfma_f32_32x32x2f32(a, g, accT, 0, 0, 0);
                 }
                 // S: eight pixels per lane half, split into fp16 (hi, lo) pairs
                 unsigned hq[4], lq[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a0 = xs[abase + yy * RS + x0 + 8 * lh + 2 * j], a1 = xs[abase + yy * RS + x0 + 8 * lh + 2 * j + 1];
-                    if (li >= 27) { a0 = li == 27 ? 1.f : 0.f; a1 = a0; }
-                    wg_split2_fast(a0, a1, hq[j], lq[j]);
-                }
+                for (int j = 0; j < 4; ++j)
+                    wg_split2_fast(xs[abase + yy * ystep + x0 + 8 * lh + 2 * j], xs[abase + yy * ystep + x0 + 8 * lh + 2 * j + 1], hq[j], lq[j]);
                 const wg_f16x8 ah = wg_hfrag(hq[0], hq[1], hq[2], hq[3]), al = wg_hfrag(lq[0], lq[1], lq[2], lq[3]);
                 accS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ah, accS, 0, 0, 0);
                 corS = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, al, corS, 0, 0, 0);
@@ -2850,7 +2855,7 @@ int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout_bf16, int io1
     p.nitems = (unsigned)p.splits;
     pf.splits = p.splits; pf.pairs_per_split = p.pairs_per_split; pf.nitems = p.nitems;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = 2 * ((size_t)12 * (w + 12) * 4 + (size_t)(w / 2) * (io16 ? 96 : 160));
+    const size_t lds = io16 ? 2 * ((size_t)12 * (w + 12) * 4 + (size_t)(w / 2) * 96) : 2 * ((size_t)14 * (w + 12) + 640) * 4;
     VAD_REQUIRE(lds <= 160 * 1024, "conv_c3_wgrad_routed: frame too wide (%zu B of LDS)", lds);
     const dim3 grid((unsigned)((p.splits + 1) / 2));
     // (> 64 KB of dynamic LDS needs the attribute, once per kernel and process)
