@@ -108,6 +108,23 @@ def driver(pack_path: str, oracle_path: str) -> None:
             checked += 1
         assert L.vad_vid_pack(_ptrs(params), len(params), lat, hid, layers + 1, 0, _vp(blob)) < 0
     assert L.vad_vid_packed_floats(128, 128, 9) == 0 and L.vad_img_packed_floats(3, 0) == 0
+    # models with more than 3 input planes (round 4: generic first / last layer slots, planes padded to 32)
+    L.vad_vid_packed_floats_c.restype = C.c_size_t
+    g = np.load(gold / "img_c5_l32_32.npz")
+    params, latent, cin = _float_params(_golden_state(synth, g)), int(g["latent_dim"]), int(g["in_channels"])
+    for prec in (0, 1, 4):
+        blob = np.full(L.vad_img_packed_floats(cin, latent), np.nan, np.float32)
+        assert L.vad_img_pack(_ptrs(params), len(params), cin, latent, prec, _vp(blob)) == 0, L.vad_last_error()
+        checked += 1
+    assert L.vad_img_packed_floats(33, latent) == 0 and L.vad_img_pack(_ptrs(params), len(params), 2, latent, 0, _vp(blob)) < 0
+    g = np.load(gold / "vid_c4_l32_32.npz")
+    params, cin = _float_params(_golden_state(synth, g)), int(g["in_channels"])
+    lat, hid, layers = int(g["latent_dim"]), int(g["hid"]), int(g["layers"])
+    for prec in (0, 1, 4):
+        blob = np.full(L.vad_vid_packed_floats_c(cin, lat, hid, layers), np.nan, np.float32)
+        assert L.vad_vid_pack_c(_ptrs(params), len(params), cin, lat, hid, layers, prec, _vp(blob)) == 0, L.vad_last_error()
+        checked += 1
+    assert L.vad_vid_packed_floats_c(33, lat, hid, layers) == 0
     # single-layer packers, odd-but-legal shapes
     rng = np.random.default_rng(0)
     for cout, cin in ((32, 32), (64, 48), (96, 8)):

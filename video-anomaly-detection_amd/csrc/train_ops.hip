@@ -2859,9 +2859,12 @@ int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout_bf16, int io1
     VAD_REQUIRE(lds <= 160 * 1024, "conv_c3_wgrad_routed: frame too wide (%zu B of LDS)", lds);
     const dim3 grid((unsigned)((p.splits + 1) / 2));
     // (> 64 KB of dynamic LDS needs the attribute, once per kernel and process)
-    static bool attr_set[4] = {false, false, false, false};
+    static std::atomic<bool> attr_set[4];        // (setting it twice from two threads is harmless; one process per GPU)
     auto big = [&](int which, const void* fn) -> int {
-        if (lds > 64 * 1024 && !attr_set[which]) { VAD_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set[which] = true; }
+        if (lds > 64 * 1024 && !attr_set[which].load(std::memory_order_acquire)) {
+            VAD_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[which].store(true, std::memory_order_release);
+        }
         return VAD_OK;
     };
     int rc = VAD_OK;
