@@ -194,7 +194,7 @@ def test_conv1x1_on_bf16_tensors(vad, npix, cin, cout):
     assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-5).all()), float(err.max())
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 32, 48), (5, 12, 80), (2, 64, 256)])
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 32, 48), (5, 12, 80), (2, 64, 256), (1, 8, 272), (1, 4, 768)])
 def test_routed_first_layer_weight_gradient(vad, n, h, w):
     """Round 4: the bf16-tensor step forms the first layer's weight gradient from the POOLED gradient, one routing byte per pooled
     element and the Gram matrix of the input patches (csrc/train_ops.hip conv_c3_wgrad_routed_kernel) instead of writing the dense

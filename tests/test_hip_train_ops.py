@@ -235,7 +235,7 @@ def test_convt2x2_weight_and_data_gradients(vad, n, h, w, cin, cout, precision):
     _check_convt2x2_gradients(vad, n, h, w, cin, cout, precision)
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 32, 48), (5, 12, 80), (2, 64, 256), (1, 8, 272)])
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 32, 48), (5, 12, 80), (2, 64, 256), (1, 8, 272), (1, 4, 768)])
 def test_routed_first_layer_weight_gradient_fp32(vad, n, h, w):
     """fp32 form of the routed first-layer weight gradient (csrc/train_ops.hip conv_c3_wgrad_routed_f32_kernel; the bf16 form:
     tests/test_hip_train_bf16.py): dW of Conv2d(3->32) + BatchNorm(batch statistics) + LeakyReLU(0.2) + MaxPool2 from the POOLED

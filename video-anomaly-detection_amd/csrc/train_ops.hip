@@ -2837,13 +2837,14 @@ size_t vad_conv_c3_wgrad_routed_ws_floats(int n, int h) {
 static std::atomic<int> g_c3_routed{1};          // debug / A-B: 0 = BatchNorm backward pass B + the plain first-layer weight gradient (rounds 1-3)
 extern "C" int vad_debug_set_c3_routed(int on) { g_c3_routed = on != 0; return VAD_OK; }
 int vad_c3_routed_enabled(void) { return g_c3_routed.load(std::memory_order_relaxed); }
-int vad_conv_c3_wgrad_routed_ok(int h, int w, int cout) { return cout == 32 && h % 2 == 0 && w % 16 == 0 && w <= 1024; }
+// (w <= 768: two waves' input rows + gradient row + codes fit the 160 KB of LDS in both forms; wider frames take pass B + the plain kernel)
+int vad_conv_c3_wgrad_routed_ok(int h, int w, int cout) { return cout == 32 && h % 2 == 0 && w % 16 == 0 && w <= 768; }
 
 int vad_conv_c3_wgrad_routed(const float* x_nchw, const void* dout_bf16, int io16, const unsigned char* codes, const float* w0, const float* b0,
                              const float* stats, const float* gamma, const float* ksums, float* dw, float* ws, int n, int h, int w,
                              int cout, void* stream) {
     VAD_REQUIRE(x_nchw && dout_bf16 && codes && w0 && b0 && stats && gamma && ksums && dw && ws && n > 0, "conv_c3_wgrad_routed: bad arguments");
-    VAD_REQUIRE(vad_conv_c3_wgrad_routed_ok(h, w, cout), "conv_c3_wgrad_routed: needs 32 output channels, even H, W %% 16 == 0 and W <= 1024 (got %dx%d, %d)", h, w, cout);
+    VAD_REQUIRE(vad_conv_c3_wgrad_routed_ok(h, w, cout), "conv_c3_wgrad_routed: needs 32 output channels, even H, W %% 16 == 0 and W <= 768 (got %dx%d, %d)", h, w, cout);
     WgradC3RP p{};
     p.x = x_nchw; p.dout = (const vad_bf16*)dout_bf16; p.codes = codes; p.ws = ws; p.n = n; p.h = h; p.w = w;
     WgradC3RFP pf{};
